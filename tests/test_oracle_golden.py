@@ -1,0 +1,91 @@
+"""oracle/futr_oracle.py against the fixtures generated from the imported reference
+(tests/golden/make_golden.py).  CPU only; this is what pins the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import futr_oracle as O
+from tests.helpers import load_fixture, fixture_params, fixture_batch, stats, assert_close
+
+def check_stats(got, ref, rtol=1e-4):
+    """[norm, sum, abs-sum, 16 first, 16 strided] rows: the plain sum cancels, so it is judged against abs-sum."""
+    assert_close(got[:, 0], ref[:, 0], rtol, 1e-7, "norm")
+    assert_close(got[:, 2], ref[:, 2], rtol, 1e-7, "abs-sum")
+    assert bool((np.abs(got[:, 1] - ref[:, 1]) <= rtol * ref[:, 2] + 1e-7).all()), "sum"
+    scale = np.abs(ref[:, 3:]).max(axis=1, keepdims=True)
+    assert bool((np.abs(got[:, 3:] - ref[:, 3:]) <= 10 * rtol * scale + 1e-7).all()), "samples"
+
+
+STEP_CASES = ["step_tiny", "step_cfg2", "step_cfg2_zm", "step_k122_dec2"]
+
+
+@pytest.mark.parametrize("tag", STEP_CASES)
+def test_step_matches_reference(tag, oracle_lib):
+    fx = load_fixture(tag)
+    m = fx["meta"]
+    tr = O.CpuTrainer(fixture_params(fx), m["pad_idx"], m["n_head"], m["n_dec"], m["lr"], m["wd"])
+    res, out, aux = tr.step(fixture_batch(fx), apply=False)
+    assert_close(out["action"], fx["out_action"], 1e-4, 1e-5, "action")
+    assert_close(out["duration"], fx["out_duration"], 1e-4, 1e-5, "duration")
+    assert_close(out["seg"], fx["out_seg"], 1e-4, 1e-5, "seg")
+    assert_close(aux["fused"], fx["fused"], 1e-4, 1e-5, "fused")
+    assert np.array_equal(np.sort(aux["idx_rgb"].numpy()), fx["idx_rgb"])
+    assert np.array_equal(np.sort(aux["idx_dep"].numpy()), fx["idx_dep"])
+    got = [float(res[k]) for k in ("loss_seg", "loss_action", "loss_dur", "loss")]
+    assert_close(got, fx["losses"], 1e-5, 1e-6, "losses")
+    assert [res[k] for k in ("seg_correct", "seg_total", "act_correct", "act_total")] == fx["counts"].tolist()
+    assert abs(O.effective_rank(aux["fused"].detach().reshape(-1, m["H"])) - float(fx["erank_fused"][0])) < 1e-3
+    live = fx["live_names"]
+    assert sorted(live) == sorted(n for n, q in tr.p.items() if q.grad is not None)
+    gs = np.stack([stats(tr.p[n].grad) for n in live])
+    check_stats(gs, fx["grad_stats"])
+    for k in fx:
+        if k.startswith("grad::") and k not in ("grad::pos_embedding[:S]", "grad::qkv_qk_absmax"):
+            assert_close(tr.p[k[6:]].grad, fx[k], 1e-3, 1e-6, k)
+    assert float(tr.p["fuser.blocks.0.attn.qkv.weight"].grad[:2 * m["H"]].abs().max()) == 0.0 == float(fx["grad::qkv_qk_absmax"][0])
+    # one AdamW step: norms move by <= lr*sqrt(numel) when gradients are noise, so compare loosely
+    tr.t += 1
+    with torch.no_grad():
+        for n in live:
+            O.adamw_step(tr.p[n], tr.p[n].grad, tr.m[n], tr.v[n], tr.t, m["lr"], m["wd"])
+    ps = np.stack([stats(tr.p[n]) for n in live])
+    for i, n in enumerate(live):
+        numel = tr.p[n].numel()
+        well = float(fx["post_well_frac"][i])
+        tol = 2e-5 * np.sqrt(numel) + (1.0 - well) * 2.1 * m["lr"] * np.sqrt(numel)
+        assert abs(ps[i, 0] - fx["post_stats"][i, 0]) <= tol + 1e-5 * fx["post_stats"][i, 0], n
+    assert bool(fx["dead_unchanged"].all())
+
+
+@pytest.mark.parametrize("tag", ["val_h128", "val_h64"])
+def test_val_mode_matches_reference(tag, oracle_lib):
+    fx = load_fixture(tag)
+    m = fx["meta"]
+    feats, depth, lab, dur, tgt = fixture_batch(fx, pad_tail=False)
+    with torch.no_grad():
+        out, aux = O.forward(fixture_params(fx), (feats, lab), depth, "val", m["pad_idx"], m["n_head"], m["n_dec"])
+    assert_close(out["action"], fx["out_action"], 1e-4, 1e-5, "action")
+    assert_close(out["duration"], fx["out_duration"], 1e-4, 1e-5, "duration")
+    assert_close(out["seg"], fx["out_seg"], 1e-4, 1e-5, "seg")
+    assert np.array_equal(np.sort(aux["idx_rgb"].numpy()), fx["idx_rgb"])
+    assert np.array_equal(np.sort(aux["idx_dep"].numpy()), fx["idx_dep"])
+    assert_close(aux["score_rgb"], fx["score_rgb"], 1e-5, 1e-7, "score_rgb")
+
+
+def test_train_loop_matches_reference(oracle_lib):
+    fx = load_fixture("train_loop")
+    m = fx["meta"]
+    tr = O.CpuTrainer(fixture_params(fx), m["pad_idx"], m["n_head"], 1, m["lr"], m["wd"])
+    for i in range(m["n_steps"]):
+        res, _, _ = tr.step(fixture_batch(fx, seed=m["seed"] + i))
+        assert_close([float(res["loss_seg"]), float(res["loss_action"])], fx["step_losses"][i], 1e-5, 1e-6, f"step{i}")
+        ps = np.stack([stats(tr.p[n]) for n in fx["live_names"]])
+        assert_close(ps[:, 0], fx["post_stats"][i][:, 0], 1e-3, 1e-3, f"post-step norms {i}")
+    assert fx["ckpt_files"] == ["seed_1_best.ckpt", "seed_1_checkpoint0.ckpt"]
+
+
+def test_scheduler_restatement_shape():
+    # PARITY UNPINNED (pl_bolts absent): only the published closed form's landmarks are checked.
+    lrs = [O.warmup_cosine_lr(e, 1e-3, 10, 60) for e in range(60)]
+    assert lrs[0] == 0.0 and abs(lrs[9] - 1e-3) < 1e-12 and abs(lrs[10] - 1e-3) < 1e-12
+    assert all(lrs[i] >= lrs[i + 1] for i in range(10, 59)) and lrs[59] > 0
