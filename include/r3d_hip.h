@@ -1,0 +1,173 @@
+/* libr3d_hip.so -- C ABI of the MI355X (gfx950) kernels behind R3D's RGB+Depth token-fusion training step.
+ *
+ * The reference (olivesgatech/R3D) is pure Python on stock PyTorch ops and has NO FFI / plugin API of its own
+ * (SURVEY.md F3, 8(b)); every entry point below therefore replaces an ATen op *sequence* of the reference and cites
+ * the reference lines it stands in for (paths relative to the reference root).  The host side that calls them
+ * (r3d_amd/engine.py via ctypes) mirrors the reference's Python surface (FUTR / train / opts); INTEGRATION.md shows
+ * the binding a maintainer would add.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers and sizes, no torch types; every pointer is DEVICE memory owned by the caller
+ *     (PyTorch's caching allocator in practice), fp32 unless stated, row-major with explicit leading dimensions;
+ *   - `stream` is a hipStream_t (pass torch.cuda.current_stream().cuda_stream); work is only ENQUEUED on it:
+ *     no device synchronisation, no device allocation, no host<->device copies, no mutable globals
+ *     -> safe under hipGraph capture and from autograd's backward thread (one process per GPU);
+ *   - return 0 on success, a negative R3D_E* code for a rejected argument, or the positive hipError_t of a failed launch;
+ *   - rows of activations are ordered (clip b, frame s) b-major: row = b*S + s.  The reference's seq-first [S,B,H]
+ *     tensors (model/futr_safuser_tokenfusion.py:201-204) are the same data indexed the other way round.
+ */
+#ifndef R3D_HIP_H
+#define R3D_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define R3D_ABI_VERSION 1
+
+/* ---- error codes ---------------------------------------------------------------------------------------- */
+#define R3D_OK 0
+#define R3D_EINVAL (-1)
+#define R3D_EALIGN (-2)
+
+int r3d_abi_version(void);
+/* Writes up to `cap` bytes "gfx950;<build info>" -- used by the host to fail loudly on a stale library. */
+int r3d_build_info(char* buf, int cap);
+
+/* ---- GEMM family ------------------------------------------------------------------------------------------
+ * One fp32-exact MFMA GEMM (v_mfma_f32_32x32x2_f32, LDS-staged k-major tiles) carries every dense contraction of
+ * the step: nn.Linear forward  (layout NT: model/futr_safuser_tokenfusion.py:179,195,222-231;
+ * model/extras/transformerblock.py:21,34,84-88; nn.MultiheadAttention in/out projections and FFN of
+ * model/extras/transformer.py:289-327), its input gradient (NN) and its weight gradient (TN) -- the ops autograd
+ * derives for the reference at train/train_proposed_depth.py:214.
+ *
+ *   layout R3D_GEMM_NT: C[M,N] = A[M,K] . B[N,K]^T      (A rows lda, B rows ldb; both K-contiguous)
+ *   layout R3D_GEMM_NN: C[M,N] = A[M,K] . B[K,N]
+ *   layout R3D_GEMM_TN: C[M,N] = A[K,M]^T . B[K,N]
+ *
+ * Prologue on A (NT/NN only): row m is read from row (m ^ a_row_xor) and, if a_add != NULL,
+ *   A'[m,k] = A[m^xor,k] + a_add[(m % a_add_mod), k]   (broadcast add of positional / query embeddings,
+ *   model/extras/transformer.py:289,300-302).
+ * Epilogue, in this order:  v = alpha*acc (+ bias[n]);  pre_out[m,n] = v (if given);
+ *   act: 0 none | 1 relu | 2 exact-erf gelu;  v *= drop_scale*drop_mask[m,n] (if given);
+ *   mul: 0 none | 1 v *= (aux[m,n] > 0) | 2 v *= gelu'(aux[m,n])         (backward of relu / gelu);
+ *   v += res1[m,n] + res2[m,n] (if given);  if (accumulate) v += C[m,n];  C[m,n] = v.
+ * splitk > 1: the K range is cut into `splitk` slabs of k_per_split (multiple of 16); raw partial sums go to
+ *   `partial` ([splitk][M][N] floats, caller-owned) and r3d_splitk_reduce*() applies the epilogue.
+ */
+#define R3D_GEMM_NT 0
+#define R3D_GEMM_NN 1
+#define R3D_GEMM_TN 2
+
+typedef struct r3d_gemm_desc {
+    const float* A; const float* B; float* C;
+    int32_t layout, M, N, K;
+    int32_t lda, ldb, ldc;
+    const float* a_add; int32_t a_add_mod, a_add_ld, a_row_xor;
+    const float* bias;
+    float* pre_out; int32_t ldpre;
+    int32_t act;
+    const uint8_t* drop_mask; int32_t lddrop; float drop_scale;
+    const float* aux; int32_t ldaux, mul;
+    const float* res1; int32_t ldr1;
+    const float* res2; int32_t ldr2;
+    float alpha; int32_t accumulate;
+    int32_t splitk, k_per_split; float* partial;
+    int32_t tile;            /* 0 = auto; 1 = 32x32, 2 = 64x64, 3 = 128x128 workgroup tile (testing / tuning) */
+} r3d_gemm_desc;
+
+int r3d_gemm_f32(const r3d_gemm_desc* d, void* stream);
+/* Sums the split-K slabs of a previous r3d_gemm_f32(d with splitk>1) and applies d's epilogue. */
+int r3d_splitk_reduce(const r3d_gemm_desc* d, void* stream);
+/* Workspace floats r3d_gemm_f32 needs in d->partial for this (M,N,splitk). */
+int64_t r3d_gemm_partial_floats(int32_t M, int32_t N, int32_t splitk);
+/* Heuristic the host uses to pick (tile, splitk, k_per_split) for a shape on a 256-CU part; fills the desc. */
+int r3d_gemm_plan(r3d_gemm_desc* d);
+
+/* ---- row-wise kernels ---------------------------------------------------------------------------------------
+ * LayerNorm (eps 1e-5, biased variance, affine): depth_layernorm (model/futr_safuser_tokenfusion.py:147,196),
+ * Block.norm1/norm2 (model/extras/transformerblock.py:122,127,131-134), fuser.norm (:25,93), decoder norm1/2/3 and
+ * decoder.norm (model/extras/transformer.py:265-267,292-329,182-183).
+ *
+ * r3d_layernorm_fwd: y = act(LN(x)), saves mean/rstd per row.
+ *   nsplit > 0: x is the [nsplit][rows][H] split-K slab buffer of r3d_gemm_f32; the slabs are summed, `bias` added and
+ *     the sum (the nn.Linear output) stored to pre_out before normalising -- fuses depth_projection's reduction with
+ *     depth_layernorm + ReLU (:195-197).
+ *   pair_out != NULL: rows come in (token, modality) pairs and pair_out[n] = (y[2n] + y[2n+1]) / 2, the
+ *     torch.mean(x, dim=1) over the two modality tokens (:94).
+ * r3d_layernorm_bwd: dx = LN'(dy) [+ add1 + add2]; dgamma/dbeta written (not accumulated).
+ *   pair_in: dy holds one row per pair and each row of the pair receives dy/2 (backward of the mean above);
+ *   relu: dy is first masked by [LN(x) > 0] (recomputed);  dx2 (optional) = dx * drop_scale * drop_mask;
+ *   ws: r3d_layernorm_bwd_ws_floats(rows, H) floats of scratch (0 when rows <= 64).
+ */
+int r3d_layernorm_fwd(const float* x, int ldx, int nsplit, const float* bias, float* pre_out, const float* gamma,
+                      const float* beta, float* y, int ldy, float* mean, float* rstd, float* pair_out, int rows, int H,
+                      int relu, void* stream);
+int64_t r3d_layernorm_bwd_ws_floats(int rows, int H);
+int r3d_layernorm_bwd(const float* dy, int lddy, int pair_in, const float* x, int ldx, const float* mean,
+                      const float* rstd, const float* gamma, const float* beta, int relu, const float* add1, int ldadd1,
+                      const float* add2, int ldadd2, float* dx, int lddx, float* dx2, int lddx2,
+                      const uint8_t* drop_mask, int lddrop, float drop_scale, float* dgamma, float* dbeta, float* ws,
+                      int rows, int H, void* stream);
+/* out[c] (+)= sum_r x[r,c]: bias gradients.  ws: r3d_colsum_ws_floats(rows, cols) floats. */
+int64_t r3d_colsum_ws_floats(int rows, int cols);
+int r3d_colsum(const float* x, int ld, int rows, int cols, float* out, float* ws, int accumulate, void* stream);
+/* out[r,c] (+)= sum over rows with row % mod == r: gradients of query_embed / pos_embedding, which the forward
+ * broadcasts over clips (model/futr_safuser_tokenfusion.py:190,205-209). */
+int r3d_rowmod_sum(const float* x, int ld, int rows, int cols, int mod, float* out, int ldo, int accumulate,
+                   void* stream);
+
+/* ---- token selection / exchange: CMFuser.token_fusion (model/futr_safuser_tokenfusion.py:33-66) ------------- */
+/* out[c] = sum_r |x[r,c]| in fp64 (the eval-mode score before the division by B*T, :49-50). */
+int r3d_colabssum(const float* x, int ld, int rows, int cols, double* out, void* stream);
+/* k smallest of nvec score vectors of length C (torch.topk(..., largest=False) on CPU, :52-54), bit-exact as a SET
+ * including ties (libstdc++ introselect emulation when the k-th boundary cuts a group of equal scores).
+ * idx_out [nvec][k] ascending; mask_out [nvec][C] 1.0/0.0 (optional); used_serial [nvec] (optional diagnostics). */
+int r3d_token_select(const float* score_f, const double* score_sum, double count, int nvec, int C, int k,
+                     int64_t* idx_out, float* mask_out, int* used_serial, void* stream);
+/* x0[2n] = mask_rgb ? dep[n] : rgb[n];  x0[2n+1] = mask_dep ? rgb[n] : dep[n]; then embd_drop (:56-62, :83). */
+int r3d_token_exchange_fwd(const float* rgb, const float* dep, const float* mask_rgb, const float* mask_dep, float* x0,
+                           const uint8_t* drop_mask, float drop_scale, int N, int H, void* stream);
+/* d_rgb_pre = ((1-mask_rgb) g[2n] + mask_dep g[2n+1]) * [rgb > 0];  d_dep = mask_rgb g[2n] + (1-mask_dep) g[2n+1]. */
+int r3d_token_exchange_bwd(const float* dx0, const float* rgb, const float* mask_rgb, const float* mask_dep,
+                           const uint8_t* drop_mask, float drop_scale, float* d_rgb_pre, float* d_dep, int N, int H,
+                           void* stream);
+
+/* ---- decoder attention core: nn.MultiheadAttention minus its projections (model/extras/transformer.py:289-304) --
+ * q rows b*Lq+i, k/v rows b*Lk+j, head h in columns [h*dh, (h+1)*dh).  probs [B][heads][Lq][Lk] = softmax before
+ * dropout (saved for backward).  key_padding_mask [B][Lk] (1 = padded) or NULL.  drop_mask like probs or NULL. */
+int r3d_mha_core_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                     const uint8_t* key_padding_mask, float* probs, const uint8_t* drop_mask, float drop_scale, float* o,
+                     int ldo, int B, int heads, int Lq, int Lk, int dh, void* stream);
+int r3d_mha_core_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* probs,
+                     const uint8_t* drop_mask, float drop_scale, const float* d_o, int lddo, float* dq, int lddq, float* dk,
+                     int lddk, float* dv, int lddv, int B, int heads, int Lq, int Lk, int dh, void* stream);
+
+/* ---- losses: utils.py:325-328,358-378,410-490 as composed at train/train_proposed_depth.py:171-213 ------------- */
+int r3d_losses_fwd_bwd(const float* seg_logits, int ld_seg, const float* act_logits, int ld_act, const float* dur,
+                       int ld_dur, const int64_t* past_label, const int64_t* target, const float* target_dur, int B, int S,
+                       int Q, int K, int pad_idx, int exclude_idx, int val_mode, const float* dur_den, float grad_scale,
+                       float* d_seg, int ld_dseg, float* d_act, int ld_dact, float* d_dur, int ld_ddur, float* loss_out,
+                       int64_t* counts, void* stream);
+
+/* ---- optimiser / dropout masks: main_darai.py:135, train/train_proposed_depth.py:215 -------------------------- */
+/* torch.optim.AdamW semantics over flat arenas of n floats (n % 4 == 0, 16-byte aligned); g is multiplied by
+ * grad_scale first (1/world after a sum all-reduce).  lr and the 1-based step are read from device memory. */
+int r3d_adamw_flat(float* p, const float* g, float* m, float* v, int64_t n, const float* lr, const int64_t* step,
+                   float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream);
+/* mask[i] = 1 with probability 1-p (Philox4x32-10 keyed by seed, counter (i/4, *offset)). */
+int r3d_dropout_mask(uint8_t* mask, int64_t n, float p, uint64_t seed, const int64_t* offset, void* stream);
+
+/* ---- effective rank (build-side) ------------------------------------------------- */
+int64_t r3d_erank_lds_bytes(int R, int C);
+int r3d_erank_jacobi(const float* x, int ld, int64_t batch_stride, int batch, int R, int C, int gram, float* sigma,
+                     float* af_t, float* stats, int max_sweeps, void* stream);
+int r3d_erank_bwd_coef(const float* sigma, const float* stats, const float* gout, float* coef, int C, void* stream);
+int r3d_scale_rows(float* x, int ld, int rows, int cols, const float* coef, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* R3D_HIP_H */

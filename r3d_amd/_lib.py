@@ -1,0 +1,112 @@
+"""ctypes binding of libr3d_hip.so (include/r3d_hip.h).  There is NO fallback: if the library is missing or stale
+the import of the compute path fails loudly -- the product never runs on a CPU/PyTorch substitute."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "_build", "libr3d_hip.so")
+ABI_VERSION = 1
+
+c_float_p = C.c_void_p      # raw device addresses travel as integers (tensor.data_ptr())
+
+
+class GemmDesc(C.Structure):
+    """struct r3d_gemm_desc (include/r3d_hip.h)."""
+    _fields_ = [
+        ("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p),
+        ("layout", C.c_int32), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32),
+        ("a_add", C.c_void_p), ("a_add_mod", C.c_int32), ("a_add_ld", C.c_int32), ("a_row_xor", C.c_int32),
+        ("bias", C.c_void_p),
+        ("pre_out", C.c_void_p), ("ldpre", C.c_int32),
+        ("act", C.c_int32),
+        ("drop_mask", C.c_void_p), ("lddrop", C.c_int32), ("drop_scale", C.c_float),
+        ("aux", C.c_void_p), ("ldaux", C.c_int32), ("mul", C.c_int32),
+        ("res1", C.c_void_p), ("ldr1", C.c_int32),
+        ("res2", C.c_void_p), ("ldr2", C.c_int32),
+        ("alpha", C.c_float), ("accumulate", C.c_int32),
+        ("splitk", C.c_int32), ("k_per_split", C.c_int32), ("partial", C.c_void_p),
+        ("tile", C.c_int32),
+    ]
+
+
+GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
+
+_I, _L, _F, _P, _D = C.c_int, C.c_int64, C.c_float, C.c_void_p, C.c_double
+
+_SIGNATURES = {
+    "r3d_abi_version": ([], C.c_int),
+    "r3d_build_info": ([C.c_char_p, _I], C.c_int),
+    "r3d_gemm_f32": ([C.POINTER(GemmDesc), _P], C.c_int),
+    "r3d_splitk_reduce": ([C.POINTER(GemmDesc), _P], C.c_int),
+    "r3d_gemm_partial_floats": ([C.c_int32, C.c_int32, C.c_int32], C.c_int64),
+    "r3d_gemm_plan": ([C.POINTER(GemmDesc)], C.c_int),
+    "r3d_layernorm_fwd": ([_P, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P], C.c_int),
+    "r3d_layernorm_bwd_ws_floats": ([_I, _I], C.c_int64),
+    "r3d_layernorm_bwd": ([_P, _I, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _F,
+                           _P, _P, _P, _I, _I, _P], C.c_int),
+    "r3d_colsum_ws_floats": ([_I, _I], C.c_int64),
+    "r3d_colsum": ([_P, _I, _I, _I, _P, _P, _I, _P], C.c_int),
+    "r3d_rowmod_sum": ([_P, _I, _I, _I, _I, _P, _I, _I, _P], C.c_int),
+    "r3d_colabssum": ([_P, _I, _I, _I, _P, _P], C.c_int),
+    "r3d_token_select": ([_P, _P, _D, _I, _I, _I, _P, _P, _P, _P], C.c_int),
+    "r3d_token_exchange_fwd": ([_P, _P, _P, _P, _P, _P, _F, _I, _I, _P], C.c_int),
+    "r3d_token_exchange_bwd": ([_P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _P], C.c_int),
+    "r3d_mha_core_fwd": ([_P, _I, _P, _I, _P, _I, _P, _P, _P, _F, _P, _I, _I, _I, _I, _I, _I, _P], C.c_int),
+    "r3d_mha_core_bwd": ([_P, _I, _P, _I, _P, _I, _P, _P, _F, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
+                         C.c_int),
+    "r3d_losses_fwd_bwd": ([_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _F, _P, _I, _P, _I,
+                            _P, _I, _P, _P, _P], C.c_int),
+    "r3d_adamw_flat": ([_P, _P, _P, _P, _L, _P, _P, _F, _F, _F, _F, _F, _P], C.c_int),
+    "r3d_dropout_mask": ([_P, _L, _F, C.c_uint64, _P, _P], C.c_int),
+    "r3d_erank_lds_bytes": ([_I, _I], C.c_int64),
+    "r3d_erank_jacobi": ([_P, _I, _L, _I, _I, _I, _I, _P, _P, _P, _I, _P], C.c_int),
+    "r3d_erank_bwd_coef": ([_P, _P, _P, _P, _I, _P], C.c_int),
+    "r3d_scale_rows": ([_P, _I, _I, _I, _P, _P], C.c_int),
+}
+
+EXPORTS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+class R3DHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes library.  Raises R3DHipError with build instructions if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise R3DHipError(
+            f"{LIB_PATH} is missing: the HIP kernels are the only compute path of r3d_amd (no CPU/PyTorch fallback). "
+            f"Build it with `python -m r3d_amd.build` (needs hipcc; cross-compiles for gfx950 without a GPU).")
+    lib = C.CDLL(LIB_PATH)
+    for name, (argt, rest) in _SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise R3DHipError(f"{LIB_PATH} does not export {name}: stale build, run `python -m r3d_amd.build --force`") from e
+        fn.argtypes = argt
+        fn.restype = rest
+    v = lib.r3d_abi_version()
+    if v != ABI_VERSION:
+        raise R3DHipError(f"libr3d_hip.so ABI {v} != expected {ABI_VERSION}: rebuild with `python -m r3d_amd.build --force`")
+    _lib = lib
+    return lib
+
+
+_ERR = {-1: "R3D_EINVAL (rejected argument)", -2: "R3D_EALIGN (misaligned pointer / leading dimension)"}
+
+
+def check(rc, what):
+    if rc != 0:
+        raise R3DHipError(f"{what} failed: {_ERR.get(rc, f'hipError_t {rc}' if rc > 0 else rc)}")
+
+
+def build_info():
+    buf = C.create_string_buffer(128)
+    check(load().r3d_build_info(buf, 128), "r3d_build_info")
+    return buf.value.decode()

@@ -1,0 +1,213 @@
+// Multi-head attention core of the DETR-style decoder (nn.MultiheadAttention inside
+// TransformerDecoderLayer.forward_post, model/extras/transformer.py:289-304):
+//   scores = (q . k^T) * dh^-0.5, key_padding_mask -> -inf, softmax over keys, dropout(p) on the probabilities, P . v
+// The decoder has only n_query (8) query rows per clip, so the core is tiny and latency-bound: one wave per
+// (clip, head); the key chunk is staged in LDS ([64][dh+1], conflict-free lane-per-key dot products), the score
+// matrix [Lq][Lk] lives in LDS, reductions are wave shuffles.  The in/out projections run on the MFMA GEMM.
+#include "common.h"
+#include "../../include/r3d_hip.h"
+
+namespace r3d {
+
+struct MhaArgs {
+    const float* q; int ldq; const float* k; int ldk; const float* v; int ldv;
+    const uint8_t* kpm;                 // [B][Lk], 1 = padded key (cross attention only), or NULL
+    float* probs;                       // [B][heads][Lq][Lk] softmax output BEFORE dropout (saved for backward)
+    const uint8_t* drop; float drop_scale;   // [B][heads][Lq][Lk] keep mask, or NULL
+    float* o; int ldo;                  // fwd: attention output rows (b*Lq + i), columns h*dh + d
+    const float* d_o; int lddo;         // bwd
+    float* dq; int lddq; float* dk; int lddk; float* dv; int lddv;
+    int B, heads, Lq, Lk, dh; float scale;
+};
+
+__device__ __forceinline__ void load_chunk(float* kc, const float* base, int ld, int row0, int nrows, int rows_total,
+                                           int dh, int lane) {
+    for (int r = 0; r < nrows; ++r) {
+        const bool ok = (row0 + r) < rows_total;
+        for (int d = lane; d < dh; d += 64) kc[r * (dh + 1) + d] = ok ? base[(size_t)(row0 + r) * ld + d] : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(64) void mha_fwd_kernel(const MhaArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
+    const int lane = threadIdx.x;
+    const int Lq = a.Lq, Lk = a.Lk, dh = a.dh;
+    float* qs = lds;                       // [Lq][dh]
+    float* sc = qs + Lq * dh;              // [Lq][Lk]
+    float* kc = sc + Lq * Lk;              // [64][dh+1]
+    const float* qb = a.q + (size_t)b * Lq * a.ldq + h * dh;
+    const float* kb = a.k + (size_t)b * Lk * a.ldk + h * dh;
+    const float* vb = a.v + (size_t)b * Lk * a.ldv + h * dh;
+    for (int i = 0; i < Lq; ++i)
+        for (int d = lane; d < dh; d += 64) qs[i * dh + d] = qb[(size_t)i * a.ldq + d];
+    for (int c0 = 0; c0 < Lk; c0 += 64) {
+        __syncthreads();
+        load_chunk(kc, kb, a.ldk, c0, 64, Lk, dh, lane);
+        __syncthreads();
+        const int j = c0 + lane;
+        if (j < Lk) {
+            const bool masked = a.kpm && a.kpm[(size_t)b * Lk + j];
+            for (int i = 0; i < Lq; ++i) {
+                float s = 0.f;
+                for (int d = 0; d < dh; ++d) s += qs[i * dh + d] * kc[lane * (dh + 1) + d];
+                sc[i * Lk + j] = masked ? -INFINITY : s * a.scale;
+            }
+        }
+    }
+    __syncthreads();
+    const size_t pbase = ((size_t)(b * a.heads + h) * Lq) * Lk;
+    for (int i = 0; i < Lq; ++i) {
+        float m = -INFINITY;
+        for (int j = lane; j < Lk; j += 64) m = fmaxf(m, sc[i * Lk + j]);
+        m = wave_max(m);
+        float sum = 0.f;
+        for (int j = lane; j < Lk; j += 64) {
+            const float e = expf(sc[i * Lk + j] - m);       // all keys masked: -inf - -inf = NaN, as in PyTorch
+            sc[i * Lk + j] = e;
+            sum += e;
+        }
+        sum = wave_sum(sum);
+        for (int j = lane; j < Lk; j += 64) {
+            const float p = sc[i * Lk + j] / sum;
+            a.probs[pbase + (size_t)i * Lk + j] = p;
+            sc[i * Lk + j] = a.drop ? p * a.drop_scale * (float)a.drop[pbase + (size_t)i * Lk + j] : p;
+        }
+    }
+    __syncthreads();
+    for (int i = 0; i < Lq; ++i)
+        for (int d = lane; d < dh; d += 64) {
+            float acc = 0.f;
+            for (int j = 0; j < Lk; ++j) acc += sc[i * Lk + j] * vb[(size_t)j * a.ldv + d];
+            a.o[((size_t)b * Lq + i) * a.ldo + h * dh + d] = acc;
+        }
+}
+
+__global__ __launch_bounds__(64) void mha_bwd_kernel(const MhaArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
+    const int lane = threadIdx.x;
+    const int Lq = a.Lq, Lk = a.Lk, dh = a.dh;
+    float* qs = lds;                       // [Lq][dh]
+    float* dos = qs + Lq * dh;             // [Lq][dh]
+    float* P = dos + Lq * dh;              // [Lq][Lk]  softmax probs, later the dropped probs
+    float* dS = P + Lq * Lk;               // [Lq][Lk]
+    float* kc = dS + Lq * Lk;              // [64][dh+1]
+    const float* qb = a.q + (size_t)b * Lq * a.ldq + h * dh;
+    const float* kb = a.k + (size_t)b * Lk * a.ldk + h * dh;
+    const float* vb = a.v + (size_t)b * Lk * a.ldv + h * dh;
+    const float* dob = a.d_o + (size_t)b * Lq * a.lddo + h * dh;
+    const size_t pbase = ((size_t)(b * a.heads + h) * Lq) * Lk;
+    for (int i = 0; i < Lq; ++i)
+        for (int d = lane; d < dh; d += 64) {
+            qs[i * dh + d] = qb[(size_t)i * a.ldq + d];
+            dos[i * dh + d] = dob[(size_t)i * a.lddo + d];
+        }
+    for (int e = lane; e < Lq * Lk; e += 64) P[e] = a.probs[pbase + e];
+    // dP = (dO . V^T) o keep*scale
+    for (int c0 = 0; c0 < Lk; c0 += 64) {
+        __syncthreads();
+        load_chunk(kc, vb, a.ldv, c0, 64, Lk, dh, lane);
+        __syncthreads();
+        const int j = c0 + lane;
+        if (j < Lk)
+            for (int i = 0; i < Lq; ++i) {
+                float s = 0.f;
+                for (int d = 0; d < dh; ++d) s += dos[i * dh + d] * kc[lane * (dh + 1) + d];
+                if (a.drop) s *= a.drop_scale * (float)a.drop[pbase + (size_t)i * Lk + j];
+                dS[i * Lk + j] = s;
+            }
+    }
+    __syncthreads();
+    // softmax backward, with the 1/sqrt(dh) of the scores folded in; then P <- dropped probs for dV
+    for (int i = 0; i < Lq; ++i) {
+        float t = 0.f;
+        for (int j = lane; j < Lk; j += 64) t += P[i * Lk + j] * dS[i * Lk + j];
+        t = wave_sum(t);
+        for (int j = lane; j < Lk; j += 64) {
+            const float p = P[i * Lk + j];
+            dS[i * Lk + j] = p * (dS[i * Lk + j] - t) * a.scale;
+            if (a.drop) P[i * Lk + j] = p * a.drop_scale * (float)a.drop[pbase + (size_t)i * Lk + j];
+        }
+    }
+    __syncthreads();
+    for (int i = 0; i < Lq; ++i)
+        for (int d = lane; d < dh; d += 64) {
+            float acc = 0.f;
+            for (int j = 0; j < Lk; ++j) acc += dS[i * Lk + j] * kb[(size_t)j * a.ldk + d];
+            a.dq[((size_t)b * Lq + i) * a.lddq + h * dh + d] = acc;
+        }
+    for (int j = 0; j < Lk; ++j)
+        for (int d = lane; d < dh; d += 64) {
+            float gk = 0.f, gv = 0.f;
+            for (int i = 0; i < Lq; ++i) {
+                gk += dS[i * Lk + j] * qs[i * dh + d];
+                gv += P[i * Lk + j] * dos[i * dh + d];
+            }
+            a.dk[((size_t)b * Lk + j) * a.lddk + h * dh + d] = gk;
+            a.dv[((size_t)b * Lk + j) * a.lddv + h * dh + d] = gv;
+        }
+}
+
+static size_t mha_lds_bytes(int Lq, int Lk, int dh, bool bwd) {
+    size_t f = (size_t)Lq * dh + (size_t)Lq * Lk + (size_t)64 * (dh + 1);
+    if (bwd) f += (size_t)Lq * dh + (size_t)Lq * Lk;
+    return f * sizeof(float);
+}
+
+static int mha_check(const MhaArgs& a, bool bwd) {
+    if (!a.q || !a.k || !a.v || !a.probs) return R3D_EINVAL;
+    if (a.B <= 0 || a.heads <= 0 || a.Lq <= 0 || a.Lk <= 0 || a.dh <= 0) return R3D_EINVAL;
+    const int H = a.heads * a.dh;
+    if (a.ldq < H || a.ldk < H || a.ldv < H) return R3D_EINVAL;
+    if (!bwd && (!a.o || a.ldo < H)) return R3D_EINVAL;
+    if (bwd && (!a.d_o || !a.dq || !a.dk || !a.dv || a.lddo < H || a.lddq < H || a.lddk < H || a.lddv < H))
+        return R3D_EINVAL;
+    if (mha_lds_bytes(a.Lq, a.Lk, a.dh, bwd) > 160 * 1024) return R3D_EINVAL;
+    return R3D_OK;
+}
+
+}  // namespace r3d
+
+using namespace r3d;
+
+R3D_EXPORT int r3d_mha_core_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                                const uint8_t* key_padding_mask, float* probs, const uint8_t* drop_mask,
+                                float drop_scale, float* o, int ldo, int B, int heads, int Lq, int Lk, int dh,
+                                void* stream) {
+    MhaArgs a{};
+    a.q = q; a.ldq = ldq; a.k = k; a.ldk = ldk; a.v = v; a.ldv = ldv; a.kpm = key_padding_mask; a.probs = probs;
+    a.drop = drop_mask; a.drop_scale = drop_scale; a.o = o; a.ldo = ldo;
+    a.B = B; a.heads = heads; a.Lq = Lq; a.Lk = Lk; a.dh = dh; a.scale = 1.0f / sqrtf((float)dh);
+    int rc = mha_check(a, false);
+    if (rc != R3D_OK) return rc;
+    const size_t lds = mha_lds_bytes(Lq, Lk, dh, false);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)mha_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(mha_fwd_kernel, dim3(B * heads), dim3(64), lds, (hipStream_t)stream, a);
+    R3D_LAUNCH_CHECK();
+    return R3D_OK;
+}
+
+R3D_EXPORT int r3d_mha_core_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                                const float* probs, const uint8_t* drop_mask, float drop_scale, const float* d_o,
+                                int lddo, float* dq, int lddq, float* dk, int lddk, float* dv, int lddv, int B, int heads,
+                                int Lq, int Lk, int dh, void* stream) {
+    MhaArgs a{};
+    a.q = q; a.ldq = ldq; a.k = k; a.ldk = ldk; a.v = v; a.ldv = ldv; a.probs = const_cast<float*>(probs);
+    a.drop = drop_mask; a.drop_scale = drop_scale; a.d_o = d_o; a.lddo = lddo;
+    a.dq = dq; a.lddq = lddq; a.dk = dk; a.lddk = lddk; a.dv = dv; a.lddv = lddv;
+    a.B = B; a.heads = heads; a.Lq = Lq; a.Lk = Lk; a.dh = dh; a.scale = 1.0f / sqrtf((float)dh);
+    int rc = mha_check(a, true);
+    if (rc != R3D_OK) return rc;
+    const size_t lds = mha_lds_bytes(Lq, Lk, dh, true);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)mha_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(mha_bwd_kernel, dim3(B * heads), dim3(64), lds, (hipStream_t)stream, a);
+    R3D_LAUNCH_CHECK();
+    return R3D_OK;
+}

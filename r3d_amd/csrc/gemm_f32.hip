@@ -1,0 +1,371 @@
+// fp32-exact MFMA GEMM family for gfx950 (MI355X).  See include/r3d_hip.h "GEMM family" for the contract.
+//
+// Why f32 MFMA: the depth projection contracts over K = 50176 (model/futr_safuser_tokenfusion.py:143,195);
+// bf16 inputs cannot hold the 1e-3 parity budget there, and gfx950 has no TF32/xf32.  v_mfma_f32_32x32x2_f32 is an
+// exact fp32 fma chain at the f32 vector peak (157 TFLOP/s) with 1 operand VGPR per lane per 4096 FLOP.
+//
+// Tile scheme (per workgroup):  BM x BN output, BK = 16 k per step, waves laid out WM x WN, each wave owning
+// (BM/WM) x (BN/WN) as 32x32 MFMA tiles.  Both operands are staged into LDS K-MAJOR ([k][m] and [k][n]); an MFMA
+// fragment read is then 32 consecutive floats per half-wave (ds_read_b32, conflict-free) whatever the global layout:
+//   - a K-contiguous global operand (nn.Linear weights / activations in NT) is loaded as float4 along k and
+//     transposed by 4 ds_write_b32 (row stride = tile+2 floats -> conflict-free writes);
+//   - an M/N-contiguous operand (NN's B, TN's A and B) is copied with float4 loads + ds_write_b128 (stride tile+4).
+// Global loads for step t+1 are issued before the MFMAs of step t (register prefetch, double-buffered LDS, one
+// barrier per step).  Out-of-range rows / columns / k are zero-filled, so any M, N, K works; the float4 path needs
+// 16-byte aligned bases and leading dimensions that are multiples of 4, otherwise a scalar-load twin is used.
+#include "common.h"
+#include "../../include/r3d_hip.h"
+
+namespace r3d {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 16;
+
+// ---------------------------------------------------------------------------------------------------------
+// epilogue shared by the GEMM kernel and the split-K reducer
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void gemm_epilogue(const r3d_gemm_desc& d, int m, int n, float acc) {
+    float v = d.alpha * acc;
+    if (d.bias) v += d.bias[n];
+    if (d.pre_out) d.pre_out[(size_t)m * d.ldpre + n] = v;
+    if (d.act == 1) v = fmaxf(v, 0.0f);
+    else if (d.act == 2) v = gelu_f(v);
+    if (d.drop_mask) v *= d.drop_scale * (float)d.drop_mask[(size_t)m * d.lddrop + n];
+    if (d.mul == 1) v = (d.aux[(size_t)m * d.ldaux + n] > 0.0f) ? v : 0.0f;
+    else if (d.mul == 2) v *= gelu_grad_f(d.aux[(size_t)m * d.ldaux + n]);
+    if (d.res1) v += d.res1[(size_t)m * d.ldr1 + n];
+    if (d.res2) v += d.res2[(size_t)m * d.ldr2 + n];
+    float* c = d.C + (size_t)m * d.ldc + n;
+    if (d.accumulate) v += *c;
+    *c = v;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// staging helpers
+// ---------------------------------------------------------------------------------------------------------
+// K-contiguous source: tile of R rows x 16 k.  f indexes float4s: row = f/4, kq = f%4.
+template <int R, int NT, bool VEC, bool PROLOGUE>
+struct StageKC {
+    static constexpr int NLD = (R * 4) / NT;
+    static_assert(NLD >= 1 && (R * 4) % NT == 0, "tile too small for the workgroup");
+    float4 v[NLD];
+    __device__ __forceinline__ void load(const float* __restrict__ base, int ld, int row0, int rows_total,
+                                         int k0, int k_end, const r3d_gemm_desc& d) {
+#pragma unroll
+        for (int p = 0; p < NLD; ++p) {
+            const int f = threadIdx.x + p * NT;
+            const int row = row0 + (f >> 2);
+            const int k = k0 + ((f & 3) << 2);
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < rows_total && k < k_end) {
+                int srow = row;
+                if (PROLOGUE) srow = row ^ d.a_row_xor;
+                const float* src = base + (size_t)srow * ld + k;
+                if (VEC && k + 3 < k_end) {
+                    x = *reinterpret_cast<const float4*>(src);
+                } else {
+                    x.x = src[0];
+                    if (k + 1 < k_end) x.y = src[1];
+                    if (k + 2 < k_end) x.z = src[2];
+                    if (k + 3 < k_end) x.w = src[3];
+                }
+                if (PROLOGUE && d.a_add) {
+                    const float* ad = d.a_add + (size_t)(row % d.a_add_mod) * d.a_add_ld + k;
+                    x.x += ad[0];
+                    if (k + 1 < k_end) x.y += ad[1];
+                    if (k + 2 < k_end) x.z += ad[2];
+                    if (k + 3 < k_end) x.w += ad[3];
+                }
+            }
+            v[p] = x;
+        }
+    }
+    // LDS image [16][R + 2]
+    __device__ __forceinline__ void store(float* __restrict__ s) const {
+        constexpr int S = R + 2;
+#pragma unroll
+        for (int p = 0; p < NLD; ++p) {
+            const int f = threadIdx.x + p * NT;
+            const int row = f >> 2, kq = (f & 3) << 2;
+            s[(kq + 0) * S + row] = v[p].x;
+            s[(kq + 1) * S + row] = v[p].y;
+            s[(kq + 2) * S + row] = v[p].z;
+            s[(kq + 3) * S + row] = v[p].w;
+        }
+    }
+};
+
+// M/N-contiguous source: tile of 16 k-rows x R columns.  f indexes float4s: krow = f/(R/4), cq = f%(R/4).
+template <int R, int NT, bool VEC>
+struct StageMC {
+    static constexpr int NLD = (R * 4) / NT;
+    static_assert(NLD >= 1 && (R * 4) % NT == 0, "tile too small for the workgroup");
+    float4 v[NLD];
+    __device__ __forceinline__ void load(const float* __restrict__ base, int ld, int col0, int cols_total,
+                                         int k0, int k_end) {
+#pragma unroll
+        for (int p = 0; p < NLD; ++p) {
+            const int f = threadIdx.x + p * NT;
+            const int k = k0 + f / (R / 4);
+            const int c = col0 + ((f % (R / 4)) << 2);
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < k_end && c < cols_total) {
+                const float* src = base + (size_t)k * ld + c;
+                if (VEC && c + 3 < cols_total) {
+                    x = *reinterpret_cast<const float4*>(src);
+                } else {
+                    x.x = src[0];
+                    if (c + 1 < cols_total) x.y = src[1];
+                    if (c + 2 < cols_total) x.z = src[2];
+                    if (c + 3 < cols_total) x.w = src[3];
+                }
+            }
+            v[p] = x;
+        }
+    }
+    // LDS image [16][R + 4]
+    __device__ __forceinline__ void store(float* __restrict__ s) const {
+        constexpr int S = R + 4;
+#pragma unroll
+        for (int p = 0; p < NLD; ++p) {
+            const int f = threadIdx.x + p * NT;
+            const int krow = f / (R / 4), cq = (f % (R / 4)) << 2;
+            *reinterpret_cast<float4*>(s + krow * S + cq) = v[p];
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// the kernel
+// ---------------------------------------------------------------------------------------------------------
+template <int LA, int LB, int BM, int BN, int WM, int WN, bool VEC>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const r3d_gemm_desc d) {
+    constexpr int NT = 64 * WM * WN;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int SA = BM + (LA == 0 ? 2 : 4);
+    constexpr int SB = BN + (LB == 0 ? 2 : 4);
+    constexpr int A_FLOATS = BK * SA, B_FLOATS = BK * SB;
+    static_assert(A_FLOATS % 4 == 0 && B_FLOATS % 4 == 0, "LDS carve must stay 16-byte aligned");
+    __shared__ __attribute__((aligned(16))) float smem[2 * (A_FLOATS + B_FLOATS)];
+    float* As0 = smem;
+    float* As1 = smem + A_FLOATS;
+    float* Bs0 = smem + 2 * A_FLOATS;
+    float* Bs1 = smem + 2 * A_FLOATS + B_FLOATS;
+
+    const int tiles_n = (d.N + BN - 1) / BN;
+    const int tile = blockIdx.x;
+    const int m0 = (tile / tiles_n) * BM;
+    const int n0 = (tile % tiles_n) * BN;
+    const int split = blockIdx.y;
+    const int k_begin = (d.splitk > 1) ? split * d.k_per_split : 0;
+    const int k_end = (d.splitk > 1) ? min(d.K, k_begin + d.k_per_split) : d.K;
+    const int nk = (k_end - k_begin + BK - 1) / BK;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int wm_off = (wave / WN) * (BM / WM);
+    const int wn_off = (wave % WN) * (BN / WN);
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    StageKC<BM, NT, VEC, true> a_kc;
+    StageMC<BM, NT, VEC> a_mc;
+    StageKC<BN, NT, VEC, false> b_kc;
+    StageMC<BN, NT, VEC> b_mc;
+
+    auto load_tiles = [&](int kt) {
+        const int k0 = k_begin + kt * BK;
+        if (LA == 0) a_kc.load(d.A, d.lda, m0, d.M, k0, k_end, d);
+        else a_mc.load(d.A, d.lda, m0, d.M, k0, k_end);
+        if (LB == 0) b_kc.load(d.B, d.ldb, n0, d.N, k0, k_end, d);
+        else b_mc.load(d.B, d.ldb, n0, d.N, k0, k_end);
+    };
+    auto store_tiles = [&](float* as, float* bs) {
+        if (LA == 0) a_kc.store(as); else a_mc.store(as);
+        if (LB == 0) b_kc.store(bs); else b_mc.store(bs);
+    };
+
+    if (nk > 0) {
+        load_tiles(0);
+        store_tiles(As0, Bs0);
+    }
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = (kt + 1 < nk);
+        if (more) load_tiles(kt + 1);
+        const float* as = (kt & 1) ? As1 : As0;
+        const float* bs = (kt & 1) ? Bs1 : Bs0;
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            const int kr = kk * 2 + lhi;
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = as[kr * SA + wm_off + i * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = bs[kr * SB + wn_off + j * 32 + l31];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) store_tiles((kt & 1) ? As0 : As1, (kt & 1) ? Bs0 : Bs1);
+        __syncthreads();
+    }
+
+    // Epilogue through LDS: each wave parks one 32x32 accumulator tile in its own [32][33] LDS patch (C/D map of the
+    // 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)), then walks it row-major so the
+    // (long, fully optional) epilogue is a compact runtime loop with statically indexed accumulators.
+    static_assert(2 * (A_FLOATS + B_FLOATS) >= WM * WN * 32 * 33, "epilogue patch does not fit the staging LDS");
+    float* patch = smem + wave * (32 * 33);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            __syncthreads();                       // previous patch consumed / main-loop LDS reads finished
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                patch[((r & 3) + 8 * (r >> 2) + 4 * lhi) * 33 + l31] = acc[i][j][r];
+            __syncthreads();
+            const int mb = m0 + wm_off + i * 32, nb = n0 + wn_off + j * 32;
+            for (int e = lane; e < 1024; e += 64) {
+                const int m = mb + (e >> 5), n = nb + (e & 31);
+                if (m < d.M && n < d.N) {
+                    const float v = patch[(e >> 5) * 33 + (e & 31)];
+                    if (d.splitk > 1) d.partial[((size_t)split * d.M + m) * d.N + n] = v;
+                    else gemm_epilogue(d, m, n, v);
+                }
+            }
+        }
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const r3d_gemm_desc d, int nsplit) {
+    const size_t total = (size_t)d.M * d.N;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        float s = 0.0f;
+        for (int p = 0; p < nsplit; ++p) s += d.partial[(size_t)p * total + e];
+        gemm_epilogue(d, (int)(e / d.N), (int)(e % d.N), s);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------
+template <int LA, int LB, int BM, int BN, int WM, int WN>
+static int launch_cfg(const r3d_gemm_desc& d, bool vec, int nsplit, hipStream_t s) {
+    dim3 grid(r3d_cdiv(d.M, BM) * r3d_cdiv(d.N, BN), nsplit, 1);
+    dim3 block(64 * WM * WN, 1, 1);
+    if (vec) hipLaunchKernelGGL((gemm_f32_kernel<LA, LB, BM, BN, WM, WN, true>), grid, block, 0, s, d);
+    else hipLaunchKernelGGL((gemm_f32_kernel<LA, LB, BM, BN, WM, WN, false>), grid, block, 0, s, d);
+    R3D_LAUNCH_CHECK();
+    return R3D_OK;
+}
+
+template <int LA, int LB>
+static int launch_layout(const r3d_gemm_desc& d, bool vec, int nsplit, hipStream_t s) {
+    switch (d.tile) {
+        case 1: return launch_cfg<LA, LB, 32, 32, 1, 1>(d, vec, nsplit, s);
+        case 2: return launch_cfg<LA, LB, 64, 64, 2, 2>(d, vec, nsplit, s);
+        case 3: return launch_cfg<LA, LB, 128, 128, 2, 2>(d, vec, nsplit, s);
+        default: return R3D_EINVAL;
+    }
+}
+
+static int nsplits_of(const r3d_gemm_desc& d) {
+    return (d.splitk > 1) ? r3d_cdiv(d.K, d.k_per_split) : 1;
+}
+
+}  // namespace r3d
+
+using namespace r3d;
+
+R3D_EXPORT int64_t r3d_gemm_partial_floats(int32_t M, int32_t N, int32_t splitk) {
+    return (splitk > 1) ? (int64_t)splitk * M * N : 0;
+}
+
+// Cost model for a 256-CU / 1024-SIMD part: pick the workgroup tile and the K split that minimise
+//   rounds(waves over SIMDs) * (k-steps * MFMA cycles per step + fixed overhead) + partial-slab traffic.
+R3D_EXPORT int r3d_gemm_plan(r3d_gemm_desc* d) {
+    if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0) return R3D_EINVAL;
+    static const int tile_sz[4] = {0, 32, 64, 128};
+    static const int tile_waves[4] = {0, 1, 4, 4};
+    static const int tile_cyc[4] = {0, 512, 512, 2048};   // MFMA cycles per 16-deep k-step per wave
+    double best = 1e300;
+    int bt = 1, bs = 1, bk = d->K;
+    for (int t = 1; t <= 3; ++t) {
+        const long tiles = (long)r3d_cdiv(d->M, tile_sz[t]) * r3d_cdiv(d->N, tile_sz[t]);
+        for (int sk = 1; sk <= 256; sk *= 2) {
+            int kps = r3d_cdiv(r3d_cdiv(d->K, sk), BK) * BK;
+            if (sk > 1 && kps < 4 * BK) break;
+            const int ns = r3d_cdiv(d->K, kps);
+            if (sk > 1 && ns < 2) continue;
+            const long waves = tiles * ns * tile_waves[t];
+            const double rounds = (double)((waves + 1023) / 1024);
+            const double per_wave = (double)r3d_cdiv(kps, BK) * tile_cyc[t] + 4000.0;
+            // slab write + read at ~4 TB/s ~= 0.6 cycle/KB-per-CU-equivalent; expressed in cycles @2.4 GHz
+            const double slab = (ns > 1) ? 2.0 * ns * (double)d->M * d->N * 4.0 / 4.0e12 * 2.4e9 + 4500.0 : 0.0;
+            // wasted MFMA work in ragged edge tiles is already inside `tiles`
+            const double cost = rounds * per_wave + slab;
+            if (cost < best) { best = cost; bt = t; bs = ns; bk = kps; }
+        }
+    }
+    d->tile = bt;
+    d->splitk = bs;
+    d->k_per_split = (bs > 1) ? bk : d->K;
+    return R3D_OK;
+}
+
+static int gemm_validate(const r3d_gemm_desc* d) {
+    if (!d || !d->A || !d->B || !d->C) return R3D_EINVAL;
+    if (d->M <= 0 || d->N <= 0 || d->K <= 0) return R3D_EINVAL;
+    if (d->layout < 0 || d->layout > 2) return R3D_EINVAL;
+    if (d->tile < 1 || d->tile > 3) return R3D_EINVAL;
+    const int a_min = (d->layout == R3D_GEMM_TN) ? d->M : d->K;
+    const int b_min = (d->layout == R3D_GEMM_NT) ? d->K : d->N;
+    if (d->lda < a_min || d->ldb < b_min || d->ldc < d->N) return R3D_EINVAL;
+    if (d->layout == R3D_GEMM_TN && (d->a_add || d->a_row_xor)) return R3D_EINVAL;
+    if (d->a_add && (d->a_add_mod <= 0 || d->a_add_ld < d->K)) return R3D_EINVAL;
+    if (d->a_row_xor && (d->M & 1)) return R3D_EINVAL;            // pair swap needs an even row count
+    if (d->a_row_xor < 0 || d->a_row_xor > 1) return R3D_EINVAL;
+    if (d->mul && !d->aux) return R3D_EINVAL;
+    if (d->splitk > 1) {
+        if (!d->partial || d->k_per_split <= 0 || (d->k_per_split % 16) != 0) return R3D_EINVAL;
+        if (r3d_cdiv(d->K, d->k_per_split) > d->splitk) return R3D_EINVAL;
+    }
+    return R3D_OK;
+}
+
+R3D_EXPORT int r3d_gemm_f32(const r3d_gemm_desc* dp, void* stream) {
+    int rc = gemm_validate(dp);
+    if (rc != R3D_OK) return rc;
+    const r3d_gemm_desc& d = *dp;
+    hipStream_t s = (hipStream_t)stream;
+    bool vec = r3d_aligned16(d.A) && r3d_aligned16(d.B) && (d.lda % 4 == 0) && (d.ldb % 4 == 0);
+    if (d.a_add) vec = vec && r3d_aligned16(d.a_add) && (d.a_add_ld % 4 == 0);
+    const int ns = nsplits_of(d);
+    switch (d.layout) {
+        case R3D_GEMM_NT: return launch_layout<0, 0>(d, vec, ns, s);
+        case R3D_GEMM_NN: return launch_layout<0, 1>(d, vec, ns, s);
+        default: return launch_layout<1, 1>(d, vec, ns, s);
+    }
+}
+
+R3D_EXPORT int r3d_splitk_reduce(const r3d_gemm_desc* dp, void* stream) {
+    int rc = gemm_validate(dp);
+    if (rc != R3D_OK) return rc;
+    if (dp->splitk <= 1) return R3D_EINVAL;
+    const size_t total = (size_t)dp->M * dp->N;
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *dp, nsplits_of(*dp));
+    R3D_LAUNCH_CHECK();
+    return R3D_OK;
+}

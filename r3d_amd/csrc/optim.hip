@@ -1,0 +1,99 @@
+// Fused multi-tensor AdamW over a flat parameter arena, and the Philox keep-masks for dropout.
+//   AdamW: torch.optim.AdamW(lr, weight_decay) as constructed at main_darai.py:135 and stepped at
+//          train/train_proposed_depth.py:215 -- the largest HBM term of the step (28 B/param).
+//          One launch over [p | g | m | v] arenas, float4 per lane, grid-stride; hyper-parameters that change while a
+//          hipGraph is replayed (lr, step) are read from device memory.
+//   Dropout: nn.Dropout(0.1) sites of the path (futr_safuser_tokenfusion.py:26,83; transformer.py:268-276 and the
+//          attention-probability dropout inside nn.MultiheadAttention).  RNG parity with PyTorch is impossible, so the
+//          masks come from Philox4x32-10 keyed by (seed, per-step offset read from device memory).
+#include "common.h"
+#include "../../include/r3d_hip.h"
+
+namespace r3d {
+
+__global__ __launch_bounds__(256) void adamw_kernel(float4* __restrict__ p, const float4* __restrict__ g,
+                                                    float4* __restrict__ m, float4* __restrict__ v, size_t n4,
+                                                    const float* lr_ptr, const int64_t* step_ptr, float b1, float b2,
+                                                    float eps, float wd, float gscale) {
+    const float lr = *lr_ptr;
+    const double step = (double)*step_ptr;
+    const float bc1 = (float)(1.0 - pow((double)b1, step));
+    const float bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, step));
+    const float decay = 1.0f - lr * wd;
+    const float step_size = lr / bc1;
+    const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        float4 pp = p[i], gg = g[i], mm = m[i], vv = v[i];
+#define R3D_ADAM1(c)                                               \
+        {                                                          \
+            const float gr = gg.c * gscale;                        \
+            pp.c *= decay;                                         \
+            mm.c = mm.c + (gr - mm.c) * omb1;                      \
+            vv.c = vv.c * b2 + gr * gr * omb2;                     \
+            const float den = sqrtf(vv.c) / bc2_sqrt + eps;        \
+            pp.c -= step_size * (mm.c / den);                      \
+        }
+        R3D_ADAM1(x) R3D_ADAM1(y) R3D_ADAM1(z) R3D_ADAM1(w)
+#undef R3D_ADAM1
+        p[i] = pp; m[i] = mm; v[i] = vv;
+    }
+}
+
+__device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) { return __umulhi(a, b); }
+
+__device__ __forceinline__ uint4 philox4x32_10(uint4 ctr, uint2 key) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = mulhi32(M0, ctr.x), lo0 = M0 * ctr.x;
+        const uint32_t hi1 = mulhi32(M1, ctr.z), lo1 = M1 * ctr.z;
+        ctr = make_uint4(hi1 ^ ctr.y ^ key.x, lo1, hi0 ^ ctr.w ^ key.y, lo0);
+        key.x += W0;
+        key.y += W1;
+    }
+    return ctr;
+}
+
+// mask[i] = 1 with probability (1-p).  4 elements per Philox call.
+__global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* mask, size_t n, uint32_t thresh, uint64_t seed,
+                                                           const int64_t* offset_ptr) {
+    const uint64_t off = offset_ptr ? (uint64_t)*offset_ptr : 0ull;
+    const size_t n4 = (n + 3) / 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const uint4 r = philox4x32_10(make_uint4((uint32_t)i, (uint32_t)(i >> 32), (uint32_t)off, (uint32_t)(off >> 32)),
+                                      make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+        const uint32_t u[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (i * 4 + j < n) mask[i * 4 + j] = (u[j] >= thresh) ? 1 : 0;
+    }
+}
+
+}  // namespace r3d
+
+using namespace r3d;
+
+R3D_EXPORT int r3d_adamw_flat(float* p, const float* g, float* m, float* v, int64_t n, const float* lr, const int64_t* step,
+                              float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream) {
+    R3D_REQUIRE(p && g && m && v && lr && step && n > 0);
+    R3D_REQUIRE((n % 4) == 0);
+    if (!(r3d_aligned16(p) && r3d_aligned16(g) && r3d_aligned16(m) && r3d_aligned16(v))) return R3D_EALIGN;
+    const size_t n4 = (size_t)n / 4;
+    const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float4*)p, (const float4*)g,
+                       (float4*)m, (float4*)v, n4, lr, step, beta1, beta2, eps, weight_decay, grad_scale);
+    R3D_LAUNCH_CHECK();
+    return R3D_OK;
+}
+
+R3D_EXPORT int r3d_dropout_mask(uint8_t* mask, int64_t n, float p, uint64_t seed, const int64_t* offset, void* stream) {
+    R3D_REQUIRE(mask && n > 0 && p >= 0.f && p < 1.f);
+    const double t = (double)p * 4294967296.0;
+    const uint32_t thresh = (uint32_t)(t >= 4294967295.0 ? 4294967295.0 : t);
+    const size_t n4 = ((size_t)n + 3) / 4;
+    const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, mask, (size_t)n, thresh, seed,
+                       offset);
+    R3D_LAUNCH_CHECK();
+    return R3D_OK;
+}

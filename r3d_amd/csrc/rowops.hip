@@ -1,0 +1,304 @@
+// Row-wise kernels: LayerNorm forward / backward (with the fusions the token-fusion step needs), column sums for
+// bias gradients, row-modulo sums for broadcast-parameter gradients.  HBM-bound, one wave (64 lanes) per row,
+// lane c owns columns c, c+64, ... (256-B coalesced wave accesses); reductions are wave shuffles -> no LDS traffic
+// on the row path and bitwise run-to-run reproducible results (no float atomics anywhere).
+#include "common.h"
+#include "../../include/r3d_hip.h"
+
+namespace r3d {
+
+constexpr float kLnEps = 1e-5f;   // nn.LayerNorm default; SURVEY.md Appendix A.2
+
+struct LnFwdArgs {
+    const float* x; int ldx; int nsplit; const float* bias; float* pre_out;
+    const float* gamma; const float* beta; float* y; int ldy; float* mean; float* rstd;
+    float* pair_out; int rows; int H; int relu;
+};
+
+template <int EPL>
+__device__ __forceinline__ void ln_fwd_row(const LnFwdArgs& a, int row, int lane, float (&yv)[EPL]) {
+    float v[EPL];
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const int c = lane + 64 * e;
+        float t = 0.f;
+        if (c < a.H) {
+            if (a.nsplit > 0) {
+                for (int p = 0; p < a.nsplit; ++p) t += a.x[((size_t)p * a.rows + row) * a.H + c];
+                if (a.bias) t += a.bias[c];
+                if (a.pre_out) a.pre_out[(size_t)row * a.H + c] = t;
+            } else {
+                t = a.x[(size_t)row * a.ldx + c];
+            }
+        }
+        v[e] = t;
+        s += t;
+    }
+    const float mean = wave_sum(s) / (float)a.H;
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const int c = lane + 64 * e;
+        const float dlt = (c < a.H) ? v[e] - mean : 0.f;
+        q += dlt * dlt;
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)a.H + kLnEps);
+    if (lane == 0) { a.mean[row] = mean; a.rstd[row] = rstd; }
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const int c = lane + 64 * e;
+        float o = 0.f;
+        if (c < a.H) {
+            o = (v[e] - mean) * rstd * a.gamma[c] + a.beta[c];
+            if (a.relu) o = fmaxf(o, 0.f);
+            a.y[(size_t)row * a.ldy + c] = o;
+        }
+        yv[e] = o;
+    }
+}
+
+template <int EPL>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int unit = blockIdx.x * 4 + wave;
+    float y0[EPL];
+    if (a.pair_out) {
+        if (2 * unit >= a.rows) return;
+        float y1[EPL];
+        ln_fwd_row<EPL>(a, 2 * unit, lane, y0);
+        ln_fwd_row<EPL>(a, 2 * unit + 1, lane, y1);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const int c = lane + 64 * e;
+            if (c < a.H) a.pair_out[(size_t)unit * a.H + c] = (y0[e] + y1[e]) * 0.5f;
+        }
+    } else {
+        if (unit >= a.rows) return;
+        ln_fwd_row<EPL>(a, unit, lane, y0);
+    }
+}
+
+struct LnBwdArgs {
+    const float* dy; int lddy; int pair_in;
+    const float* x; int ldx; const float* mean; const float* rstd; const float* gamma; const float* beta; int relu;
+    const float* add1; int ldadd1; const float* add2; int ldadd2;
+    float* dx; int lddx;
+    float* dx2; int lddx2; const uint8_t* drop_mask; int lddrop; float drop_scale;
+    float* dgamma; float* dbeta; float* ws;       // ws: [gridDim.x][2][H] when gridDim.x > 1
+    int rows; int H; int rows_per_block;
+};
+
+template <int EPL>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float red[];     // [4][2][H]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r_begin = blockIdx.x * a.rows_per_block;
+    const int r_end = min(a.rows, r_begin + a.rows_per_block);
+    float dg[EPL], db[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) { dg[e] = 0.f; db[e] = 0.f; }
+    for (int row = r_begin + wave; row < r_end; row += 4) {
+        const float mean = a.mean[row], rstd = a.rstd[row];
+        float xh[EPL], g[EPL];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const int c = lane + 64 * e;
+            float xhat = 0.f, gg = 0.f;
+            if (c < a.H) {
+                xhat = (a.x[(size_t)row * a.ldx + c] - mean) * rstd;
+                float d = a.pair_in ? 0.5f * a.dy[(size_t)(row >> 1) * a.lddy + c] : a.dy[(size_t)row * a.lddy + c];
+                const float gam = a.gamma[c];
+                if (a.relu && !(xhat * gam + a.beta[c] > 0.f)) d = 0.f;
+                dg[e] += d * xhat;
+                db[e] += d;
+                gg = d * gam;
+            }
+            xh[e] = xhat;
+            g[e] = gg;
+            s1 += gg;
+            s2 += gg * xhat;
+        }
+        s1 = wave_sum(s1) / (float)a.H;
+        s2 = wave_sum(s2) / (float)a.H;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const int c = lane + 64 * e;
+            if (c < a.H) {
+                float o = rstd * (g[e] - s1 - xh[e] * s2);
+                if (a.add1) o += a.add1[(size_t)row * a.ldadd1 + c];
+                if (a.add2) o += a.add2[(size_t)row * a.ldadd2 + c];
+                a.dx[(size_t)row * a.lddx + c] = o;
+                if (a.dx2) {
+                    float o2 = o;
+                    if (a.drop_mask) o2 *= a.drop_scale * (float)a.drop_mask[(size_t)row * a.lddrop + c];
+                    a.dx2[(size_t)row * a.lddx2 + c] = o2;
+                }
+            }
+        }
+    }
+    if (!a.dgamma) return;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const int c = lane + 64 * e;
+        if (c < a.H) { red[(wave * 2 + 0) * a.H + c] = dg[e]; red[(wave * 2 + 1) * a.H + c] = db[e]; }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * a.H; c += 256) {
+        const int which = c / a.H, col = c % a.H;
+        const float s = red[(0 * 2 + which) * a.H + col] + red[(1 * 2 + which) * a.H + col] +
+                        red[(2 * 2 + which) * a.H + col] + red[(3 * 2 + which) * a.H + col];
+        if (gridDim.x == 1) (which == 0 ? a.dgamma : a.dbeta)[col] = s;
+        else a.ws[((size_t)blockIdx.x * 2 + which) * a.H + col] = s;
+    }
+}
+
+// out[i] (+)= sum_{p < nchunks} ws[p * len + i]
+__global__ __launch_bounds__(256) void chunk_sum_kernel(const float* ws, int nchunks, int len, float* out, int accumulate) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= len) return;
+    float s = 0.f;
+    for (int p = 0; p < nchunks; ++p) s += ws[(size_t)p * len + i];
+    if (accumulate) s += out[i];
+    out[i] = s;
+}
+
+// ws: [blocks][2][H] -> dgamma[H], dbeta[H]
+__global__ __launch_bounds__(256) void ln_param_finalize_kernel(const float* ws, int blocks, int H, float* dgamma,
+                                                                float* dbeta) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 2 * H) return;
+    const int which = i / H, col = i % H;
+    float s = 0.f;
+    for (int p = 0; p < blocks; ++p) s += ws[((size_t)p * 2 + which) * H + col];
+    (which == 0 ? dgamma : dbeta)[col] = s;
+}
+
+// column sums of x[rows, cols]: grid (colblocks of 64, rowchunks); wave w of the block takes rows w, w+4, ...
+__global__ __launch_bounds__(256) void colsum_kernel(const float* x, int ld, int rows, int cols, int rows_per_chunk,
+                                                     float* out, float* ws, int accumulate) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int r0 = blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+    float s = 0.f;
+    if (c < cols)
+        for (int r = r0 + wave; r < r1; r += 4) s += x[(size_t)r * ld + c];
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && c < cols) {
+        float t = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+        if (gridDim.y == 1) { if (accumulate) t += out[c]; out[c] = t; }
+        else ws[(size_t)blockIdx.y * cols + c] = t;
+    }
+}
+
+// out[r, c] (+)= sum_{rows with row % mod == r} x[row, c]      (gradient of a parameter broadcast over clips)
+__global__ __launch_bounds__(256) void rowmod_sum_kernel(const float* x, int ld, int rows, int cols, int mod,
+                                                         float* out, int ldo, int accumulate) {
+    const int r = blockIdx.y;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (int row = r; row < rows; row += mod) s += x[(size_t)row * ld + c];
+    float* o = out + (size_t)r * ldo + c;
+    if (accumulate) s += *o;
+    *o = s;
+}
+
+template <typename K, typename A>
+static int launch_epl(K k32, K k16, K k8, K k2, int H, dim3 grid, size_t shmem, hipStream_t s, const A& a) {
+    if (H <= 128) hipLaunchKernelGGL(k2, grid, dim3(256), shmem, s, a);
+    else if (H <= 512) hipLaunchKernelGGL(k8, grid, dim3(256), shmem, s, a);
+    else if (H <= 1024) hipLaunchKernelGGL(k16, grid, dim3(256), shmem, s, a);
+    else hipLaunchKernelGGL(k32, grid, dim3(256), shmem, s, a);
+    R3D_LAUNCH_CHECK();
+    return R3D_OK;
+}
+
+}  // namespace r3d
+
+using namespace r3d;
+
+R3D_EXPORT int r3d_layernorm_fwd(const float* x, int ldx, int nsplit, const float* bias, float* pre_out,
+                                 const float* gamma, const float* beta, float* y, int ldy, float* mean, float* rstd,
+                                 float* pair_out, int rows, int H, int relu, void* stream) {
+    R3D_REQUIRE(x && gamma && beta && y && mean && rstd);
+    R3D_REQUIRE(rows > 0 && H > 0 && H <= 2048 && ldy >= H && nsplit >= 0);
+    R3D_REQUIRE(nsplit > 0 || ldx >= H);
+    R3D_REQUIRE(!pair_out || (rows % 2) == 0);
+    LnFwdArgs a{x, ldx, nsplit, bias, pre_out, gamma, beta, y, ldy, mean, rstd, pair_out, rows, H, relu};
+    const int units = pair_out ? rows / 2 : rows;
+    return launch_epl(ln_fwd_kernel<32>, ln_fwd_kernel<16>, ln_fwd_kernel<8>, ln_fwd_kernel<2>, H,
+                      dim3(r3d_cdiv(units, 4)), 0, (hipStream_t)stream, a);
+}
+
+R3D_EXPORT int64_t r3d_layernorm_bwd_ws_floats(int rows, int H) {
+    const int rpb = rows <= 64 ? rows : (r3d_cdiv(rows, 64) < 16 ? 16 : r3d_cdiv(rows, 64));
+    const int blocks = r3d_cdiv(rows, rpb);
+    return blocks > 1 ? (int64_t)blocks * 2 * H : 0;
+}
+
+R3D_EXPORT int r3d_layernorm_bwd(const float* dy, int lddy, int pair_in, const float* x, int ldx, const float* mean,
+                                 const float* rstd, const float* gamma, const float* beta, int relu,
+                                 const float* add1, int ldadd1, const float* add2, int ldadd2, float* dx, int lddx,
+                                 float* dx2, int lddx2, const uint8_t* drop_mask, int lddrop, float drop_scale,
+                                 float* dgamma, float* dbeta, float* ws, int rows, int H, void* stream) {
+    R3D_REQUIRE(dy && x && mean && rstd && gamma && beta && dx);
+    R3D_REQUIRE(rows > 0 && H > 0 && H <= 2048 && ldx >= H && lddx >= H && lddy >= H);
+    R3D_REQUIRE((dgamma == nullptr) == (dbeta == nullptr));
+    R3D_REQUIRE(!pair_in || (rows % 2) == 0);
+    const int rpb = rows <= 64 ? rows : (r3d_cdiv(rows, 64) < 16 ? 16 : r3d_cdiv(rows, 64));
+    const int blocks = r3d_cdiv(rows, rpb);
+    R3D_REQUIRE(blocks == 1 || !dgamma || ws);
+    LnBwdArgs a{dy, lddy, pair_in, x, ldx, mean, rstd, gamma, beta, relu, add1, ldadd1, add2, ldadd2, dx, lddx,
+                dx2, lddx2, drop_mask, lddrop, drop_scale, dgamma, dbeta, ws, rows, H, rpb};
+    hipStream_t s = (hipStream_t)stream;
+    const size_t shmem = (size_t)8 * H * sizeof(float);
+    int rc = launch_epl(ln_bwd_kernel<32>, ln_bwd_kernel<16>, ln_bwd_kernel<8>, ln_bwd_kernel<2>, H, dim3(blocks),
+                        shmem, s, a);
+    if (rc != R3D_OK) return rc;
+    if (dgamma && blocks > 1) {
+        hipLaunchKernelGGL(ln_param_finalize_kernel, dim3(r3d_cdiv(2 * H, 256)), dim3(256), 0, s, ws, blocks, H,
+                           dgamma, dbeta);
+        R3D_LAUNCH_CHECK();
+    }
+    return R3D_OK;
+}
+
+static int colsum_chunks(int rows) { int c = r3d_cdiv(rows, 64); return c < 1 ? 1 : (c > 32 ? 32 : c); }
+
+R3D_EXPORT int64_t r3d_colsum_ws_floats(int rows, int cols) {
+    const int ch = colsum_chunks(rows);
+    return ch > 1 ? (int64_t)ch * cols : 0;
+}
+
+/* out[c] (+)= sum_r x[r, c] -- bias gradients (the db of every nn.Linear autograd derives for the reference). */
+R3D_EXPORT int r3d_colsum(const float* x, int ld, int rows, int cols, float* out, float* ws, int accumulate,
+                          void* stream) {
+    R3D_REQUIRE(x && out && rows > 0 && cols > 0 && ld >= cols);
+    const int ch = colsum_chunks(rows);
+    R3D_REQUIRE(ch == 1 || ws);
+    hipStream_t s = (hipStream_t)stream;
+    const int rpc = r3d_cdiv(rows, ch);
+    hipLaunchKernelGGL(colsum_kernel, dim3(r3d_cdiv(cols, 64), ch), dim3(256), 0, s, x, ld, rows, cols, rpc, out, ws,
+                       accumulate);
+    R3D_LAUNCH_CHECK();
+    if (ch > 1) {
+        hipLaunchKernelGGL(chunk_sum_kernel, dim3(r3d_cdiv(cols, 256)), dim3(256), 0, s, ws, ch, cols, out, accumulate);
+        R3D_LAUNCH_CHECK();
+    }
+    return R3D_OK;
+}
+
+/* out[r, c] (+)= sum over rows with (row % mod) == r of x[row, c] -- gradient of parameters that the forward
+ * broadcasts over clips: query_embed (futr_safuser_tokenfusion.py:205-209) and pos_embedding[:, :S] (:190). */
+R3D_EXPORT int r3d_rowmod_sum(const float* x, int ld, int rows, int cols, int mod, float* out, int ldo,
+                              int accumulate, void* stream) {
+    R3D_REQUIRE(x && out && rows > 0 && cols > 0 && mod > 0 && ld >= cols && ldo >= cols);
+    hipLaunchKernelGGL(rowmod_sum_kernel, dim3(r3d_cdiv(cols, 256), mod), dim3(256), 0, (hipStream_t)stream, x, ld,
+                       rows, cols, mod, out, ldo, accumulate);
+    R3D_LAUNCH_CHECK();
+    return R3D_OK;
+}

@@ -1,0 +1,268 @@
+"""Tensor-level wrappers over the C ABI (include/r3d_hip.h).  PyTorch is only plumbing here: it owns the device
+buffers and the stream; every call enqueues hand-written HIP kernels on torch's current stream."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import GemmDesc, GEMM_NT, GEMM_NN, GEMM_TN, check
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    if t is None:
+        return None
+    assert t.is_cuda, "r3d_amd kernels take device tensors only"
+    return C.c_void_p(t.data_ptr())
+
+
+def _f32(t, name="tensor"):
+    assert t.dtype == torch.float32 and t.is_cuda, f"{name} must be a float32 device tensor"
+    return t
+
+
+def _ld(t):
+    """leading dimension of a 2-D row-major (possibly column-sliced) tensor"""
+    assert t.dim() == 2 and t.stride(1) == 1, "expected a 2-D tensor with unit column stride"
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+# ----------------------------------------------------------------------------------------------------------
+# GEMM
+# ----------------------------------------------------------------------------------------------------------
+class GemmWorkspace:
+    """Grow-only split-K slab buffer shared by all GEMMs of a stream-ordered step."""
+
+    def __init__(self, device):
+        self.device = device
+        self.buf = None
+
+    def get(self, nfloats):
+        if nfloats <= 0:
+            return None
+        if self.buf is None or self.buf.numel() < nfloats:
+            self.buf = torch.empty(int(nfloats), dtype=torch.float32, device=self.device)
+        return self.buf
+
+
+def gemm(layout, a, b, c, *, bias=None, act=0, pre_out=None, a_add=None, a_add_mod=0, a_row_xor=0,
+         drop_mask=None, drop_scale=1.0, aux=None, mul=0, res1=None, res2=None, alpha=1.0, accumulate=False,
+         ws=None, tile=0, splitk=0, defer_reduce=False):
+    """C = epilogue(A op B), see r3d_gemm_desc.  Shapes: NT a[M,K] b[N,K]; NN a[M,K] b[K,N]; TN a[K,M] b[K,N].
+    Returns the (filled) descriptor; with defer_reduce=True and split-K the caller reduces the slabs itself
+    (e.g. through layernorm_fwd(nsplit=...))."""
+    lib = _lib.load()
+    _f32(a, "A"), _f32(b, "B"), _f32(c, "C")
+    d = GemmDesc()
+    if layout == GEMM_NT:
+        M, K = a.shape
+        N = b.shape[0]
+        assert b.shape[1] == K
+    elif layout == GEMM_NN:
+        M, K = a.shape
+        N = b.shape[1]
+        assert b.shape[0] == K
+    else:
+        K, M = a.shape
+        N = b.shape[1]
+        assert b.shape[0] == K
+    assert tuple(c.shape) == (M, N), f"C is {tuple(c.shape)}, expected {(M, N)}"
+    d.A, d.B, d.C = a.data_ptr(), b.data_ptr(), c.data_ptr()
+    d.layout, d.M, d.N, d.K = layout, M, N, K
+    d.lda, d.ldb, d.ldc = _ld(a), _ld(b), _ld(c)
+    if a_add is not None:
+        d.a_add, d.a_add_mod, d.a_add_ld = a_add.data_ptr(), a_add_mod, _ld(a_add)
+    d.a_row_xor = a_row_xor
+    if bias is not None:
+        assert bias.numel() == N
+        d.bias = bias.data_ptr()
+    if pre_out is not None:
+        d.pre_out, d.ldpre = pre_out.data_ptr(), _ld(pre_out)
+    d.act = act
+    if drop_mask is not None:
+        assert drop_mask.dtype == torch.uint8
+        d.drop_mask, d.lddrop, d.drop_scale = drop_mask.data_ptr(), _ld(drop_mask), drop_scale
+    if aux is not None:
+        d.aux, d.ldaux = aux.data_ptr(), _ld(aux)
+    d.mul = mul
+    if res1 is not None:
+        d.res1, d.ldr1 = res1.data_ptr(), _ld(res1)
+    if res2 is not None:
+        d.res2, d.ldr2 = res2.data_ptr(), _ld(res2)
+    d.alpha, d.accumulate = alpha, 1 if accumulate else 0
+    check(lib.r3d_gemm_plan(C.byref(d)), "r3d_gemm_plan")
+    if tile:
+        d.tile = tile
+    if splitk:
+        if splitk == 1:
+            d.splitk, d.k_per_split = 1, K
+        else:
+            kps = ((K + splitk - 1) // splitk + 15) // 16 * 16
+            d.splitk, d.k_per_split = (K + kps - 1) // kps, kps
+            if d.splitk < 2:
+                d.splitk, d.k_per_split = 1, K
+    if d.splitk > 1:
+        assert ws is not None, "split-K needs a GemmWorkspace"
+        d.partial = ws.get(lib.r3d_gemm_partial_floats(M, N, d.splitk)).data_ptr()
+    s = _stream()
+    check(lib.r3d_gemm_f32(C.byref(d), s), "r3d_gemm_f32")
+    if d.splitk > 1 and not defer_reduce:
+        check(lib.r3d_splitk_reduce(C.byref(d), s), "r3d_splitk_reduce")
+    return d
+
+
+# ----------------------------------------------------------------------------------------------------------
+# row-wise
+# ----------------------------------------------------------------------------------------------------------
+def layernorm_fwd(x, gamma, beta, y, mean, rstd, *, relu=False, pair_out=None, nsplit=0, bias=None, pre_out=None,
+                  rows=None, H=None):
+    lib = _lib.load()
+    if nsplit > 0:
+        assert rows is not None and H is not None
+        ldx = H
+    else:
+        rows, H = x.shape
+        ldx = _ld(x)
+    check(lib.r3d_layernorm_fwd(_p(x), ldx, nsplit, _p(bias), _p(pre_out), _p(gamma), _p(beta), _p(y), _ld(y), _p(mean),
+                                _p(rstd), _p(pair_out), rows, H, 1 if relu else 0, _stream()), "r3d_layernorm_fwd")
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, beta, dx, dgamma, dbeta, *, pair_in=False, relu=False, add1=None, add2=None,
+                  dx2=None, drop_mask=None, drop_scale=1.0, ws=None):
+    lib = _lib.load()
+    rows, H = x.shape
+    need = lib.r3d_layernorm_bwd_ws_floats(rows, H)
+    wsb = ws.get(need) if (need > 0 and dgamma is not None) else None
+    check(lib.r3d_layernorm_bwd(_p(dy), _ld(dy), 1 if pair_in else 0, _p(x), _ld(x), _p(mean), _p(rstd), _p(gamma), _p(beta),
+                                1 if relu else 0, _p(add1), _ld(add1) if add1 is not None else 0, _p(add2),
+                                _ld(add2) if add2 is not None else 0, _p(dx), _ld(dx), _p(dx2),
+                                _ld(dx2) if dx2 is not None else 0, _p(drop_mask),
+                                _ld(drop_mask) if drop_mask is not None else 0, drop_scale, _p(dgamma), _p(dbeta),
+                                _p(wsb), rows, H, _stream()), "r3d_layernorm_bwd")
+
+
+def colsum(x, out, *, accumulate=False, ws=None):
+    lib = _lib.load()
+    rows, cols = x.shape
+    need = lib.r3d_colsum_ws_floats(rows, cols)
+    wsb = ws.get(need) if need > 0 else None
+    check(lib.r3d_colsum(_p(x), _ld(x), rows, cols, _p(out), _p(wsb), 1 if accumulate else 0, _stream()), "r3d_colsum")
+
+
+def rowmod_sum(x, mod, out, *, accumulate=False):
+    lib = _lib.load()
+    rows, cols = x.shape
+    check(lib.r3d_rowmod_sum(_p(x), _ld(x), rows, cols, mod, _p(out), _ld(out), 1 if accumulate else 0, _stream()),
+          "r3d_rowmod_sum")
+
+
+# ----------------------------------------------------------------------------------------------------------
+# token selection / exchange
+# ----------------------------------------------------------------------------------------------------------
+def colabssum(x, out):
+    lib = _lib.load()
+    rows, cols = x.shape
+    assert out.dtype == torch.float64
+    check(lib.r3d_colabssum(_p(x), _ld(x), rows, cols, _p(out), _stream()), "r3d_colabssum")
+
+
+def token_select(k, idx_out, mask_out, *, score_f=None, score_sum=None, count=0.0, used_serial=None):
+    lib = _lib.load()
+    src = score_f if score_f is not None else score_sum
+    nvec, Cc = src.shape
+    assert src.is_contiguous() and idx_out.dtype == torch.int64 and tuple(idx_out.shape) == (nvec, k)
+    check(lib.r3d_token_select(_p(score_f), _p(score_sum), float(count), nvec, Cc, k, _p(idx_out), _p(mask_out),
+                               _p(used_serial), _stream()), "r3d_token_select")
+
+
+def token_exchange_fwd(rgb, dep, mask_rgb, mask_dep, x0, *, drop_mask=None, drop_scale=1.0):
+    lib = _lib.load()
+    N, H = rgb.shape
+    assert rgb.is_contiguous() and dep.is_contiguous() and x0.is_contiguous()
+    check(lib.r3d_token_exchange_fwd(_p(rgb), _p(dep), _p(mask_rgb), _p(mask_dep), _p(x0), _p(drop_mask), drop_scale, N, H,
+                                     _stream()), "r3d_token_exchange_fwd")
+
+
+def token_exchange_bwd(dx0, rgb, mask_rgb, mask_dep, d_rgb_pre, d_dep, *, drop_mask=None, drop_scale=1.0):
+    lib = _lib.load()
+    N, H = rgb.shape
+    check(lib.r3d_token_exchange_bwd(_p(dx0), _p(rgb), _p(mask_rgb), _p(mask_dep), _p(drop_mask), drop_scale, _p(d_rgb_pre),
+                                     _p(d_dep), N, H, _stream()), "r3d_token_exchange_bwd")
+
+
+# ----------------------------------------------------------------------------------------------------------
+# attention core
+# ----------------------------------------------------------------------------------------------------------
+def mha_core_fwd(q, k, v, probs, o, B, heads, Lq, Lk, dh, *, kpm=None, drop_mask=None, drop_scale=1.0):
+    lib = _lib.load()
+    check(lib.r3d_mha_core_fwd(_p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), _p(kpm), _p(probs), _p(drop_mask), drop_scale,
+                               _p(o), _ld(o), B, heads, Lq, Lk, dh, _stream()), "r3d_mha_core_fwd")
+
+
+def mha_core_bwd(q, k, v, probs, d_o, dq, dk, dv, B, heads, Lq, Lk, dh, *, drop_mask=None, drop_scale=1.0):
+    lib = _lib.load()
+    check(lib.r3d_mha_core_bwd(_p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), _p(probs), _p(drop_mask), drop_scale, _p(d_o),
+                               _ld(d_o), _p(dq), _ld(dq), _p(dk), _ld(dk), _p(dv), _ld(dv), B, heads, Lq, Lk, dh,
+                               _stream()), "r3d_mha_core_bwd")
+
+
+# ----------------------------------------------------------------------------------------------------------
+# losses / optimiser / dropout / erank
+# ----------------------------------------------------------------------------------------------------------
+def losses_fwd_bwd(seg, act, dur, ld_dur, past_label, target, target_dur, B, S, Q, K, pad_idx, exclude_idx, loss_out,
+                   counts, *, val_mode=False, dur_den=None, grad_scale=1.0, d_seg=None, d_act=None, d_dur=None,
+                   ld_ddur=1):
+    lib = _lib.load()
+    assert past_label.dtype == torch.int64 and target.dtype == torch.int64 and target_dur.dtype == torch.float32
+    assert past_label.is_contiguous() and target.is_contiguous() and target_dur.is_contiguous()
+    assert counts.dtype == torch.int64 and loss_out.dtype == torch.float32
+    check(lib.r3d_losses_fwd_bwd(_p(seg), _ld(seg) if seg is not None else 0, _p(act), _ld(act), _p(dur), ld_dur,
+                                 _p(past_label), _p(target), _p(target_dur), B, S, Q, K, pad_idx, exclude_idx,
+                                 1 if val_mode else 0, _p(dur_den), grad_scale, _p(d_seg),
+                                 _ld(d_seg) if d_seg is not None else 0, _p(d_act), _ld(d_act) if d_act is not None else 0,
+                                 _p(d_dur), ld_ddur, _p(loss_out), _p(counts), _stream()), "r3d_losses_fwd_bwd")
+
+
+def adamw_flat(p, g, m, v, lr_t, step_t, *, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, grad_scale=1.0):
+    lib = _lib.load()
+    n = p.numel()
+    assert g.numel() == n and m.numel() == n and v.numel() == n
+    assert lr_t.dtype == torch.float32 and step_t.dtype == torch.int64
+    check(lib.r3d_adamw_flat(_p(p), _p(g), _p(m), _p(v), n, _p(lr_t), _p(step_t), beta1, beta2, eps, weight_decay, grad_scale,
+                             _stream()), "r3d_adamw_flat")
+
+
+def dropout_mask(mask, p, seed, offset_t=None):
+    lib = _lib.load()
+    assert mask.dtype == torch.uint8 and mask.is_contiguous()
+    check(lib.r3d_dropout_mask(_p(mask), mask.numel(), p, C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), _p(offset_t), _stream()),
+          "r3d_dropout_mask")
+
+
+def erank_fits(R, Cc):
+    return _lib.load().r3d_erank_lds_bytes(R, Cc) <= 160 * 1024 - 256
+
+
+def erank_jacobi(x, sigma, stats, *, af_t=None, gram=False, max_sweeps=30):
+    """x: [batch, R, C] contiguous (or [R, C])."""
+    lib = _lib.load()
+    if x.dim() == 2:
+        x = x.unsqueeze(0)
+    batch, R, Cc = x.shape
+    assert x.stride(2) == 1
+    check(lib.r3d_erank_jacobi(_p(x), x.stride(1), x.stride(0), batch, R, Cc, 1 if gram else 0, _p(sigma), _p(af_t), _p(stats),
+                               max_sweeps, _stream()), "r3d_erank_jacobi")
+
+
+def erank_bwd_coef(sigma, stats, gout, coef):
+    lib = _lib.load()
+    check(lib.r3d_erank_bwd_coef(_p(sigma), _p(stats), _p(gout), _p(coef), sigma.numel(), _stream()), "r3d_erank_bwd_coef")
+
+
+def scale_rows(x, coef):
+    lib = _lib.load()
+    rows, cols = x.shape
+    check(lib.r3d_scale_rows(_p(x), _ld(x), rows, cols, _p(coef), _stream()), "r3d_scale_rows")

@@ -1,0 +1,389 @@
+"""Per-kernel parity of libr3d_hip.so (called through the C ABI via r3d_amd.ops) against plain PyTorch fp32/fp64
+CPU references of the same op, and against the oracle where the op is index / integer work.  Needs an MI355X."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from tests.helpers import assert_close  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    from r3d_amd import ops as o
+    return o
+
+
+def dev(t):
+    return t.to("cuda")
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).float()
+
+
+# ----------------------------------------------------------------------------------------------------------
+# GEMM
+# ----------------------------------------------------------------------------------------------------------
+def _gemm_ref(layout, a, b):
+    a, b = a.double(), b.double()
+    if layout == 0:
+        return a @ b.t()
+    if layout == 1:
+        return a @ b
+    return a.t() @ b
+
+
+def _mk_ab(layout, M, N, K, pad, seed):
+    """operands with leading dimension = cols + pad (pad not multiple of 4 -> scalar-load twin)"""
+    sa = (M, K) if layout in (0, 1) else (K, M)
+    sb = (N, K) if layout == 0 else (K, N)
+    A = rnd(sa[0], sa[1] + pad, seed=seed)
+    B = rnd(sb[0], sb[1] + pad, seed=seed + 1)
+    return A, B, A[:, :sa[1]], B[:, :sb[1]]
+
+
+@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("tile", [1, 2, 3])
+@pytest.mark.parametrize("shape", [(128, 128, 256), (50, 17, 33), (64, 1, 128), (130, 260, 70), (8, 384, 128)])
+@pytest.mark.parametrize("pad", [0, 3])
+def test_gemm_layouts_tiles(ops, layout, tile, shape, pad):
+    M, N, K = shape
+    A, B, Av, Bv = _mk_ab(layout, M, N, K, pad, seed=M + N + K + layout)
+    Ad, Bd = dev(A), dev(B)
+    sa1 = K if layout in (0, 1) else M
+    sb1 = K if layout == 0 else N
+    Cd = torch.full((M, N), float("nan"), device="cuda")
+    ops.gemm(layout, Ad[:, :sa1], Bd[:, :sb1], Cd, tile=tile, splitk=1)
+    torch.cuda.synchronize()
+    assert_close(Cd.cpu(), _gemm_ref(layout, Av, Bv), 1e-4, 1e-4 * math.sqrt(K), f"gemm L{layout} t{tile} {shape}")
+
+
+@pytest.mark.parametrize("layout", [0, 1, 2])
+def test_gemm_splitk_and_auto_plan(ops, layout):
+    ws = ops.GemmWorkspace("cuda")
+    for (M, N, K) in [(128, 128, 2048), (16, 32, 50176), (96, 40, 1000)]:
+        A, B, Av, Bv = _mk_ab(layout, M, N, K, 0, seed=K)
+        Cd = torch.full((M, N), float("nan"), device="cuda")
+        d = ops.gemm(layout, dev(A), dev(B), Cd, ws=ws)            # auto plan
+        torch.cuda.synchronize()
+        assert_close(Cd.cpu(), _gemm_ref(layout, Av, Bv), 2e-4, 2e-4 * math.sqrt(K), f"auto L{layout} {M,N,K} splitk={d.splitk}")
+        Cd.fill_(float("nan"))
+        ops.gemm(layout, dev(A), dev(B), Cd, ws=ws, splitk=7, tile=2)
+        torch.cuda.synchronize()
+        assert_close(Cd.cpu(), _gemm_ref(layout, Av, Bv), 2e-4, 2e-4 * math.sqrt(K), f"splitk7 L{layout} {M,N,K}")
+
+
+def test_gemm_epilogue_and_prologue(ops):
+    ws = ops.GemmWorkspace("cuda")
+    M, N, K = 96, 72, 64
+    A, B = rnd(M, K, seed=1), rnd(N, K, seed=2)
+    bias, res1, res2, aux = rnd(N, seed=3), rnd(M, N, seed=4), rnd(M, N, seed=5), rnd(M, N, seed=6)
+    add = rnd(8, K, seed=7)
+    mask = (torch.rand(M, N, generator=torch.Generator().manual_seed(8)) > 0.3).to(torch.uint8)
+    c0 = rnd(M, N, seed=9)
+    for splitk in (1, 2):
+        for act in (0, 1, 2):
+            for mul in (0, 1, 2):
+                Cd = dev(c0.clone())
+                pre = torch.empty(M, N, device="cuda")
+                ops.gemm(0, dev(A), dev(B), Cd, bias=dev(bias), act=act, pre_out=pre, a_add=dev(add), a_add_mod=8,
+                         a_row_xor=1, drop_mask=dev(mask), drop_scale=1.25, aux=dev(aux), mul=mul, res1=dev(res1),
+                         res2=dev(res2), alpha=0.5, accumulate=True, ws=ws, splitk=splitk, tile=1)
+                torch.cuda.synchronize()
+                rows = torch.arange(M)
+                Ap = A[rows ^ 1].double() + add[rows % 8].double()
+                v = 0.5 * (Ap @ B.double().t()) + bias.double()
+                ref_pre = v.clone()
+                if act == 1:
+                    v = v.relu()
+                elif act == 2:
+                    v = F.gelu(v)
+                v = v * 1.25 * mask.double()
+                if mul == 1:
+                    v = v * (aux > 0).double()
+                elif mul == 2:
+                    x = aux.double()
+                    v = v * (0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi))
+                v = v + res1.double() + res2.double() + c0.double()
+                assert_close(pre.cpu(), ref_pre, 1e-4, 1e-4, f"pre_out sk{splitk}")
+                assert_close(Cd.cpu(), v, 1e-4, 1e-4, f"epilogue sk{splitk} act{act} mul{mul}")
+
+
+def test_gemm_rejects_bad_arguments(ops):
+    from r3d_amd._lib import R3DHipError
+    a, b, c = torch.zeros(4, 8, device="cuda"), torch.zeros(4, 8, device="cuda"), torch.zeros(4, 4, device="cuda")
+    with pytest.raises(R3DHipError):
+        ops.gemm(0, a, b, c, mul=1)                      # mul without aux
+    with pytest.raises(R3DHipError):
+        ops.gemm(0, torch.zeros(3, 8, device="cuda"), b, torch.zeros(3, 4, device="cuda"), a_row_xor=1)  # odd M
+
+
+# ----------------------------------------------------------------------------------------------------------
+# LayerNorm / reductions
+# ----------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows,H", [(7, 32), (128, 128), (256, 512), (70, 1024), (3, 1536)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_layernorm_fwd_bwd(ops, rows, H, relu):
+    ws = ops.GemmWorkspace("cuda")
+    x, g, b = rnd(rows, H, seed=1), 1 + 0.2 * rnd(H, seed=2), 0.1 * rnd(H, seed=3)
+    dy, add1 = rnd(rows, H, seed=4), rnd(rows, H, seed=5)
+    xr = x.double().requires_grad_(True)
+    gr, br = g.double().requires_grad_(True), b.double().requires_grad_(True)
+    y = F.layer_norm(xr, (H,), gr, br, 1e-5)
+    if relu:
+        y = y.relu()
+    y.backward(dy.double())
+    yd, mean, rstd = torch.empty(rows, H, device="cuda"), torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
+    ops.layernorm_fwd(dev(x), dev(g), dev(b), yd, mean, rstd, relu=relu)
+    dx, dg, db = torch.empty(rows, H, device="cuda"), torch.empty(H, device="cuda"), torch.empty(H, device="cuda")
+    ops.layernorm_bwd(dev(dy), dev(x), mean, rstd, dev(g), dev(b), dx, dg, db, relu=relu, add1=dev(add1), ws=ws)
+    torch.cuda.synchronize()
+    assert_close(yd.cpu(), y.detach(), 1e-4, 1e-5, "ln y")
+    assert_close(dx.cpu(), xr.grad + add1.double(), 1e-3, 1e-4, "ln dx")
+    assert_close(dg.cpu(), gr.grad, 1e-3, 1e-3, "ln dgamma")
+    assert_close(db.cpu(), br.grad, 1e-3, 1e-3, "ln dbeta")
+
+
+def test_layernorm_pair_mean_and_splitk_input(ops):
+    ws = ops.GemmWorkspace("cuda")
+    rows, H, ns = 64, 128, 5
+    part, bias = rnd(ns, rows, H, seed=1), rnd(H, seed=2)
+    g, b = 1 + 0.2 * rnd(H, seed=3), 0.1 * rnd(H, seed=4)
+    pre = part.double().sum(0) + bias.double()
+    y = F.layer_norm(pre, (H,), g.double(), b.double(), 1e-5).relu()
+    yd, mean, rstd = torch.empty(rows, H, device="cuda"), torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
+    pre_d, pair = torch.empty(rows, H, device="cuda"), torch.empty(rows // 2, H, device="cuda")
+    ops.layernorm_fwd(dev(part), dev(g), dev(b), yd, mean, rstd, relu=True, pair_out=pair, nsplit=ns, bias=dev(bias),
+                      pre_out=pre_d, rows=rows, H=H)
+    torch.cuda.synchronize()
+    assert_close(pre_d.cpu(), pre, 1e-5, 1e-5, "pre")
+    assert_close(yd.cpu(), y, 1e-4, 1e-5, "y")
+    assert_close(pair.cpu(), y.view(rows // 2, 2, H).mean(1), 1e-4, 1e-5, "pair mean")
+    # pair_in backward
+    x = rnd(rows, H, seed=5)
+    dyp = rnd(rows // 2, H, seed=6)
+    xr = x.double().requires_grad_(True)
+    gr, br = g.double().requires_grad_(True), b.double().requires_grad_(True)
+    F.layer_norm(xr, (H,), gr, br, 1e-5).view(rows // 2, 2, H).mean(1).backward(dyp.double())
+    ops.layernorm_fwd(dev(x), dev(g), dev(b), yd, mean, rstd)
+    dx, dg, db = torch.empty(rows, H, device="cuda"), torch.empty(H, device="cuda"), torch.empty(H, device="cuda")
+    ops.layernorm_bwd(dev(dyp), dev(x), mean, rstd, dev(g), dev(b), dx, dg, db, pair_in=True, ws=ws)
+    torch.cuda.synchronize()
+    assert_close(dx.cpu(), xr.grad, 1e-3, 1e-5, "pair dx")
+    assert_close(dg.cpu(), gr.grad, 1e-3, 1e-4, "pair dgamma")
+    assert_close(db.cpu(), br.grad, 1e-3, 1e-4, "pair dbeta")
+
+
+@pytest.mark.parametrize("rows,cols", [(5, 17), (128, 128), (1000, 513)])
+def test_colsum_rowmod(ops, rows, cols):
+    ws = ops.GemmWorkspace("cuda")
+    x = rnd(rows, cols, seed=rows)
+    out = dev(torch.ones(cols))
+    ops.colsum(dev(x), out, accumulate=True, ws=ws)
+    mod = 5
+    o2 = torch.zeros(mod, cols, device="cuda")
+    ops.rowmod_sum(dev(x), mod, o2)
+    torch.cuda.synchronize()
+    assert_close(out.cpu(), x.double().sum(0) + 1, 1e-4, 1e-3, "colsum")
+    ref = torch.stack([x[r::mod].double().sum(0) for r in range(mod)])
+    assert_close(o2.cpu(), ref, 1e-4, 1e-3, "rowmod")
+
+
+# ----------------------------------------------------------------------------------------------------------
+# token selection (bit-exact vs the oracle / torch.topk) and exchange
+# ----------------------------------------------------------------------------------------------------------
+def test_token_select_matches_cpu_topk(ops, oracle_lib):
+    from oracle import futr_oracle as O
+    rng = np.random.default_rng(0)
+    for Cc in (32, 128, 512, 1024):
+        k = Cc // 4
+        vecs = [np.full(Cc, 1.0 / (8 * 16 * Cc), np.float32), rng.random(Cc).astype(np.float32),
+                rng.integers(0, 3, Cc).astype(np.float32), rng.integers(0, Cc // 2 + 1, Cc).astype(np.float32)]
+        s = torch.from_numpy(np.stack(vecs))
+        idx = torch.empty(len(vecs), k, dtype=torch.int64, device="cuda")
+        mask = torch.empty(len(vecs), Cc, device="cuda")
+        used = torch.zeros(len(vecs), dtype=torch.int32, device="cuda")
+        ops.token_select(k, idx, mask, score_f=dev(s), used_serial=used)
+        torch.cuda.synchronize()
+        for v in range(len(vecs)):
+            want = O.select_smallest(vecs[v], k)
+            ref = np.sort(torch.topk(torch.from_numpy(vecs[v]).view(1, 1, Cc), k, dim=-1, largest=False)[1].view(-1).numpy())
+            assert np.array_equal(want, ref)
+            assert np.array_equal(idx[v].cpu().numpy(), want), (Cc, v)
+            m = np.zeros(Cc, np.float32)
+            m[want] = 1
+            assert np.array_equal(mask[v].cpu().numpy(), m)
+        assert used.cpu().tolist()[0] == 1 and used.cpu().tolist()[1] == 0      # all-equal -> tie path; distinct -> parallel
+
+
+def test_colabssum_and_select_from_sums(ops, oracle_lib):
+    from oracle import futr_oracle as O
+    rows, Cc = 176, 128
+    x = rnd(2, rows, Cc, seed=3)
+    sums = torch.empty(2, Cc, dtype=torch.float64, device="cuda")
+    ops.colabssum(dev(x[0]), sums[0])
+    ops.colabssum(dev(x[1]), sums[1])
+    idx = torch.empty(2, Cc // 4, dtype=torch.int64, device="cuda")
+    mask = torch.empty(2, Cc, device="cuda")
+    ops.token_select(Cc // 4, idx, mask, score_sum=sums, count=float(rows))
+    torch.cuda.synchronize()
+    assert_close(sums.cpu(), x.double().abs().sum(1), 1e-12, 1e-9, "abs sums")
+    for v in range(2):
+        want = O.select_smallest(x[v].abs().mean(0).numpy(), Cc // 4)
+        assert np.array_equal(idx[v].cpu().numpy(), want)
+
+
+def test_token_exchange_fwd_bwd(ops):
+    N, H = 37, 64
+    rgb, dep = rnd(N, H, seed=1).relu(), rnd(N, H, seed=2).relu()
+    g = torch.Generator().manual_seed(3)
+    mr = torch.zeros(H)
+    md = torch.zeros(H)
+    mr[torch.randperm(H, generator=g)[:H // 4]] = 1
+    md[torch.randperm(H, generator=g)[:H // 4]] = 1
+    keep = (torch.rand(2 * N, H, generator=g) > 0.1).to(torch.uint8)
+    x0 = torch.empty(2 * N, H, device="cuda")
+    ops.token_exchange_fwd(dev(rgb), dev(dep), dev(mr), dev(md), x0, drop_mask=dev(keep), drop_scale=1 / 0.9)
+    r, d = rgb.double().requires_grad_(True), dep.double().requires_grad_(True)
+    ex_r = torch.where(mr.bool(), d, r)
+    ex_d = torch.where(md.bool(), r, d)
+    st = torch.stack([ex_r, ex_d], 1).reshape(2 * N, H) * keep.double() / 0.9
+    dx0 = rnd(2 * N, H, seed=4)
+    st.backward(dx0.double())
+    drp, ddp = torch.empty(N, H, device="cuda"), torch.empty(N, H, device="cuda")
+    ops.token_exchange_bwd(dev(dx0), dev(rgb), dev(mr), dev(md), drp, ddp, drop_mask=dev(keep), drop_scale=1 / 0.9)
+    torch.cuda.synchronize()
+    assert_close(x0.cpu(), st.detach(), 1e-6, 1e-6, "exchange fwd")
+    assert_close(drp.cpu(), r.grad * (rgb > 0).double(), 1e-6, 1e-6, "d_rgb_pre")
+    assert_close(ddp.cpu(), d.grad, 1e-6, 1e-6, "d_dep")
+
+
+# ----------------------------------------------------------------------------------------------------------
+# attention core
+# ----------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,heads,Lq,Lk,dh,masked,drop", [(3, 8, 8, 8, 16, False, False), (2, 8, 8, 21, 16, True, False),
+                                                           (2, 4, 8, 130, 64, True, True), (1, 8, 8, 700, 4, False, False)])
+def test_mha_core(ops, B, heads, Lq, Lk, dh, masked, drop):
+    H = heads * dh
+    q, kv = rnd(B * Lq, H, seed=1), rnd(B * Lk, 2 * H, seed=2)
+    kpm = torch.zeros(B, Lk, dtype=torch.uint8)
+    if masked:
+        kpm[:, Lk - 3:] = 1
+        kpm[0, 1] = 1
+    g = torch.Generator().manual_seed(5)
+    keep = (torch.rand(B, heads, Lq, Lk, generator=g) > 0.1).to(torch.uint8) if drop else None
+    dsc = 1 / 0.9 if drop else 1.0
+    d_o = rnd(B * Lq, H, seed=3)
+    qr, kvr = q.double().requires_grad_(True), kv.double().requires_grad_(True)
+    qh = qr.view(B, Lq, heads, dh).transpose(1, 2)
+    kh = kvr[:, :H].reshape(B, Lk, heads, dh).transpose(1, 2)
+    vh = kvr[:, H:].reshape(B, Lk, heads, dh).transpose(1, 2)
+    att = (qh @ kh.transpose(-2, -1)) / math.sqrt(dh)
+    att = att.masked_fill(kpm.bool()[:, None, None, :], float("-inf")).softmax(-1)
+    attd = att * keep.double() * dsc if drop else att
+    o = (attd @ vh).transpose(1, 2).reshape(B * Lq, H)
+    o.backward(d_o.double())
+    qd, kvd = dev(q), dev(kv)
+    probs = torch.empty(B, heads, Lq, Lk, device="cuda")
+    od = torch.empty(B * Lq, H, device="cuda")
+    kd = dev(keep) if drop else None
+    ops.mha_core_fwd(qd, kvd[:, :H], kvd[:, H:], probs, od, B, heads, Lq, Lk, dh, kpm=dev(kpm) if masked else None,
+                     drop_mask=kd, drop_scale=dsc)
+    dq = torch.empty(B * Lq, H, device="cuda")
+    dkv = torch.empty(B * Lk, 2 * H, device="cuda")
+    ops.mha_core_bwd(qd, kvd[:, :H], kvd[:, H:], probs, dev(d_o), dq, dkv[:, :H], dkv[:, H:], B, heads, Lq, Lk, dh,
+                     drop_mask=kd, drop_scale=dsc)
+    torch.cuda.synchronize()
+    assert_close(probs.cpu(), att.detach(), 1e-4, 1e-6, "probs")
+    assert_close(od.cpu(), o.detach(), 1e-4, 1e-5, "attn out")
+    assert_close(dq.cpu(), qr.grad, 1e-3, 1e-5, "dq")
+    assert_close(dkv.cpu(), kvr.grad, 1e-3, 1e-5, "dkv")
+
+
+# ----------------------------------------------------------------------------------------------------------
+# losses / AdamW / dropout masks
+# ----------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,S,Q,K", [(8, 16, 8, 17), (3, 7, 8, 122), (1, 40, 8, 17)])
+def test_losses_match_oracle(ops, B, S, Q, K):
+    from oracle import futr_oracle as O, synth
+    pad = K + 1
+    _, _, lab, dur, tgt = [torch.from_numpy(x) for x in synth.make_batch(B, S, K, pad, 7, depth_hw=(2, 2))]
+    seg, act, du = rnd(B, S, K, seed=1), rnd(B, Q, K, seed=2), 0.5 * rnd(B, Q, seed=3)
+    segr, actr, dur_r = seg.clone().requires_grad_(True), act.clone().requires_grad_(True), du.clone().requires_grad_(True)
+    res = O.losses(dict(seg=segr, action=actr, duration=dur_r), lab, dur, tgt, pad)
+    res["loss"].backward()
+    comb = torch.cat([act.view(B * Q, K), du.view(B * Q, 1)], 1).contiguous()     # [BQ, K+1] as the engine lays it out
+    combd = dev(comb)
+    dcomb = torch.zeros_like(combd)
+    dseg = torch.empty(B * S, K, device="cuda")
+    loss, counts = torch.empty(4, device="cuda"), torch.empty(4, dtype=torch.int64, device="cuda")
+    ops.losses_fwd_bwd(dev(seg.view(B * S, K)), combd[:, :K], combd[:, K:], K + 1, dev(lab), dev(tgt), dev(dur), B, S, Q, K, pad,
+                       47, loss, counts, d_seg=dseg, d_act=dcomb[:, :K], d_dur=dcomb[:, K:], ld_ddur=K + 1)
+    torch.cuda.synchronize()
+    want = [float(res[k]) for k in ("loss_seg", "loss_action", "loss_dur", "loss")]
+    assert_close(loss.cpu(), want, 1e-5, 1e-6, "losses")
+    assert counts.cpu().tolist() == [res[k] for k in ("seg_correct", "seg_total", "act_correct", "act_total")]
+    assert_close(dseg.cpu().view(B, S, K), segr.grad, 1e-4, 1e-7, "d seg")
+    assert_close(dcomb[:, :K].cpu().reshape(B, Q, K), actr.grad, 1e-4, 1e-7, "d act")
+    assert_close(dcomb[:, K].cpu().reshape(B, Q), dur_r.grad, 1e-4, 1e-7, "d dur")
+
+
+def test_adamw_flat_matches_oracle(ops):
+    from oracle import futr_oracle as O
+    n = 4096 + 64
+    p, g = rnd(n, seed=1), rnd(n, seed=2) * 1e-2
+    m, v = torch.zeros(n), torch.zeros(n)
+    pd, md, vd = dev(p.clone()), dev(m.clone()), dev(v.clone())
+    lr_t = torch.tensor([1e-3], device="cuda")
+    step_t = torch.zeros(1, dtype=torch.int64, device="cuda")
+    for t in range(1, 4):
+        gt = g * t
+        O.adamw_step(p, gt, m, v, t, 1e-3, 5e-3)
+        step_t.add_(1)
+        ops.adamw_flat(pd, dev(gt * 2.0), md, vd, lr_t, step_t, weight_decay=5e-3, grad_scale=0.5)
+    torch.cuda.synchronize()
+    assert_close(pd.cpu(), p, 1e-5, 1e-6, "adamw p")
+    assert_close(md.cpu(), m, 1e-5, 1e-8, "adamw m")
+    assert_close(vd.cpu(), v, 1e-5, 1e-10, "adamw v")
+
+
+def test_dropout_mask_statistics(ops):
+    n = 1 << 20
+    mk = torch.empty(n, dtype=torch.uint8, device="cuda")
+    off = torch.zeros(1, dtype=torch.int64, device="cuda")
+    ops.dropout_mask(mk, 0.1, 1234, off)
+    a = mk.cpu().float()
+    off.add_(1)
+    ops.dropout_mask(mk, 0.1, 1234, off)
+    b = mk.cpu().float()
+    assert abs(float(a.mean()) - 0.9) < 2e-3 and abs(float(b.mean()) - 0.9) < 2e-3
+    assert float((a != b).float().mean()) > 0.1          # a new offset gives a new mask
+    assert set(a.unique().tolist()) <= {0.0, 1.0}
+
+
+# ----------------------------------------------------------------------------------------------------------
+# effective rank
+# ----------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("R,Cc", [(128, 128), (40, 24), (256, 128), (33, 64)])
+def test_erank_jacobi_vs_svdvals(ops, R, Cc):
+    from oracle import futr_oracle as O
+    x = rnd(R, Cc, seed=R) @ torch.diag(torch.linspace(0.05, 2.0, Cc)) + 0.3
+    sig, st = torch.empty(1, Cc, device="cuda"), torch.empty(1, 4, device="cuda")
+    aft = torch.empty(1, Cc, R, device="cuda")
+    ops.erank_jacobi(dev(x), sig, st, af_t=aft)
+    torch.cuda.synchronize()
+    sv = torch.linalg.svdvals(x.double())
+    assert_close(torch.sort(sig[0].cpu(), descending=True)[0][:min(R, Cc)], sv, 1e-4, 1e-4 * float(sv[0]), "sigma")
+    assert abs(float(st[0, 0]) - O.effective_rank(x)) < 5e-3, (float(st[0, 0]), O.effective_rank(x))
+    assert float(st[0, 3]) < 30
+    # rotated columns are orthogonal with norms sigma
+    G = aft[0].cpu().double() @ aft[0].cpu().double().t()
+    off = G - torch.diag(torch.diag(G))
+    assert float(off.abs().max()) < 1e-3 * float(sv[0]) ** 2
