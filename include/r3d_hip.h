@@ -54,6 +54,9 @@ int r3d_build_info(char* buf, int cap);
  *   act: 0 none | 1 relu | 2 exact-erf gelu;  v *= drop_scale*drop_mask[m,n] (if given);
  *   mul: 0 none | 1 v *= (aux[m,n] > 0) | 2 v *= gelu'(aux[m,n])         (backward of relu / gelu);
  *   v += res1[m,n] + res2[m,n] (if given);  if (accumulate) v += C[m,n];  C[m,n] = v.
+ *   c_row_xor = 1 applies the whole epilogue at row m^1 instead of m: the modality swap that the fuser's masked
+ *   2-token attention reduces to (softmax([[-inf,s],[s,-inf]]) = [[0,1],[1,0]] exactly; SURVEY.md F5b,
+ *   model/extras/transformerblock.py:24-33 under the mask of model/futr_safuser_tokenfusion.py:68-72).
  * splitk > 1: the K range is cut into `splitk` slabs of k_per_split (multiple of 16); raw partial sums go to
  *   `partial` ([splitk][M][N] floats, caller-owned) and r3d_splitk_reduce*() applies the epilogue.
  */
@@ -74,6 +77,7 @@ typedef struct r3d_gemm_desc {
     const float* res1; int32_t ldr1;
     const float* res2; int32_t ldr2;
     float alpha; int32_t accumulate;
+    int32_t c_row_xor;       /* output (and pre_out/aux/res/drop operand) row index = m ^ c_row_xor: pair swap at store */
     int32_t splitk, k_per_split; float* partial;
     int32_t tile;            /* 0 = auto; 1 = 32x32, 2 = 64x64, 3 = 128x128 workgroup tile (testing / tuning) */
 } r3d_gemm_desc;
@@ -98,6 +102,7 @@ int r3d_gemm_plan(r3d_gemm_desc* d);
  *   pair_out != NULL: rows come in (token, modality) pairs and pair_out[n] = (y[2n] + y[2n+1]) / 2, the
  *     torch.mean(x, dim=1) over the two modality tokens (:94).
  * r3d_layernorm_bwd: dx = LN'(dy) [+ add1 + add2]; dgamma/dbeta written (not accumulated).
+ *   dy2 (optional, same shape as x) is added to dy first (a second consumer of the LN output);
  *   pair_in: dy holds one row per pair and each row of the pair receives dy/2 (backward of the mean above);
  *   relu: dy is first masked by [LN(x) > 0] (recomputed);  dx2 (optional) = dx * drop_scale * drop_mask;
  *   ws: r3d_layernorm_bwd_ws_floats(rows, H) floats of scratch (0 when rows <= 64).
@@ -106,7 +111,8 @@ int r3d_layernorm_fwd(const float* x, int ldx, int nsplit, const float* bias, fl
                       const float* beta, float* y, int ldy, float* mean, float* rstd, float* pair_out, int rows, int H,
                       int relu, void* stream);
 int64_t r3d_layernorm_bwd_ws_floats(int rows, int H);
-int r3d_layernorm_bwd(const float* dy, int lddy, int pair_in, const float* x, int ldx, const float* mean,
+int r3d_layernorm_bwd(const float* dy, int lddy, int pair_in, const float* dy2, int lddy2, const float* x, int ldx,
+                      const float* mean,
                       const float* rstd, const float* gamma, const float* beta, int relu, const float* add1, int ldadd1,
                       const float* add2, int ldadd2, float* dx, int lddx, float* dx2, int lddx2,
                       const uint8_t* drop_mask, int lddrop, float drop_scale, float* dgamma, float* dbeta, float* ws,
@@ -118,6 +124,10 @@ int r3d_colsum(const float* x, int ld, int rows, int cols, float* out, float* ws
  * broadcasts over clips (model/futr_safuser_tokenfusion.py:190,205-209). */
 int r3d_rowmod_sum(const float* x, int ld, int rows, int cols, int mod, float* out, int ldo, int accumulate,
                    void* stream);
+
+/* out[r,:] = x[r,:] + add[r % mod,:]: with_pos_embed (model/extras/transformer.py:278-279,289,300-302); x may be NULL. */
+int r3d_add_rowbcast(const float* x, int ldx, const float* add, int ldadd, int mod, float* out, int ldo, int rows, int cols,
+                     void* stream);
 
 /* ---- token selection / exchange: CMFuser.token_fusion (model/futr_safuser_tokenfusion.py:33-66) ------------- */
 /* out[c] = sum_r |x[r,c]| in fp64 (the eval-mode score before the division by B*T, :49-50). */
@@ -137,10 +147,13 @@ int r3d_token_exchange_bwd(const float* dx0, const float* rgb, const float* mask
 
 /* ---- decoder attention core: nn.MultiheadAttention minus its projections (model/extras/transformer.py:289-304) --
  * q rows b*Lq+i, k/v rows b*Lk+j, head h in columns [h*dh, (h+1)*dh).  probs [B][heads][Lq][Lk] = softmax before
- * dropout (saved for backward).  key_padding_mask [B][Lk] (1 = padded) or NULL.  drop_mask like probs or NULL. */
+ * dropout (saved for backward).  Padded keys: key_padding_mask [B][Lk] (1 = padded) and/or key_label [B][Lk] int64
+ * with key padded iff label == pad_idx (get_pad_mask, model/futr_safuser_tokenfusion.py:168,243-244); both may be NULL.
+ * drop_mask like probs or NULL. */
 int r3d_mha_core_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
-                     const uint8_t* key_padding_mask, float* probs, const uint8_t* drop_mask, float drop_scale, float* o,
-                     int ldo, int B, int heads, int Lq, int Lk, int dh, void* stream);
+                     const uint8_t* key_padding_mask, const int64_t* key_label, int pad_idx, float* probs,
+                     const uint8_t* drop_mask, float drop_scale, float* o, int ldo, int B, int heads, int Lq, int Lk,
+                     int dh, void* stream);
 int r3d_mha_core_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* probs,
                      const uint8_t* drop_mask, float drop_scale, const float* d_o, int lddo, float* dq, int lddq, float* dk,
                      int lddk, float* dv, int lddv, int B, int heads, int Lq, int Lk, int dh, void* stream);

@@ -25,6 +25,7 @@ class GemmDesc(C.Structure):
         ("res1", C.c_void_p), ("ldr1", C.c_int32),
         ("res2", C.c_void_p), ("ldr2", C.c_int32),
         ("alpha", C.c_float), ("accumulate", C.c_int32),
+        ("c_row_xor", C.c_int32),
         ("splitk", C.c_int32), ("k_per_split", C.c_int32), ("partial", C.c_void_p),
         ("tile", C.c_int32),
     ]
@@ -43,7 +44,8 @@ _SIGNATURES = {
     "r3d_gemm_plan": ([C.POINTER(GemmDesc)], C.c_int),
     "r3d_layernorm_fwd": ([_P, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P], C.c_int),
     "r3d_layernorm_bwd_ws_floats": ([_I, _I], C.c_int64),
-    "r3d_layernorm_bwd": ([_P, _I, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _F,
+    "r3d_add_rowbcast": ([_P, _I, _P, _I, _I, _P, _I, _I, _I, _P], C.c_int),
+    "r3d_layernorm_bwd": ([_P, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _F,
                            _P, _P, _P, _I, _I, _P], C.c_int),
     "r3d_colsum_ws_floats": ([_I, _I], C.c_int64),
     "r3d_colsum": ([_P, _I, _I, _I, _P, _P, _I, _P], C.c_int),
@@ -52,7 +54,7 @@ _SIGNATURES = {
     "r3d_token_select": ([_P, _P, _D, _I, _I, _I, _P, _P, _P, _P], C.c_int),
     "r3d_token_exchange_fwd": ([_P, _P, _P, _P, _P, _P, _F, _I, _I, _P], C.c_int),
     "r3d_token_exchange_bwd": ([_P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _P], C.c_int),
-    "r3d_mha_core_fwd": ([_P, _I, _P, _I, _P, _I, _P, _P, _P, _F, _P, _I, _I, _I, _I, _I, _I, _P], C.c_int),
+    "r3d_mha_core_fwd": ([_P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P, _F, _P, _I, _I, _I, _I, _I, _I, _P], C.c_int),
     "r3d_mha_core_bwd": ([_P, _I, _P, _I, _P, _I, _P, _P, _F, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
                          C.c_int),
     "r3d_losses_fwd_bwd": ([_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _F, _P, _I, _P, _I,

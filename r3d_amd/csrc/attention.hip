@@ -12,6 +12,7 @@ namespace r3d {
 struct MhaArgs {
     const float* q; int ldq; const float* k; int ldk; const float* v; int ldv;
     const uint8_t* kpm;                 // [B][Lk], 1 = padded key (cross attention only), or NULL
+    const int64_t* key_label; int pad_idx;   // alternative form: key j of clip b is padded iff key_label[b][j] == pad_idx
     float* probs;                       // [B][heads][Lq][Lk] softmax output BEFORE dropout (saved for backward)
     const uint8_t* drop; float drop_scale;   // [B][heads][Lq][Lk] keep mask, or NULL
     float* o; int ldo;                  // fwd: attention output rows (b*Lq + i), columns h*dh + d
@@ -47,7 +48,8 @@ __global__ __launch_bounds__(64) void mha_fwd_kernel(const MhaArgs a) {
         __syncthreads();
         const int j = c0 + lane;
         if (j < Lk) {
-            const bool masked = a.kpm && a.kpm[(size_t)b * Lk + j];
+            const bool masked = (a.kpm && a.kpm[(size_t)b * Lk + j]) ||
+                                (a.key_label && a.key_label[(size_t)b * Lk + j] == (int64_t)a.pad_idx);
             for (int i = 0; i < Lq; ++i) {
                 float s = 0.f;
                 for (int d = 0; d < dh; ++d) s += qs[i * dh + d] * kc[lane * (dh + 1) + d];
@@ -172,11 +174,13 @@ static int mha_check(const MhaArgs& a, bool bwd) {
 using namespace r3d;
 
 R3D_EXPORT int r3d_mha_core_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
-                                const uint8_t* key_padding_mask, float* probs, const uint8_t* drop_mask,
+                                const uint8_t* key_padding_mask, const int64_t* key_label, int pad_idx, float* probs,
+                                const uint8_t* drop_mask,
                                 float drop_scale, float* o, int ldo, int B, int heads, int Lq, int Lk, int dh,
                                 void* stream) {
     MhaArgs a{};
     a.q = q; a.ldq = ldq; a.k = k; a.ldk = ldk; a.v = v; a.ldv = ldv; a.kpm = key_padding_mask; a.probs = probs;
+    a.key_label = key_label; a.pad_idx = pad_idx;
     a.drop = drop_mask; a.drop_scale = drop_scale; a.o = o; a.ldo = ldo;
     a.B = B; a.heads = heads; a.Lq = Lq; a.Lk = Lk; a.dh = dh; a.scale = 1.0f / sqrtf((float)dh);
     int rc = mha_check(a, false);

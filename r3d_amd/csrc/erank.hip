@@ -48,6 +48,18 @@ __global__ __launch_bounds__(64 * kJacWaves) void erank_jacobi_kernel(const Eran
         for (int r = tid; r < R; r += 64 * kJacWaves) A[C * Rp + r] = 0.f;
     __syncthreads();
 
+    // ||X||_F^2: columns whose squared norm falls below (1e-6 ||X||_F)^2 are numerically zero (rank-deficient
+    // input, e.g. R < C) and are not rotated against each other -- their mutual "angles" are rounding noise.
+    float fpart = 0.f;
+    for (int c = wave; c < C; c += kJacWaves)
+        for (int r = lane; r < R; r += 64) { const float u = A[c * Rp + r]; fpart += u * u; }
+    fpart = wave_sum(fpart);
+    if (lane == 0) wred[wave] = fpart;
+    __syncthreads();
+    float fro2 = 0.f;
+    for (int w = 0; w < kJacWaves; ++w) fro2 += wred[w];
+    __syncthreads();
+    const float negl = fro2 * 1e-12f;
     const float tol = sqrtf((float)R) * 1.1920929e-7f;
     const int npairs = Cp / 2, nrounds = Cp - 1;
     int sweeps = 0;
@@ -69,7 +81,7 @@ __global__ __launch_bounds__(64 * kJacWaves) void erank_jacobi_kernel(const Eran
                     al += u * u; be += v * v; ga += u * v;
                 }
                 al = wave_sum(al); be = wave_sum(be); ga = wave_sum(ga);
-                if (fabsf(ga) > tol * sqrtf(al * be) && al > 0.f && be > 0.f) {
+                if (fabsf(ga) > tol * sqrtf(al * be) && al > negl && be > negl) {
                     const float zeta = (be - al) / (2.f * ga);
                     const float t = (zeta >= 0.f ? 1.f : -1.f) / (fabsf(zeta) + sqrtf(1.f + zeta * zeta));
                     const float c = 1.f / sqrtf(1.f + t * t), s = c * t;

@@ -26,6 +26,7 @@ constexpr int BK = 16;
 // epilogue shared by the GEMM kernel and the split-K reducer
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void gemm_epilogue(const r3d_gemm_desc& d, int m, int n, float acc) {
+    m ^= d.c_row_xor;
     float v = d.alpha * acc;
     if (d.bias) v += d.bias[n];
     if (d.pre_out) d.pre_out[(size_t)m * d.ldpre + n] = v;
@@ -334,7 +335,8 @@ static int gemm_validate(const r3d_gemm_desc* d) {
     if (d->lda < a_min || d->ldb < b_min || d->ldc < d->N) return R3D_EINVAL;
     if (d->layout == R3D_GEMM_TN && (d->a_add || d->a_row_xor)) return R3D_EINVAL;
     if (d->a_add && (d->a_add_mod <= 0 || d->a_add_ld < d->K)) return R3D_EINVAL;
-    if (d->a_row_xor && (d->M & 1)) return R3D_EINVAL;            // pair swap needs an even row count
+    if ((d->a_row_xor || d->c_row_xor) && (d->M & 1)) return R3D_EINVAL;   // pair swap needs an even row count
+    if (d->c_row_xor < 0 || d->c_row_xor > 1) return R3D_EINVAL;
     if (d->a_row_xor < 0 || d->a_row_xor > 1) return R3D_EINVAL;
     if (d->mul && !d->aux) return R3D_EINVAL;
     if (d->splitk > 1) {

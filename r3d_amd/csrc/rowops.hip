@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs a) {
 }
 
 struct LnBwdArgs {
-    const float* dy; int lddy; int pair_in;
+    const float* dy; int lddy; int pair_in; const float* dy2; int lddy2;
     const float* x; int ldx; const float* mean; const float* rstd; const float* gamma; const float* beta; int relu;
     const float* add1; int ldadd1; const float* add2; int ldadd2;
     float* dx; int lddx;
@@ -109,6 +109,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
             if (c < a.H) {
                 xhat = (a.x[(size_t)row * a.ldx + c] - mean) * rstd;
                 float d = a.pair_in ? 0.5f * a.dy[(size_t)(row >> 1) * a.lddy + c] : a.dy[(size_t)row * a.lddy + c];
+                if (a.dy2) d += a.dy2[(size_t)row * a.lddy2 + c];
                 const float gam = a.gamma[c];
                 if (a.relu && !(xhat * gam + a.beta[c] > 0.f)) d = 0.f;
                 dg[e] += d * xhat;
@@ -207,6 +208,18 @@ __global__ __launch_bounds__(256) void rowmod_sum_kernel(const float* x, int ld,
     *o = s;
 }
 
+// out[r, :] = x[r, :] + add[r % mod, :]   (x may be NULL: pure broadcast)
+__global__ __launch_bounds__(256) void add_rowbcast_kernel(const float* x, int ldx, const float* add, int ldadd, int mod,
+                                                           float* out, int ldo, int rows, int cols) {
+    const size_t total = (size_t)rows * cols;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int r = (int)(e / cols), c = (int)(e % cols);
+        float v = add[(size_t)(r % mod) * ldadd + c];
+        if (x) v += x[(size_t)r * ldx + c];
+        out[(size_t)r * ldo + c] = v;
+    }
+}
+
 template <typename K, typename A>
 static int launch_epl(K k32, K k16, K k8, K k2, int H, dim3 grid, size_t shmem, hipStream_t s, const A& a) {
     if (H <= 128) hipLaunchKernelGGL(k2, grid, dim3(256), shmem, s, a);
@@ -240,7 +253,8 @@ R3D_EXPORT int64_t r3d_layernorm_bwd_ws_floats(int rows, int H) {
     return blocks > 1 ? (int64_t)blocks * 2 * H : 0;
 }
 
-R3D_EXPORT int r3d_layernorm_bwd(const float* dy, int lddy, int pair_in, const float* x, int ldx, const float* mean,
+R3D_EXPORT int r3d_layernorm_bwd(const float* dy, int lddy, int pair_in, const float* dy2, int lddy2, const float* x,
+                                 int ldx, const float* mean,
                                  const float* rstd, const float* gamma, const float* beta, int relu,
                                  const float* add1, int ldadd1, const float* add2, int ldadd2, float* dx, int lddx,
                                  float* dx2, int lddx2, const uint8_t* drop_mask, int lddrop, float drop_scale,
@@ -249,10 +263,11 @@ R3D_EXPORT int r3d_layernorm_bwd(const float* dy, int lddy, int pair_in, const f
     R3D_REQUIRE(rows > 0 && H > 0 && H <= 2048 && ldx >= H && lddx >= H && lddy >= H);
     R3D_REQUIRE((dgamma == nullptr) == (dbeta == nullptr));
     R3D_REQUIRE(!pair_in || (rows % 2) == 0);
+    R3D_REQUIRE(!dy2 || (lddy2 >= H && !pair_in));
     const int rpb = rows <= 64 ? rows : (r3d_cdiv(rows, 64) < 16 ? 16 : r3d_cdiv(rows, 64));
     const int blocks = r3d_cdiv(rows, rpb);
     R3D_REQUIRE(blocks == 1 || !dgamma || ws);
-    LnBwdArgs a{dy, lddy, pair_in, x, ldx, mean, rstd, gamma, beta, relu, add1, ldadd1, add2, ldadd2, dx, lddx,
+    LnBwdArgs a{dy, lddy, pair_in, dy2, lddy2, x, ldx, mean, rstd, gamma, beta, relu, add1, ldadd1, add2, ldadd2, dx, lddx,
                 dx2, lddx2, drop_mask, lddrop, drop_scale, dgamma, dbeta, ws, rows, H, rpb};
     hipStream_t s = (hipStream_t)stream;
     const size_t shmem = (size_t)8 * H * sizeof(float);
@@ -299,6 +314,19 @@ R3D_EXPORT int r3d_rowmod_sum(const float* x, int ld, int rows, int cols, int mo
     R3D_REQUIRE(x && out && rows > 0 && cols > 0 && mod > 0 && ld >= cols && ldo >= cols);
     hipLaunchKernelGGL(rowmod_sum_kernel, dim3(r3d_cdiv(cols, 256), mod), dim3(256), 0, (hipStream_t)stream, x, ld,
                        rows, cols, mod, out, ldo, accumulate);
+    R3D_LAUNCH_CHECK();
+    return R3D_OK;
+}
+
+/* out[r,:] = x[r,:] + add[r % mod,:] -- with_pos_embed of the decoder (model/extras/transformer.py:278-279,289,300-302):
+ * tgt + query_pos (mod = n_query) and memory + pos (mod = S).  x == NULL gives the pure broadcast (layer 0: tgt = 0). */
+R3D_EXPORT int r3d_add_rowbcast(const float* x, int ldx, const float* add, int ldadd, int mod, float* out, int ldo,
+                                int rows, int cols, void* stream) {
+    R3D_REQUIRE(add && out && rows > 0 && cols > 0 && mod > 0 && ldadd >= cols && ldo >= cols && (!x || ldx >= cols));
+    const size_t total = (size_t)rows * cols;
+    const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+    hipLaunchKernelGGL(add_rowbcast_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, add, ldadd, mod, out,
+                       ldo, rows, cols);
     R3D_LAUNCH_CHECK();
     return R3D_OK;
 }

@@ -1,0 +1,452 @@
+"""Host-side sequencing of the token-fusion training step on one MI355X.
+
+The engine owns (a) flat fp32 arenas [params | grads | exp_avg | exp_avg_sq] whose slices back the nn.Parameters of
+r3d_amd.model.futr_safuser_tokenfusion.FUTR, and (b) per-shape activation workspaces; it enqueues the HIP kernels of
+libr3d_hip.so (r3d_amd.ops) in forward / backward order on torch's current stream.  No ATen math runs in the step:
+torch only allocates buffers, provides the stream (and hipGraph capture) and the RCCL process group.
+
+Forward restates FUTR.forward (model/futr_safuser_tokenfusion.py:164-239) with
+  * rows ordered (clip, frame) b-major instead of the reference's seq-first [S,B,H];
+  * the fuser's masked 2-token attention in closed form: softmax([[-inf,s],[s,-inf]]) == [[0,1],[1,0]] exactly, so
+    attention == swap of V between the modality tokens and the Q/K projections receive exactly zero gradient
+    (checked against the full attention of the oracle);
+  * fc and fc_len evaluated as one [K+1, H] GEMM (their weights are adjacent in the arena).
+Backward is the hand-derived adjoint of the same sequence (the reference gets it from autograd,
+train/train_proposed_depth.py:214).
+"""
+import math
+
+import torch
+
+from . import ops
+from ._lib import GEMM_NT, GEMM_NN, GEMM_TN
+
+LIVE_PREFIXES = ("input_embed.", "depth_projection.", "depth_layernorm.", "pos_embedding", "query_embed.",
+                 "fuser.blocks.", "fuser.norm.", "transformer.decoder.", "fc_seg.", "fc.", "fc_len.")
+EXCLUDE_CLASS_IDX = 47          # hard-coded at train/train_proposed_depth.py:181,195
+DROP_P = 0.1                    # every nn.Dropout on the path (futr_safuser_tokenfusion.py:26; transformer.py:22)
+
+
+def is_live(name):
+    """Parameters that receive a gradient in the reference step; the rest keep grad=None."""
+    return name.startswith(LIVE_PREFIXES)
+
+
+class ParamArena:
+    """Flat arenas; live parameters first (AdamW touches only that prefix), depth_projection.weight last among them
+    so that everything else forms one contiguous all-reduce bucket that is ready before the big weight gradient."""
+
+    def __init__(self, named_params, device):
+        named = list(named_params)
+        live = [(n, p) for n, p in named if is_live(n)]
+        dead = [(n, p) for n, p in named if not is_live(n)]
+
+        def key(item):
+            n, p = item
+            if n == "depth_projection.weight":
+                return (3, 0)
+            if n in ("fc.weight", "fc_len.weight"):
+                return (0, 0 if n == "fc.weight" else 1)        # adjacent: [fc.weight ; fc_len.weight] = [K+1, H]
+            if n in ("fc.bias", "fc_len.bias"):
+                return (2, 0 if n == "fc.bias" else 1)          # adjacent: [fc.bias ; fc_len.bias] = [K+1]
+            return (1, 0) if p.numel() % 4 == 0 else (2, 2)
+        order = sorted(range(len(live)), key=lambda i: (key(live[i]), i))
+        live = [live[i] for i in order]
+        self.offsets, off = {}, 0
+        for n, p in live:
+            if n == "depth_projection.weight":
+                off = (off + 3) // 4 * 4
+            self.offsets[n] = (off, p.numel(), tuple(p.shape))
+            off += p.numel()
+        self.n_live = (off + 3) // 4 * 4
+        off = self.n_live
+        for n, p in dead:
+            off = (off + 3) // 4 * 4
+            self.offsets[n] = (off, p.numel(), tuple(p.shape))
+            off += p.numel()
+        self.n_total = (off + 3) // 4 * 4
+        self.bucket_small = (0, self.offsets["depth_projection.weight"][0])
+        self.bucket_big = (self.offsets["depth_projection.weight"][0], self.n_live)
+        self.params = torch.zeros(self.n_total, dtype=torch.float32, device=device)
+        self.grads = torch.zeros(self.n_live, dtype=torch.float32, device=device)
+        self.exp_avg = torch.zeros(self.n_live, dtype=torch.float32, device=device)
+        self.exp_avg_sq = torch.zeros(self.n_live, dtype=torch.float32, device=device)
+        self.live_names = [n for n, _ in live]
+        with torch.no_grad():
+            for n, p in named:
+                o, k, shp = self.offsets[n]
+                self.params[o:o + k].copy_(p.detach().reshape(-1).to(device=device, dtype=torch.float32))
+                p.data = self.params[o:o + k].view(shp)
+                p.grad = self.grads[o:o + k].view(shp) if is_live(n) else None
+
+    def p(self, name):
+        o, k, shp = self.offsets[name]
+        return self.params[o:o + k].view(shp)
+
+    def g(self, name):
+        o, k, shp = self.offsets[name]
+        return self.grads[o:o + k].view(shp)
+
+    def reattach_grads(self, named_params):
+        """optimizer.zero_grad(set_to_none=True) drops .grad; the step writes into the arena, so point them back."""
+        for n, p in named_params:
+            if is_live(n) and (p.grad is None or p.grad.data_ptr() != self.g(n).data_ptr()):
+                p.grad = self.g(n)
+
+
+class _Shape:
+    """Activation / gradient workspace for one (B, S, mode) shape."""
+
+    def __init__(self, eng, B, S, train):
+        dev, H, Q, K, L, heads = eng.device, eng.H, eng.Q, eng.K, eng.L, eng.heads
+        N, BQ = B * S, B * Q
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)     # noqa: E731
+        self.B, self.S, self.N, self.BQ = B, S, N, BQ
+        self.rgb, self.dep, self.dep_pre = f(N, H), f(N, H), f(N, H)
+        self.mean_d, self.rstd_d = f(N), f(N)
+        self.sums = torch.empty(2, H, dtype=torch.float64, device=dev)
+        self.idx = torch.empty(2, H // 4, dtype=torch.int64, device=dev)
+        self.mask = f(2, H)
+        self.x0, self.h1, self.vsw, self.x1, self.h2 = f(2 * N, H), f(2 * N, H), f(2 * N, H), f(2 * N, H), f(2 * N, H)
+        self.u, self.f1 = f(2 * N, 4 * H), f(2 * N, 4 * H)
+        self.x3, self.y = f(2 * N, H), f(2 * N, H)
+        self.m1, self.r1, self.m2, self.r2, self.mf, self.rf = f(2 * N), f(2 * N), f(2 * N), f(2 * N), f(2 * N), f(2 * N)
+        self.fused, self.kv_in = f(N, H), f(N, H)
+        self.tgt0 = torch.zeros(BQ, H, dtype=torch.float32, device=dev)
+        self.layers = []
+        for _ in range(L):
+            d = dict(sa_in=f(BQ, H), sa_qkv=f(BQ, 3 * H), sa_o=f(BQ, H), p_sa=f(B, heads, Q, Q), t1_pre=f(BQ, H),
+                     t1=f(BQ, H), m1=f(BQ), r1=f(BQ), caq_in=f(BQ, H), caq=f(BQ, H), cakv=f(N, 2 * H), ca_o=f(BQ, H),
+                     p_ca=f(B, heads, Q, S), t2_pre=f(BQ, H), t2=f(BQ, H), m2=f(BQ), r2=f(BQ), ff1=f(BQ, 4 * H),
+                     t3_pre=f(BQ, H), t3=f(BQ, H), m3=f(BQ), r3=f(BQ))
+            self.layers.append(d)
+        self.tgtF, self.mF, self.rF = f(BQ, H), f(BQ), f(BQ)
+        self.actdur = f(BQ, K + 1)
+        self.seg = f(N, K)
+        self.loss = f(4)
+        self.counts = torch.zeros(4, dtype=torch.int64, device=dev)
+        if train:
+            self.d_actdur, self.d_seg = torch.zeros(BQ, K + 1, dtype=torch.float32, device=dev), f(N, K)
+            self.d_tgtF, self.d_t = f(BQ, H), f(BQ, H)
+            self.g_a, self.g_b, self.g_c, self.g_d = f(BQ, H), f(BQ, H), f(BQ, H), f(BQ, H)
+            self.d_ff1, self.d_sa_qkv, self.d_cakv, self.g_kv = f(BQ, 4 * H), f(BQ, 3 * H), f(N, 2 * H), f(N, H)
+            self.d_fused = f(N, H)
+            self.d_x3, self.d_u, self.d_h, self.d_x1, self.d_v, self.d_x0 = (f(2 * N, H), f(2 * N, 4 * H), f(2 * N, H),
+                                                                              f(2 * N, H), f(2 * N, H), f(2 * N, H))
+            self.d_rgb_pre, self.d_dep, self.d_dep_pre = f(N, H), f(N, H), f(N, H)
+            # dropout keep-masks (one Philox launch fills the whole pool)
+            sizes = dict(x0=2 * N * H)
+            for l in range(L):
+                sizes.update({f"sa_p{l}": B * heads * Q * Q, f"ca_p{l}": B * heads * Q * S, f"d1_{l}": BQ * H,
+                              f"d2_{l}": BQ * H, f"d3_{l}": BQ * H, f"ff_{l}": BQ * 4 * H})
+            tot = sum((v + 15) // 16 * 16 for v in sizes.values())
+            self.drop_pool = torch.ones(tot, dtype=torch.uint8, device=dev)
+            self.drop, o = {}, 0
+            for k, v in sizes.items():
+                self.drop[k] = self.drop_pool[o:o + v]
+                o += (v + 15) // 16 * 16
+
+
+class FusionEngine:
+    def __init__(self, module, device):
+        self.module = module
+        self.device = torch.device(device)
+        assert self.device.type == "cuda", "the HIP engine needs an MI355X device (there is no CPU path)"
+        ops._lib.load()
+        self.H, self.Q, self.K = module.hidden_dim, module.n_query, module.n_class
+        self.heads, self.L = module.n_head, module.num_decoder_layers
+        self.dh = self.H // self.heads
+        self.pad_idx = module.src_pad_idx
+        self.P, self.D = module.depth_projection.in_features, module.input_embed.in_features
+        assert self.H % 8 == 0 and self.H % self.heads == 0
+        self.arena = ParamArena(list(module.named_parameters()), self.device)
+        self.ws = ops.GemmWorkspace(self.device)
+        self.shapes = {}
+        self.train_mask = None            # cached train-mode selection (data independent)
+        self.drop_seed = 0x5EED
+        self.drop_offset = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self.lr_t = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self.step_t = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self._lr_host = None
+        self.dur_den = None               # device scalar set by the data-parallel wrapper
+        self.score_allreduce = None       # callable(sums fp64 [2,H]) -> global row count, set by the DP wrapper
+        self.grad_hook = None             # callable(stage) set by the DP wrapper: "small_ready" / "big_ready"
+        self.last = None
+        a = self.arena
+        K, H = self.K, self.H
+        o_w = a.offsets["fc.weight"][0]
+        self.w_head = a.params[o_w:o_w + (K + 1) * H].view(K + 1, H)
+        self.gw_head = a.grads[o_w:o_w + (K + 1) * H].view(K + 1, H)
+        o_b = a.offsets["fc.bias"][0]
+        assert a.offsets["fc_len.weight"][0] == o_w + K * H and a.offsets["fc_len.bias"][0] == o_b + K
+        self.b_head = a.params[o_b:o_b + K + 1]
+        self.gb_head = a.grads[o_b:o_b + K + 1]
+
+    # ------------------------------------------------------------------------------------------------------
+    def _shape(self, B, S, train):
+        key = (B, S, bool(train))
+        if key not in self.shapes:
+            self.shapes[key] = _Shape(self, B, S, train)
+        return self.shapes[key]
+
+    def _train_masks(self, B, S):
+        """train mode: score = |d(mean)/dx| averaged over (B,T) = the constant 1/(B*T*C) for every channel
+        (futr_safuser_tokenfusion.py:40-45) -> selection is pure tie-breaking and depends on C only."""
+        if self.train_mask is None:
+            C = self.H
+            sc = torch.full((2, C), 1.0 / (B * S * C), dtype=torch.float32, device=self.device)
+            idx = torch.empty(2, C // 4, dtype=torch.int64, device=self.device)
+            mask = torch.empty(2, C, dtype=torch.float32, device=self.device)
+            ops.token_select(C // 4, idx, mask, score_f=sc)
+            self.train_mask = (idx, mask)
+        return self.train_mask
+
+    # ------------------------------------------------------------------------------------------------------
+    def forward(self, feats, depth, labels, mode="train", training=False, need_grad=True):
+        """feats [B,S,D] f32, depth [B,S,...] f32 (flattened to [N,P]), labels [B,S] int64 (train mode only).
+        Returns dict of views into the workspace: seg [B,S,K], action [B,Q,K], duration [B,Q] (strided views)."""
+        a, H, Q, K, heads, dh = self.arena, self.H, self.Q, self.K, self.heads, self.dh
+        B, S = feats.shape[0], feats.shape[1]
+        N, BQ = B * S, B * Q
+        assert feats.is_cuda and depth.is_cuda and feats.dtype == torch.float32 and depth.dtype == torch.float32
+        x_rgb = feats.reshape(N, -1)
+        x_dep = depth.reshape(N, -1)
+        assert x_rgb.shape[1] == self.D and x_dep.shape[1] == self.P, (x_rgb.shape, x_dep.shape, self.D, self.P)
+        assert x_rgb.is_contiguous() and x_dep.is_contiguous()
+        w = self._shape(B, S, need_grad)
+        drop = training and need_grad
+        dsc = 1.0 / (1.0 - DROP_P)
+        dm = (lambda k: w.drop[k]) if drop else (lambda k: None)
+        if drop:
+            ops.dropout_mask(w.drop_pool, DROP_P, self.drop_seed, self.drop_offset)
+        key_labels = None
+        if mode == "train":                     # get_pad_mask (:168,243-244) is evaluated inside the attention kernel
+            assert labels.dtype == torch.int64 and labels.is_cuda and labels.is_contiguous()
+            key_labels = labels
+        # ---- per-modality embeddings (:179-183, :194-197)
+        ops.gemm(GEMM_NT, x_rgb, a.p("input_embed.weight"), w.rgb, bias=a.p("input_embed.bias"), act=1, ws=self.ws)
+        d = ops.gemm(GEMM_NT, x_dep, a.p("depth_projection.weight"), w.dep_pre, bias=a.p("depth_projection.bias"),
+                     ws=self.ws, defer_reduce=True)
+        if d.splitk > 1:
+            ops.layernorm_fwd(self.ws.buf, a.p("depth_layernorm.weight"), a.p("depth_layernorm.bias"), w.dep, w.mean_d,
+                              w.rstd_d, relu=True, nsplit=d.splitk, bias=a.p("depth_projection.bias"),
+                              pre_out=w.dep_pre, rows=N, H=H)
+        else:
+            ops.layernorm_fwd(w.dep_pre, a.p("depth_layernorm.weight"), a.p("depth_layernorm.bias"), w.dep, w.mean_d,
+                              w.rstd_d, relu=True)
+        # ---- token selection + exchange (:33-66)
+        if mode == "train":
+            idx, mask = self._train_masks(B, S)
+        else:
+            ops.colabssum(w.rgb, w.sums[0])
+            ops.colabssum(w.dep, w.sums[1])
+            count = float(N)
+            if self.score_allreduce is not None:
+                count = self.score_allreduce(w.sums, N)
+            ops.token_select(H // 4, w.idx, w.mask, score_sum=w.sums, count=count)
+            idx, mask = w.idx, w.mask
+        ops.token_exchange_fwd(w.rgb, w.dep, mask[0], mask[1], w.x0, drop_mask=dm("x0"), drop_scale=dsc)
+        # ---- SA-Fuser block in closed form (transformerblock.py:118-135) + x_res + norm + mean (:86-94)
+        pre = "fuser.blocks.0."
+        ops.layernorm_fwd(w.x0, a.p(pre + "norm1.weight"), a.p(pre + "norm1.bias"), w.h1, w.m1, w.r1)
+        wv = a.p(pre + "attn.qkv.weight")[2 * H:]
+        ops.gemm(GEMM_NT, w.h1, wv, w.vsw, c_row_xor=1, ws=self.ws)            # V of the OTHER modality token
+        ops.gemm(GEMM_NT, w.vsw, a.p(pre + "attn.proj.weight"), w.x1, bias=a.p(pre + "attn.proj.bias"), res1=w.x0,
+                 ws=self.ws)
+        ops.layernorm_fwd(w.x1, a.p(pre + "norm2.weight"), a.p(pre + "norm2.bias"), w.h2, w.m2, w.r2)
+        ops.gemm(GEMM_NT, w.h2, a.p(pre + "mlp.mlp.0.weight"), w.f1, bias=a.p(pre + "mlp.mlp.0.bias"), act=2,
+                 pre_out=w.u, ws=self.ws)
+        ops.gemm(GEMM_NT, w.f1, a.p(pre + "mlp.mlp.2.weight"), w.x3, bias=a.p(pre + "mlp.mlp.2.bias"), res1=w.x1,
+                 res2=w.x0, ws=self.ws)
+        ops.layernorm_fwd(w.x3, a.p("fuser.norm.weight"), a.p("fuser.norm.bias"), w.y, w.mf, w.rf, pair_out=w.fused)
+        # ---- decoder (transformer.py:75-128,161-191,281-330); memory = fused, encoder bypassed (:77-78)
+        qpos = a.p("query_embed.weight")
+        pos = a.p("pos_embedding")[0, :S]
+        ops.add_rowbcast(w.fused, pos, S, w.kv_in)
+        tgt = None
+        for l in range(self.L):
+            c, pl = w.layers[l], f"transformer.decoder.layers.{l}."
+            ops.add_rowbcast(tgt, qpos, Q, c["sa_in"])
+            ops.gemm(GEMM_NT, c["sa_in"], a.p(pl + "self_attn.in_proj_weight"), c["sa_qkv"],
+                     bias=a.p(pl + "self_attn.in_proj_bias"), ws=self.ws)
+            ops.mha_core_fwd(c["sa_qkv"][:, :H], c["sa_qkv"][:, H:2 * H], c["sa_qkv"][:, 2 * H:], c["p_sa"], c["sa_o"], B,
+                             heads, Q, Q, dh, drop_mask=dm(f"sa_p{l}"), drop_scale=dsc)
+            ops.gemm(GEMM_NT, c["sa_o"], a.p(pl + "self_attn.out_proj.weight"), c["t1_pre"],
+                     bias=a.p(pl + "self_attn.out_proj.bias"), drop_mask=self._dm2(dm(f"d1_{l}"), BQ, H), drop_scale=dsc,
+                     res1=tgt, ws=self.ws)                                  # layer 0: tgt = 0 (:209)
+            ops.layernorm_fwd(c["t1_pre"], a.p(pl + "norm1.weight"), a.p(pl + "norm1.bias"), c["t1"], c["m1"], c["r1"])
+            ops.add_rowbcast(c["t1"], qpos, Q, c["caq_in"])
+            wi, bi = a.p(pl + "multihead_attn.in_proj_weight"), a.p(pl + "multihead_attn.in_proj_bias")
+            ops.gemm(GEMM_NT, c["caq_in"], wi[:H], c["caq"], bias=bi[:H], ws=self.ws)
+            ops.gemm(GEMM_NT, w.kv_in, wi[H:], c["cakv"], bias=bi[H:], ws=self.ws)
+            ops.mha_core_fwd(c["caq"], c["cakv"][:, :H], c["cakv"][:, H:], c["p_ca"], c["ca_o"], B, heads, Q, S, dh,
+                             key_labels=key_labels, pad_idx=self.pad_idx, drop_mask=dm(f"ca_p{l}"), drop_scale=dsc)
+            ops.gemm(GEMM_NT, c["ca_o"], a.p(pl + "multihead_attn.out_proj.weight"), c["t2_pre"],
+                     bias=a.p(pl + "multihead_attn.out_proj.bias"), drop_mask=self._dm2(dm(f"d2_{l}"), BQ, H),
+                     drop_scale=dsc, res1=c["t1"], ws=self.ws)
+            ops.layernorm_fwd(c["t2_pre"], a.p(pl + "norm2.weight"), a.p(pl + "norm2.bias"), c["t2"], c["m2"], c["r2"])
+            ops.gemm(GEMM_NT, c["t2"], a.p(pl + "linear1.weight"), c["ff1"], bias=a.p(pl + "linear1.bias"), act=1,
+                     drop_mask=self._dm2(dm(f"ff_{l}"), BQ, 4 * H), drop_scale=dsc, ws=self.ws)
+            ops.gemm(GEMM_NT, c["ff1"], a.p(pl + "linear2.weight"), c["t3_pre"], bias=a.p(pl + "linear2.bias"),
+                     drop_mask=self._dm2(dm(f"d3_{l}"), BQ, H), drop_scale=dsc, res1=c["t2"], ws=self.ws)
+            ops.layernorm_fwd(c["t3_pre"], a.p(pl + "norm3.weight"), a.p(pl + "norm3.bias"), c["t3"], c["m3"], c["r3"])
+            tgt = c["t3"]
+        ops.layernorm_fwd(tgt, a.p("transformer.decoder.norm.weight"), a.p("transformer.decoder.norm.bias"), w.tgtF,
+                          w.mF, w.rF)
+        # ---- heads (:219-232)
+        ops.gemm(GEMM_NT, w.tgtF, self.w_head, w.actdur, bias=self.b_head, ws=self.ws)
+        ops.gemm(GEMM_NT, w.fused, a.p("fc_seg.weight"), w.seg, bias=a.p("fc_seg.bias"), ws=self.ws)
+        self.last = dict(w=w, x_rgb=x_rgb, x_dep=x_dep, mask=mask, idx=idx, drop=drop, mode=mode)
+        return dict(seg=w.seg.view(B, S, K), action=w.actdur[:, :K].view(B, Q, K), duration=w.actdur[:, K].view(B, Q))
+
+    @staticmethod
+    def _dm2(m, rows, cols):
+        return None if m is None else m.view(rows, cols)
+
+    # ------------------------------------------------------------------------------------------------------
+    def losses(self, past_label, target, target_dur, with_grad=True, val_mode=False):
+        """The 3 losses + counters of train_proposed_depth.py:171-213 in one launch; fills d_seg / d_actdur."""
+        w = self.last["w"]
+        K = self.K
+        ops.losses_fwd_bwd(None if val_mode else w.seg, w.actdur[:, :K], w.actdur[:, K:], K + 1, past_label, target,
+                           target_dur, w.B, w.S, self.Q, K, self.pad_idx, EXCLUDE_CLASS_IDX, w.loss, w.counts,
+                           val_mode=val_mode, dur_den=self.dur_den,
+                           d_seg=w.d_seg if with_grad else None, d_act=w.d_actdur[:, :K] if with_grad else None,
+                           d_dur=w.d_actdur[:, K:] if with_grad else None, ld_ddur=K + 1)
+        return w.loss, w.counts
+
+    # ------------------------------------------------------------------------------------------------------
+    def backward(self, d_seg=None, d_actdur=None):
+        """Adjoint of forward(); gradients land in the grad arena (written, not accumulated)."""
+        st = self.last
+        w, a, H, Q, K, heads, dh, ws = st["w"], self.arena, self.H, self.Q, self.K, self.heads, self.dh, self.ws
+        B, S, N, BQ = w.B, w.S, w.N, w.BQ
+        d_seg = w.d_seg if d_seg is None else d_seg
+        d_actdur = w.d_actdur if d_actdur is None else d_actdur
+        drop = st["drop"]
+        dsc = 1.0 / (1.0 - DROP_P)
+        dm = (lambda k, r, c: w.drop[k].view(r, c)) if drop else (lambda k, r, c: None)
+        dmf = (lambda k: w.drop[k]) if drop else (lambda k: None)
+        # ---- heads
+        ops.gemm(GEMM_TN, d_actdur, w.tgtF, self.gw_head, ws=ws)
+        ops.colsum(d_actdur, self.gb_head, ws=ws)
+        ops.gemm(GEMM_NN, d_actdur, self.w_head, w.d_tgtF, ws=ws)
+        ops.gemm(GEMM_TN, d_seg, w.fused, a.g("fc_seg.weight"), ws=ws)
+        ops.colsum(d_seg, a.g("fc_seg.bias"), ws=ws)
+        # ---- decoder
+        last = w.layers[-1]
+        ops.layernorm_bwd(w.d_tgtF, last["t3"], w.mF, w.rF, a.p("transformer.decoder.norm.weight"),
+                          a.p("transformer.decoder.norm.bias"), w.d_t, a.g("transformer.decoder.norm.weight"),
+                          a.g("transformer.decoder.norm.bias"), ws=ws)
+        dy, dy2 = w.d_t, None                 # gradient w.r.t. t3 of the current layer (= dy + dy2)
+        qpos = a.p("query_embed.weight")
+        g_qe = a.g("query_embed.weight")
+        first_qe, first_fused = True, True
+        for l in reversed(range(self.L)):
+            c, pl = w.layers[l], f"transformer.decoder.layers.{l}."
+            g = lambda n: a.g(pl + n)         # noqa: E731
+            p = lambda n: a.p(pl + n)         # noqa: E731
+            # norm3 -> (t2 residual, FFN)
+            ops.layernorm_bwd(dy, c["t3_pre"], c["m3"], c["r3"], p("norm3.weight"), p("norm3.bias"), w.g_a,
+                              g("norm3.weight"), g("norm3.bias"), dy2=dy2, dx2=w.g_b, drop_mask=dm(f"d3_{l}", BQ, H),
+                              drop_scale=dsc, ws=ws)                           # g_a = d t3_pre ; g_b = d(linear2 out)
+            ops.gemm(GEMM_TN, w.g_b, c["ff1"], g("linear2.weight"), ws=ws)
+            ops.colsum(w.g_b, g("linear2.bias"), ws=ws)
+            ops.gemm(GEMM_NN, w.g_b, p("linear2.weight"), w.d_ff1, drop_mask=dm(f"ff_{l}", BQ, 4 * H), drop_scale=dsc,
+                     aux=c["ff1"], mul=1, ws=ws)
+            ops.gemm(GEMM_TN, w.d_ff1, c["t2"], g("linear1.weight"), ws=ws)
+            ops.colsum(w.d_ff1, g("linear1.bias"), ws=ws)
+            ops.gemm(GEMM_NN, w.d_ff1, p("linear1.weight"), w.g_c, res1=w.g_a, ws=ws)          # g_c = d t2
+            # norm2 -> (t1 residual, cross attention)
+            ops.layernorm_bwd(w.g_c, c["t2_pre"], c["m2"], c["r2"], p("norm2.weight"), p("norm2.bias"), w.g_a,
+                              g("norm2.weight"), g("norm2.bias"), dx2=w.g_b, drop_mask=dm(f"d2_{l}", BQ, H),
+                              drop_scale=dsc, ws=ws)                           # g_a = d t2_pre ; g_b = d(out_proj out)
+            ops.gemm(GEMM_TN, w.g_b, c["ca_o"], g("multihead_attn.out_proj.weight"), ws=ws)
+            ops.colsum(w.g_b, g("multihead_attn.out_proj.bias"), ws=ws)
+            ops.gemm(GEMM_NN, w.g_b, p("multihead_attn.out_proj.weight"), w.g_c, ws=ws)        # g_c = d ca_o
+            ops.mha_core_bwd(c["caq"], c["cakv"][:, :H], c["cakv"][:, H:], c["p_ca"], w.g_c, w.g_d, w.d_cakv[:, :H],
+                             w.d_cakv[:, H:], B, heads, Q, S, dh, drop_mask=dmf(f"ca_p{l}"), drop_scale=dsc)
+            wi = p("multihead_attn.in_proj_weight")
+            gwi, gbi = g("multihead_attn.in_proj_weight"), g("multihead_attn.in_proj_bias")
+            ops.gemm(GEMM_TN, w.g_d, c["caq_in"], gwi[:H], ws=ws)
+            ops.colsum(w.g_d, gbi[:H], ws=ws)
+            ops.gemm(GEMM_NN, w.g_d, wi[:H], w.g_c, ws=ws)                                    # g_c = d caq_in
+            ops.rowmod_sum(w.g_c, Q, g_qe, accumulate=not first_qe)
+            first_qe = False
+            ops.gemm(GEMM_TN, w.d_cakv, w.kv_in, gwi[H:], ws=ws)
+            ops.colsum(w.d_cakv, gbi[H:], ws=ws)
+            ops.gemm(GEMM_NN, w.d_cakv, wi[H:], w.d_fused, accumulate=not first_fused, ws=ws)   # d kv_in
+            first_fused = False
+            # norm1 -> (tgt residual, self attention);  d t1 = g_c (query path) + g_a (residual into t2_pre)
+            ops.layernorm_bwd(w.g_c, c["t1_pre"], c["m1"], c["r1"], p("norm1.weight"), p("norm1.bias"), w.g_d,
+                              g("norm1.weight"), g("norm1.bias"), dy2=w.g_a, dx2=w.g_b, drop_mask=dm(f"d1_{l}", BQ, H),
+                              drop_scale=dsc, ws=ws)                           # g_d = d t1_pre ; g_b = d(out_proj out)
+            ops.gemm(GEMM_TN, w.g_b, c["sa_o"], g("self_attn.out_proj.weight"), ws=ws)
+            ops.colsum(w.g_b, g("self_attn.out_proj.bias"), ws=ws)
+            ops.gemm(GEMM_NN, w.g_b, p("self_attn.out_proj.weight"), w.g_c, ws=ws)             # g_c = d sa_o
+            ops.mha_core_bwd(c["sa_qkv"][:, :H], c["sa_qkv"][:, H:2 * H], c["sa_qkv"][:, 2 * H:], c["p_sa"], w.g_c,
+                             w.d_sa_qkv[:, :H], w.d_sa_qkv[:, H:2 * H], w.d_sa_qkv[:, 2 * H:], B, heads, Q, Q, dh,
+                             drop_mask=dmf(f"sa_p{l}"), drop_scale=dsc)
+            ops.gemm(GEMM_TN, w.d_sa_qkv, c["sa_in"], g("self_attn.in_proj_weight"), ws=ws)
+            ops.colsum(w.d_sa_qkv, g("self_attn.in_proj_bias"), ws=ws)
+            ops.gemm(GEMM_NN, w.d_sa_qkv, p("self_attn.in_proj_weight"), w.g_c, ws=ws)         # g_c = d sa_in
+            ops.rowmod_sum(w.g_c, Q, g_qe, accumulate=True)
+            dy, dy2 = w.g_c, w.g_d             # d t3 of layer l-1 = g_c (through sa_in) + g_d (residual into t1_pre)
+        # ---- positional embedding gradient: sum over clips of d kv_in, before the seg head joins d_fused (:190)
+        ops.rowmod_sum(w.d_fused, S, a.g("pos_embedding")[0, :S])
+        ops.gemm(GEMM_NN, d_seg, a.p("fc_seg.weight"), w.d_fused, accumulate=True, ws=ws)
+        # ---- fuser
+        pre = "fuser.blocks.0."
+        ops.layernorm_bwd(w.d_fused, w.x3, w.mf, w.rf, a.p("fuser.norm.weight"), a.p("fuser.norm.bias"), w.d_x3,
+                          a.g("fuser.norm.weight"), a.g("fuser.norm.bias"), pair_in=True, ws=ws)
+        ops.gemm(GEMM_TN, w.d_x3, w.f1, a.g(pre + "mlp.mlp.2.weight"), ws=ws)
+        ops.colsum(w.d_x3, a.g(pre + "mlp.mlp.2.bias"), ws=ws)
+        ops.gemm(GEMM_NN, w.d_x3, a.p(pre + "mlp.mlp.2.weight"), w.d_u, aux=w.u, mul=2, ws=ws)
+        ops.gemm(GEMM_TN, w.d_u, w.h2, a.g(pre + "mlp.mlp.0.weight"), ws=ws)
+        ops.colsum(w.d_u, a.g(pre + "mlp.mlp.0.bias"), ws=ws)
+        ops.gemm(GEMM_NN, w.d_u, a.p(pre + "mlp.mlp.0.weight"), w.d_h, ws=ws)
+        ops.layernorm_bwd(w.d_h, w.x1, w.m2, w.r2, a.p(pre + "norm2.weight"), a.p(pre + "norm2.bias"), w.d_x1,
+                          a.g(pre + "norm2.weight"), a.g(pre + "norm2.bias"), add1=w.d_x3, ws=ws)
+        ops.gemm(GEMM_TN, w.d_x1, w.vsw, a.g(pre + "attn.proj.weight"), ws=ws)
+        ops.colsum(w.d_x1, a.g(pre + "attn.proj.bias"), ws=ws)
+        ops.gemm(GEMM_NN, w.d_x1, a.p(pre + "attn.proj.weight"), w.d_v, c_row_xor=1, ws=ws)     # un-swap
+        gqkv = a.g(pre + "attn.qkv.weight")                                   # rows [0,2H) (Q,K) stay exactly zero
+        ops.gemm(GEMM_TN, w.d_v, w.h1, gqkv[2 * H:], ws=ws)
+        ops.gemm(GEMM_NN, w.d_v, a.p(pre + "attn.qkv.weight")[2 * H:], w.d_h, ws=ws)
+        ops.layernorm_bwd(w.d_h, w.x0, w.m1, w.r1, a.p(pre + "norm1.weight"), a.p(pre + "norm1.bias"), w.d_x0,
+                          a.g(pre + "norm1.weight"), a.g(pre + "norm1.bias"), add1=w.d_x1, add2=w.d_x3, ws=ws)
+        mask = st["mask"]
+        ops.token_exchange_bwd(w.d_x0, w.rgb, mask[0], mask[1], w.d_rgb_pre, w.d_dep, drop_mask=dmf("x0"), drop_scale=dsc)
+        # ---- embeddings
+        ops.gemm(GEMM_TN, w.d_rgb_pre, st["x_rgb"], a.g("input_embed.weight"), ws=ws)
+        ops.colsum(w.d_rgb_pre, a.g("input_embed.bias"), ws=ws)
+        ops.layernorm_bwd(w.d_dep, w.dep_pre, w.mean_d, w.rstd_d, a.p("depth_layernorm.weight"),
+                          a.p("depth_layernorm.bias"), w.d_dep_pre, a.g("depth_layernorm.weight"),
+                          a.g("depth_layernorm.bias"), relu=True, ws=ws)
+        ops.colsum(w.d_dep_pre, a.g("depth_projection.bias"), ws=ws)
+        if self.grad_hook is not None:
+            self.grad_hook("small_ready")
+        ops.gemm(GEMM_TN, w.d_dep_pre, st["x_dep"], a.g("depth_projection.weight"), ws=ws)
+        if self.grad_hook is not None:
+            self.grad_hook("big_ready")
+
+    # ------------------------------------------------------------------------------------------------------
+    def adamw(self, lr, weight_decay, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
+        """One fused launch over the live prefix of the arena (main_darai.py:135; train_proposed_depth.py:215)."""
+        a = self.arena
+        if self._lr_host != float(lr):          # lr lives in device memory so a captured graph sees scheduler updates
+            self.lr_t.fill_(float(lr))
+            self._lr_host = float(lr)
+        self.step_t.add_(1)
+        ops.adamw_flat(a.params[:a.n_live], a.grads, a.exp_avg, a.exp_avg_sq, self.lr_t, self.step_t, beta1=betas[0],
+                       beta2=betas[1], eps=eps, weight_decay=weight_decay, grad_scale=grad_scale)
+
+    def train_step(self, feats, depth, past_label, target_dur, target, lr, weight_decay, training=True):
+        """forward + losses + backward + AdamW, all enqueued, no host sync.  Returns (loss[4], counts[4]) on device."""
+        self.forward(feats, depth, past_label, "train", training)
+        if self.last["drop"]:
+            self.drop_offset.add_(1)
+        loss, counts = self.losses(past_label, target, target_dur)
+        self.backward()
+        self.adamw(lr, weight_decay)
+        return loss, counts

@@ -50,7 +50,7 @@ class GemmWorkspace:
 
 def gemm(layout, a, b, c, *, bias=None, act=0, pre_out=None, a_add=None, a_add_mod=0, a_row_xor=0,
          drop_mask=None, drop_scale=1.0, aux=None, mul=0, res1=None, res2=None, alpha=1.0, accumulate=False,
-         ws=None, tile=0, splitk=0, defer_reduce=False):
+         c_row_xor=0, ws=None, tile=0, splitk=0, defer_reduce=False):
     """C = epilogue(A op B), see r3d_gemm_desc.  Shapes: NT a[M,K] b[N,K]; NN a[M,K] b[K,N]; TN a[K,M] b[K,N].
     Returns the (filled) descriptor; with defer_reduce=True and split-K the caller reduces the slabs itself
     (e.g. through layernorm_fwd(nsplit=...))."""
@@ -93,6 +93,7 @@ def gemm(layout, a, b, c, *, bias=None, act=0, pre_out=None, a_add=None, a_add_m
     if res2 is not None:
         d.res2, d.ldr2 = res2.data_ptr(), _ld(res2)
     d.alpha, d.accumulate = alpha, 1 if accumulate else 0
+    d.c_row_xor = c_row_xor
     check(lib.r3d_gemm_plan(C.byref(d)), "r3d_gemm_plan")
     if tile:
         d.tile = tile
@@ -130,18 +131,25 @@ def layernorm_fwd(x, gamma, beta, y, mean, rstd, *, relu=False, pair_out=None, n
                                 _p(rstd), _p(pair_out), rows, H, 1 if relu else 0, _stream()), "r3d_layernorm_fwd")
 
 
-def layernorm_bwd(dy, x, mean, rstd, gamma, beta, dx, dgamma, dbeta, *, pair_in=False, relu=False, add1=None, add2=None,
+def layernorm_bwd(dy, x, mean, rstd, gamma, beta, dx, dgamma, dbeta, *, pair_in=False, relu=False, dy2=None, add1=None, add2=None,
                   dx2=None, drop_mask=None, drop_scale=1.0, ws=None):
     lib = _lib.load()
     rows, H = x.shape
     need = lib.r3d_layernorm_bwd_ws_floats(rows, H)
     wsb = ws.get(need) if (need > 0 and dgamma is not None) else None
-    check(lib.r3d_layernorm_bwd(_p(dy), _ld(dy), 1 if pair_in else 0, _p(x), _ld(x), _p(mean), _p(rstd), _p(gamma), _p(beta),
+    check(lib.r3d_layernorm_bwd(_p(dy), _ld(dy), 1 if pair_in else 0, _p(dy2), _ld(dy2) if dy2 is not None else 0, _p(x), _ld(x), _p(mean), _p(rstd), _p(gamma), _p(beta),
                                 1 if relu else 0, _p(add1), _ld(add1) if add1 is not None else 0, _p(add2),
                                 _ld(add2) if add2 is not None else 0, _p(dx), _ld(dx), _p(dx2),
                                 _ld(dx2) if dx2 is not None else 0, _p(drop_mask),
                                 _ld(drop_mask) if drop_mask is not None else 0, drop_scale, _p(dgamma), _p(dbeta),
                                 _p(wsb), rows, H, _stream()), "r3d_layernorm_bwd")
+
+
+def add_rowbcast(x, add, mod, out):
+    lib = _lib.load()
+    rows, cols = out.shape
+    check(lib.r3d_add_rowbcast(_p(x), _ld(x) if x is not None else 0, _p(add), _ld(add), mod, _p(out), _ld(out), rows, cols,
+                               _stream()), "r3d_add_rowbcast")
 
 
 def colsum(x, out, *, accumulate=False, ws=None):
@@ -196,10 +204,11 @@ def token_exchange_bwd(dx0, rgb, mask_rgb, mask_dep, d_rgb_pre, d_dep, *, drop_m
 # ----------------------------------------------------------------------------------------------------------
 # attention core
 # ----------------------------------------------------------------------------------------------------------
-def mha_core_fwd(q, k, v, probs, o, B, heads, Lq, Lk, dh, *, kpm=None, drop_mask=None, drop_scale=1.0):
+def mha_core_fwd(q, k, v, probs, o, B, heads, Lq, Lk, dh, *, kpm=None, key_labels=None, pad_idx=0, drop_mask=None,
+                 drop_scale=1.0):
     lib = _lib.load()
-    check(lib.r3d_mha_core_fwd(_p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), _p(kpm), _p(probs), _p(drop_mask), drop_scale,
-                               _p(o), _ld(o), B, heads, Lq, Lk, dh, _stream()), "r3d_mha_core_fwd")
+    check(lib.r3d_mha_core_fwd(_p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), _p(kpm), _p(key_labels), pad_idx, _p(probs), _p(drop_mask),
+                               drop_scale, _p(o), _ld(o), B, heads, Lq, Lk, dh, _stream()), "r3d_mha_core_fwd")
 
 
 def mha_core_bwd(q, k, v, probs, d_o, dq, dk, dv, B, heads, Lq, Lk, dh, *, drop_mask=None, drop_scale=1.0):

@@ -116,6 +116,28 @@ def test_gemm_epilogue_and_prologue(ops):
                 assert_close(Cd.cpu(), v, 1e-4, 1e-4, f"epilogue sk{splitk} act{act} mul{mul}")
 
 
+def test_gemm_c_row_xor_is_pair_swap(ops):
+    M, N, K = 64, 48, 32
+    A, B, res = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(M, N, seed=3)
+    Cd = torch.empty(M, N, device="cuda")
+    ops.gemm(0, dev(A), dev(B), Cd, res1=dev(res), c_row_xor=1, tile=1, splitk=1)
+    torch.cuda.synchronize()
+    rows = torch.arange(M) ^ 1
+    ref = (A.double() @ B.double().t())[rows] + res.double()       # row m of the product lands in row m^1
+    assert_close(Cd.cpu(), ref, 1e-4, 1e-4, "c_row_xor")
+
+
+def test_add_rowbcast(ops):
+    x, add = rnd(24, 40, seed=1), rnd(8, 40, seed=2)
+    out = torch.empty(24, 40, device="cuda")
+    ops.add_rowbcast(dev(x), dev(add), 8, out)
+    out2 = torch.empty(24, 40, device="cuda")
+    ops.add_rowbcast(None, dev(add), 8, out2)
+    torch.cuda.synchronize()
+    assert_close(out.cpu(), x + add.repeat(3, 1), 1e-7, 1e-7, "add_rowbcast")
+    assert_close(out2.cpu(), add.repeat(3, 1), 0, 0, "bcast")
+
+
 def test_gemm_rejects_bad_arguments(ops):
     from r3d_amd._lib import R3DHipError
     a, b, c = torch.zeros(4, 8, device="cuda"), torch.zeros(4, 8, device="cuda"), torch.zeros(4, 4, device="cuda")
@@ -143,7 +165,8 @@ def test_layernorm_fwd_bwd(ops, rows, H, relu):
     yd, mean, rstd = torch.empty(rows, H, device="cuda"), torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
     ops.layernorm_fwd(dev(x), dev(g), dev(b), yd, mean, rstd, relu=relu)
     dx, dg, db = torch.empty(rows, H, device="cuda"), torch.empty(H, device="cuda"), torch.empty(H, device="cuda")
-    ops.layernorm_bwd(dev(dy), dev(x), mean, rstd, dev(g), dev(b), dx, dg, db, relu=relu, add1=dev(add1), ws=ws)
+    ops.layernorm_bwd(dev(0.25 * dy), dev(x), mean, rstd, dev(g), dev(b), dx, dg, db, relu=relu, dy2=dev(0.75 * dy),
+                      add1=dev(add1), ws=ws)
     torch.cuda.synchronize()
     assert_close(yd.cpu(), y.detach(), 1e-4, 1e-5, "ln y")
     assert_close(dx.cpu(), xr.grad + add1.double(), 1e-3, 1e-4, "ln dx")
