@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training clips/sec of the RGB+Depth token-fusion step (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A step = one full training step of r3d_amd's FUTR on one batch of synthetic clips: forward + 3 losses + backward +
+AdamW (+ gradient all-reduce over RCCL when N>1), dropout active (the reference's first-epoch state), inputs already
+resident in HBM, fp32 end to end.  Workload at every N: BASELINE.json configs[1] (DARai RGB+Depth
+futr_safuser_tokenfusion, batch 8 PER GPU, 16-frame clips, hidden 128) -> weak scaling.  One JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CFG = dict(B=8, S=16, H=128, K=17, D=2048, P=224 * 224, Q=8, heads=8, n_dec=1, n_enc=2, lr=1e-3, wd=5e-3)
+
+
+def make_inputs(c, device, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    pad = c["K"] + 1
+    feats = torch.randn(c["B"], c["S"], c["D"], generator=g)
+    depth = torch.rand(c["B"], c["S"], 1, 224, 224, generator=g)
+    lab = torch.randint(0, c["K"] - 1, (c["B"], c["S"]), generator=g)
+    lab[1::2, c["S"] - max(c["S"] // 8, 1):] = pad
+    tgt = torch.randint(0, c["K"] - 1, (c["B"], c["Q"]), generator=g)
+    dur = torch.rand(c["B"], c["Q"], generator=g) + 0.05
+    dur = dur / dur.sum(1, keepdim=True)
+    return [t.to(device) for t in (feats, depth, lab, dur, tgt)]
+
+
+def build_model(c, device):
+    from r3d_amd.model.futr_safuser_tokenfusion import FUTR
+    args = argparse.Namespace(input_dim=c["D"], seg=True, anticipate=True, max_pos_len=2000, input_type="i3d_transcript")
+    torch.manual_seed(1)
+    m = FUTR(c["K"], c["H"], c["K"] + 1, device, args, n_query=c["Q"], n_head=c["heads"], num_encoder_layers=c["n_enc"],
+             num_decoder_layers=c["n_dec"]).to(device)
+    return m.train()
+
+
+def time_kernel(fn, iters=30, warm=5):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # on torch's current stream,
+    e0.record()                                                                           # where ops.* launch
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3          # seconds per launch
+
+
+def kernel_rooflines(eng, c):
+    """Live HIP-event timing of the three heavy kernels with the step's real operands (after the timed region)."""
+    from r3d_amd import ops
+    from r3d_amd._lib import GEMM_NT, GEMM_TN
+    st, a, w = eng.last, eng.arena, eng.last["w"]
+    N, H, P = c["B"] * c["S"], c["H"], c["P"]
+    out = {}
+    t = time_kernel(lambda: ops.gemm(GEMM_TN, w.d_dep_pre, st["x_dep"], a.g("depth_projection.weight"), ws=eng.ws))
+    out["depth_projection_wgrad (gemm_f32 TN)"] = dict(seconds=t, flops=2.0 * N * P * H, bytes=4.0 * (N * P + N * H + H * P))
+
+    def fwd():
+        d = ops.gemm(GEMM_NT, st["x_dep"], a.p("depth_projection.weight"), w.dep_pre, ws=eng.ws, defer_reduce=True)
+        return d
+    t = time_kernel(fwd)
+    out["depth_projection_fwd (gemm_f32 NT split-K)"] = dict(seconds=t, flops=2.0 * N * P * H, bytes=4.0 * (N * P + H * P + N * H))
+    lr_t, step_t = eng.lr_t, eng.step_t
+    scratch = [a.params[:a.n_live].clone(), a.exp_avg.clone(), a.exp_avg_sq.clone()]
+    t = time_kernel(lambda: ops.adamw_flat(scratch[0], a.grads, scratch[1], scratch[2], lr_t, step_t, weight_decay=c["wd"]))
+    out["adamw_flat"] = dict(seconds=t, flops=0.0, bytes=28.0 * a.n_live)
+    return out
+
+
+def cpu_baseline(c, budget_s=15.0):
+    """The oracle (CPU restatement, 'port') timed on this box's host cores on a bounded sample of the same workload."""
+    from oracle import futr_oracle as O, synth
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    names = None
+    model = build_model(c, torch.device("cpu")) if False else None
+    # parameters: same architecture, random init (values do not matter for timing)
+    import argparse as ap
+    from r3d_amd.model.futr_safuser_tokenfusion import FUTR
+    args = ap.Namespace(input_dim=c["D"], seg=True, anticipate=True, max_pos_len=2000, input_type="i3d_transcript")
+    m = FUTR(c["K"], c["H"], c["K"] + 1, torch.device("cpu"), args, n_query=c["Q"], n_head=c["heads"],
+             num_encoder_layers=c["n_enc"], num_decoder_layers=c["n_dec"])
+    params = {n: p.detach().clone() for n, p in m.named_parameters()}
+    tr = O.CpuTrainer(params, c["K"] + 1, c["heads"], c["n_dec"], c["lr"], c["wd"])
+    batch = [torch.from_numpy(x) for x in synth.make_batch(c["B"], c["S"], c["K"], c["K"] + 1, 1)]
+    tr.step(batch)                                                    # warm-up
+    t0, n = time.perf_counter(), 0
+    while True:
+        tr.step(batch)
+        n += 1
+        if time.perf_counter() - t0 > budget_s or n >= 400:
+            break
+    dt = time.perf_counter() - t0
+    return dict(value=c["B"] * n / dt, unit="clips/s", cores=cores, kind="port",
+                sample=f"{n} full CPU training steps (fwd+3 losses+autograd bwd+AdamW) of the same B={c['B']},S={c['S']},"
+                       f"H={c['H']} workload in {dt:.1f}s, torch {torch.__version__} CPU, {cores} threads")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-graph", action="store_true", help="enqueue every step from Python instead of replaying hipGraphs")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eval-dropout-off", action="store_true", help="bench the eval()-state step (dropout off)")
+    a = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+    c = CFG
+    model = build_model(c, device)
+    if a.eval_dropout_off:
+        model.eval()
+    eng = model.engine()
+    from r3d_amd.parallel import DataParallelStep
+    dp = DataParallelStep(eng) if world > 1 else None
+    if dp is not None:
+        dp.broadcast_parameters()
+    feats, depth, lab, dur, tgt = make_inputs(c, device, seed=1 + rank)
+    training = model.training
+    gscale = dp.grad_scale if dp is not None else 1.0
+
+    def step_eager():
+        if dp is not None:
+            dp.prepare_duration_denominator(dur, c["K"] + 1)
+        eng.forward(feats, depth, lab, "train", training)
+        if eng.last["drop"]:
+            eng.drop_offset.add_(1)
+        eng.losses(lab, tgt, dur)
+        eng.backward()
+        if dp is not None:
+            dp.wait_grads()
+        eng.adamw(c["lr"], c["wd"], grad_scale=gscale)
+
+    for _ in range(3):
+        step_eager()
+    torch.cuda.synchronize()
+    launch = "eager"
+    run_step = step_eager
+    if not a.no_graph:
+        try:
+            if dp is None:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    step_eager()
+                run_step, launch = g.replay, "hipGraph (1 graph/step)"
+            else:
+                hook = eng.grad_hook
+                eng.grad_hook = None
+                g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g1):
+                    eng.forward(feats, depth, lab, "train", training)
+                    if eng.last["drop"]:
+                        eng.drop_offset.add_(1)
+                    eng.losses(lab, tgt, dur)
+                    eng.backward_main()
+                with torch.cuda.graph(g2):
+                    eng.backward_depth_wgrad()
+                with torch.cuda.graph(g3):
+                    eng.adamw(c["lr"], c["wd"], grad_scale=gscale)
+                eng.grad_hook = hook
+
+                def run_step():
+                    dp.prepare_duration_denominator(dur, c["K"] + 1)
+                    g1.replay()
+                    dp._on_stage("small_ready")          # RCCL all-reduce of the small bucket overlaps g2
+                    g2.replay()
+                    dp._on_stage("big_ready")
+                    dp.wait_grads()
+                    g3.replay()
+                launch = "hipGraph (3 graphs/step around 2 RCCL all-reduces)"
+        except Exception as e:                            # capture unsupported -> keep the eager path, say so
+            launch = f"eager (graph capture failed: {type(e).__name__})"
+            run_step = step_eager
+            torch.cuda.synchronize()
+    for _ in range(a.warmup):
+        run_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        run_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    w = eng.last["w"]
+    loss_now = [float(x) for x in w.loss.cpu()]
+    if rank == 0:
+        kr = kernel_rooflines(eng, c)
+        name, dom = max(kr.items(), key=lambda kv: kv[1]["seconds"])
+        ai = dom["flops"] / dom["bytes"] if dom["bytes"] else 0.0
+        if ai > 157.3e12 / 8.0e12:
+            roof = dict(bound="mfma", achieved=dom["flops"] / dom["seconds"] / 1e12, peak=157.3, unit="TFLOP/s")
+        else:
+            roof = dict(bound="hbm", achieved=dom["bytes"] / dom["seconds"] / 1e9, peak=8000.0, unit="GB/s")
+        roof["frac"] = roof["achieved"] / roof["peak"]
+        roof["traffic"] = None
+        roof["kernel"] = name
+        roof["us_per_launch"] = dom["seconds"] * 1e6
+        out = dict(metric="training clips/sec (RGB+Depth fusion, DARai) at 1/2/4/8 GPUs; effective-rank match",
+                   value=world * c["B"] * a.steps / dt, unit="clips/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
+                   ms_per_step=dt / a.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32",
+                   data="synthetic",
+                   config=dict(workload="DARai RGB+Depth futr_safuser_tokenfusion, batch=8 per GPU, 16-frame clips, "
+                                        "hidden=128, n_class=17, depth 224x224 (BASELINE.json configs[1])",
+                               global_batch=world * c["B"], clip_frames=c["S"], hidden=c["H"], parallelism=f"dp{world}",
+                               launch=launch, dropout="on" if training else "off"),
+                   roofline=roof,
+                   kernels={k: dict(us=v["seconds"] * 1e6, GBps=v["bytes"] / v["seconds"] / 1e9,
+                                    TFLOPs=v["flops"] / v["seconds"] / 1e12) for k, v in kr.items()},
+                   final_losses=loss_now)
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(c)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -9,6 +9,7 @@ on a non-HIP device forward() raises (there is no CPU path).
 """
 import copy
 import math
+import weakref
 
 import torch
 from torch import nn
@@ -163,6 +164,9 @@ class FUTR(nn.Module):
                                "GPU with .to('cuda') (there is deliberately no CPU path).")
         if self._engine is None or self._engine.device != dev:
             self._engine = FusionEngine(self, dev)
+            ref = weakref.ref(self._engine)
+            for p in self.parameters():
+                p._r3d_engine = ref              # lets r3d_amd.optim.FlatAdamW find the arena behind its parameters
         return self._engine
 
     # ---- forward ------------------------------------------------------------------------------------------------
