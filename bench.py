@@ -82,10 +82,13 @@ def kernel_rooflines(eng, c):
 def cpu_baseline(c, budget_s=15.0):
     """The oracle (CPU restatement, 'port') timed on this box's host cores on a bounded sample of the same workload."""
     from oracle import futr_oracle as O, synth
-    cores = os.cpu_count() or 1
+    # a 1-GPU box shares its host: 16 cores is this rank's CPU share (more threads only add contention)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(16, avail))
     torch.set_num_threads(cores)
-    names = None
-    model = build_model(c, torch.device("cpu")) if False else None
     # parameters: same architecture, random init (values do not matter for timing)
     import argparse as ap
     from r3d_amd.model.futr_safuser_tokenfusion import FUTR

@@ -77,6 +77,8 @@ typedef struct r3d_gemm_desc {
     const float* res1; int32_t ldr1;
     const float* res2; int32_t ldr2;
     float alpha; int32_t accumulate;
+    float* bias_grad;        /* TN only, splitk == 1: bias_grad[m] = sum_k A[k,m] (the nn.Linear bias gradient, free
+                                 with the weight-gradient GEMM that already streams dY through LDS) */
     int32_t c_row_xor;       /* output (and pre_out/aux/res/drop operand) row index = m ^ c_row_xor: pair swap at store */
     int32_t splitk, k_per_split; float* partial;
     int32_t tile;            /* 0 = auto; 1 = 32x32, 2 = 64x64, 3 = 128x128 workgroup tile (testing / tuning) */
@@ -163,7 +165,8 @@ int r3d_losses_fwd_bwd(const float* seg_logits, int ld_seg, const float* act_log
                        int ld_dur, const int64_t* past_label, const int64_t* target, const float* target_dur, int B, int S,
                        int Q, int K, int pad_idx, int exclude_idx, int val_mode, const float* dur_den, float grad_scale,
                        float* d_seg, int ld_dseg, float* d_act, int ld_dact, float* d_dur, int ld_ddur, float* loss_out,
-                       int64_t* counts, void* stream);
+                       int64_t* counts, float* ws, void* stream);
+int64_t r3d_losses_ws_floats(int B, int S, int Q);     /* scratch for r3d_losses_fwd_bwd (16-byte aligned) */
 
 /* ---- optimiser / dropout masks: main_darai.py:135, train/train_proposed_depth.py:215 -------------------------- */
 /* torch.optim.AdamW semantics over flat arenas of n floats (n % 4 == 0, 16-byte aligned); g is multiplied by

@@ -25,6 +25,7 @@ class GemmDesc(C.Structure):
         ("res1", C.c_void_p), ("ldr1", C.c_int32),
         ("res2", C.c_void_p), ("ldr2", C.c_int32),
         ("alpha", C.c_float), ("accumulate", C.c_int32),
+        ("bias_grad", C.c_void_p),
         ("c_row_xor", C.c_int32),
         ("splitk", C.c_int32), ("k_per_split", C.c_int32), ("partial", C.c_void_p),
         ("tile", C.c_int32),
@@ -58,7 +59,8 @@ _SIGNATURES = {
     "r3d_mha_core_bwd": ([_P, _I, _P, _I, _P, _I, _P, _P, _F, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
                          C.c_int),
     "r3d_losses_fwd_bwd": ([_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _F, _P, _I, _P, _I,
-                            _P, _I, _P, _P, _P], C.c_int),
+                            _P, _I, _P, _P, _P, _P], C.c_int),
+    "r3d_losses_ws_floats": ([_I, _I, _I], C.c_int64),
     "r3d_adamw_flat": ([_P, _P, _P, _P, _L, _P, _P, _F, _F, _F, _F, _F, _P], C.c_int),
     "r3d_dropout_mask": ([_P, _L, _F, C.c_uint64, _P, _P], C.c_int),
     "r3d_erank_lds_bytes": ([_I, _I], C.c_int64),

@@ -21,14 +21,18 @@ struct MhaArgs {
     int B, heads, Lq, Lk, dh; float scale;
 };
 
-__device__ __forceinline__ void load_chunk(float* kc, const float* base, int ld, int row0, int nrows, int rows_total,
-                                           int dh, int lane) {
-    for (int r = 0; r < nrows; ++r) {
-        const bool ok = (row0 + r) < rows_total;
-        for (int d = lane; d < dh; d += 64) kc[r * (dh + 1) + d] = ok ? base[(size_t)(row0 + r) * ld + d] : 0.f;
+// Coalesced copy of rows [row0, row0+nrows) x dh of a strided matrix into the padded LDS chunk [64][dh+1].
+// All loads of the flat loop are independent, so the wave keeps many in flight (the tensors are tiny and the kernel
+// is pure latency: nothing in the inner loops below touches global memory).
+__device__ __forceinline__ void load_chunk(float* kc, const float* base, int ld, int row0, int nrows, int dh, int lane) {
+    const int total = nrows * dh;
+    for (int e = lane; e < total; e += 64) {
+        const int r = e / dh, d = e - r * dh;
+        kc[r * (dh + 1) + d] = base[(size_t)(row0 + r) * ld + d];
     }
 }
 
+template <int MAXE>
 __global__ __launch_bounds__(64) void mha_fwd_kernel(const MhaArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
@@ -40,11 +44,14 @@ __global__ __launch_bounds__(64) void mha_fwd_kernel(const MhaArgs a) {
     const float* qb = a.q + (size_t)b * Lq * a.ldq + h * dh;
     const float* kb = a.k + (size_t)b * Lk * a.ldk + h * dh;
     const float* vb = a.v + (size_t)b * Lk * a.ldv + h * dh;
-    for (int i = 0; i < Lq; ++i)
-        for (int d = lane; d < dh; d += 64) qs[i * dh + d] = qb[(size_t)i * a.ldq + d];
+    for (int e = lane; e < Lq * dh; e += 64) {
+        const int i = e / dh, d = e - i * dh;
+        qs[e] = qb[(size_t)i * a.ldq + d];
+    }
     for (int c0 = 0; c0 < Lk; c0 += 64) {
+        const int nrows = min(64, Lk - c0);
         __syncthreads();
-        load_chunk(kc, kb, a.ldk, c0, 64, Lk, dh, lane);
+        load_chunk(kc, kb, a.ldk, c0, nrows, dh, lane);
         __syncthreads();
         const int j = c0 + lane;
         if (j < Lk) {
@@ -76,15 +83,37 @@ __global__ __launch_bounds__(64) void mha_fwd_kernel(const MhaArgs a) {
             sc[i * Lk + j] = a.drop ? p * a.drop_scale * (float)a.drop[pbase + (size_t)i * Lk + j] : p;
         }
     }
-    __syncthreads();
-    for (int i = 0; i < Lq; ++i)
-        for (int d = lane; d < dh; d += 64) {
-            float acc = 0.f;
-            for (int j = 0; j < Lk; ++j) acc += sc[i * Lk + j] * vb[(size_t)j * a.ldv + d];
-            a.o[((size_t)b * Lq + i) * a.ldo + h * dh + d] = acc;
+    // O = P_dropped . V : output element e = i*dh + d lives in lane e % 64, slot e / 64
+    float acc[MAXE];
+#pragma unroll
+    for (int t = 0; t < MAXE; ++t) acc[t] = 0.f;
+    for (int c0 = 0; c0 < Lk; c0 += 64) {
+        const int nrows = min(64, Lk - c0);
+        __syncthreads();
+        load_chunk(kc, vb, a.ldv, c0, nrows, dh, lane);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < MAXE; ++t) {
+            const int e = lane + 64 * t;
+            if (e < Lq * dh) {
+                const int i = e / dh, d = e - i * dh;
+                float s = 0.f;
+                for (int r = 0; r < nrows; ++r) s += sc[i * Lk + c0 + r] * kc[r * (dh + 1) + d];
+                acc[t] += s;
+            }
         }
+    }
+#pragma unroll
+    for (int t = 0; t < MAXE; ++t) {
+        const int e = lane + 64 * t;
+        if (e < Lq * dh) {
+            const int i = e / dh, d = e - i * dh;
+            a.o[((size_t)b * Lq + i) * a.ldo + h * dh + d] = acc[t];
+        }
+    }
 }
 
+template <int MAXE>
 __global__ __launch_bounds__(64) void mha_bwd_kernel(const MhaArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
@@ -100,16 +129,17 @@ __global__ __launch_bounds__(64) void mha_bwd_kernel(const MhaArgs a) {
     const float* vb = a.v + (size_t)b * Lk * a.ldv + h * dh;
     const float* dob = a.d_o + (size_t)b * Lq * a.lddo + h * dh;
     const size_t pbase = ((size_t)(b * a.heads + h) * Lq) * Lk;
-    for (int i = 0; i < Lq; ++i)
-        for (int d = lane; d < dh; d += 64) {
-            qs[i * dh + d] = qb[(size_t)i * a.ldq + d];
-            dos[i * dh + d] = dob[(size_t)i * a.lddo + d];
-        }
+    for (int e = lane; e < Lq * dh; e += 64) {
+        const int i = e / dh, d = e - i * dh;
+        qs[e] = qb[(size_t)i * a.ldq + d];
+        dos[e] = dob[(size_t)i * a.lddo + d];
+    }
     for (int e = lane; e < Lq * Lk; e += 64) P[e] = a.probs[pbase + e];
     // dP = (dO . V^T) o keep*scale
     for (int c0 = 0; c0 < Lk; c0 += 64) {
+        const int nrows = min(64, Lk - c0);
         __syncthreads();
-        load_chunk(kc, vb, a.ldv, c0, 64, Lk, dh, lane);
+        load_chunk(kc, vb, a.ldv, c0, nrows, dh, lane);
         __syncthreads();
         const int j = c0 + lane;
         if (j < Lk)
@@ -132,23 +162,44 @@ __global__ __launch_bounds__(64) void mha_bwd_kernel(const MhaArgs a) {
             if (a.drop) P[i * Lk + j] = p * a.drop_scale * (float)a.drop[pbase + (size_t)i * Lk + j];
         }
     }
-    __syncthreads();
-    for (int i = 0; i < Lq; ++i)
-        for (int d = lane; d < dh; d += 64) {
-            float acc = 0.f;
-            for (int j = 0; j < Lk; ++j) acc += dS[i * Lk + j] * kb[(size_t)j * a.ldk + d];
-            a.dq[((size_t)b * Lq + i) * a.lddq + h * dh + d] = acc;
-        }
-    for (int j = 0; j < Lk; ++j)
-        for (int d = lane; d < dh; d += 64) {
-            float gk = 0.f, gv = 0.f;
-            for (int i = 0; i < Lq; ++i) {
-                gk += dS[i * Lk + j] * qs[i * dh + d];
-                gv += P[i * Lk + j] * dos[i * dh + d];
+    // dq = dS . K ; dk = dS^T . q ; dv = P_dropped^T . dO   -- K chunk by chunk through LDS
+    float acc[MAXE];
+#pragma unroll
+    for (int t = 0; t < MAXE; ++t) acc[t] = 0.f;
+    for (int c0 = 0; c0 < Lk; c0 += 64) {
+        const int nrows = min(64, Lk - c0);
+        __syncthreads();
+        load_chunk(kc, kb, a.ldk, c0, nrows, dh, lane);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < MAXE; ++t) {
+            const int e = lane + 64 * t;
+            if (e < Lq * dh) {
+                const int i = e / dh, d = e - i * dh;
+                float s = 0.f;
+                for (int r = 0; r < nrows; ++r) s += dS[i * Lk + c0 + r] * kc[r * (dh + 1) + d];
+                acc[t] += s;
             }
-            a.dk[((size_t)b * Lk + j) * a.lddk + h * dh + d] = gk;
-            a.dv[((size_t)b * Lk + j) * a.lddv + h * dh + d] = gv;
         }
+    }
+#pragma unroll
+    for (int t = 0; t < MAXE; ++t) {
+        const int e = lane + 64 * t;
+        if (e < Lq * dh) {
+            const int i = e / dh, d = e - i * dh;
+            a.dq[((size_t)b * Lq + i) * a.lddq + h * dh + d] = acc[t];
+        }
+    }
+    for (int e = lane; e < Lk * dh; e += 64) {
+        const int j = e / dh, d = e - j * dh;
+        float gk = 0.f, gv = 0.f;
+        for (int i = 0; i < Lq; ++i) {
+            gk += dS[i * Lk + j] * qs[i * dh + d];
+            gv += P[i * Lk + j] * dos[i * dh + d];
+        }
+        a.dk[((size_t)b * Lk + j) * a.lddk + h * dh + d] = gk;
+        a.dv[((size_t)b * Lk + j) * a.lddv + h * dh + d] = gv;
+    }
 }
 
 static size_t mha_lds_bytes(int Lq, int Lk, int dh, bool bwd) {
@@ -166,6 +217,7 @@ static int mha_check(const MhaArgs& a, bool bwd) {
     if (bwd && (!a.d_o || !a.dq || !a.dk || !a.dv || a.lddo < H || a.lddq < H || a.lddk < H || a.lddv < H))
         return R3D_EINVAL;
     if (mha_lds_bytes(a.Lq, a.Lk, a.dh, bwd) > 160 * 1024) return R3D_EINVAL;
+    if ((long)a.Lq * a.dh > 1024) return R3D_EINVAL;               // 16 output slots per lane
     return R3D_OK;
 }
 
@@ -186,11 +238,14 @@ R3D_EXPORT int r3d_mha_core_fwd(const float* q, int ldq, const float* k, int ldk
     int rc = mha_check(a, false);
     if (rc != R3D_OK) return rc;
     const size_t lds = mha_lds_bytes(Lq, Lk, dh, false);
+    const bool small = (long)Lq * dh <= 128;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)mha_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(small ? (const void*)mha_fwd_kernel<2> : (const void*)mha_fwd_kernel<16>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(mha_fwd_kernel, dim3(B * heads), dim3(64), lds, (hipStream_t)stream, a);
+    if (small) hipLaunchKernelGGL(mha_fwd_kernel<2>, dim3(B * heads), dim3(64), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(mha_fwd_kernel<16>, dim3(B * heads), dim3(64), lds, (hipStream_t)stream, a);
     R3D_LAUNCH_CHECK();
     return R3D_OK;
 }
@@ -207,11 +262,14 @@ R3D_EXPORT int r3d_mha_core_bwd(const float* q, int ldq, const float* k, int ldk
     int rc = mha_check(a, true);
     if (rc != R3D_OK) return rc;
     const size_t lds = mha_lds_bytes(Lq, Lk, dh, true);
+    const bool small = (long)Lq * dh <= 128;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)mha_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(small ? (const void*)mha_bwd_kernel<2> : (const void*)mha_bwd_kernel<16>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(mha_bwd_kernel, dim3(B * heads), dim3(64), lds, (hipStream_t)stream, a);
+    if (small) hipLaunchKernelGGL(mha_bwd_kernel<2>, dim3(B * heads), dim3(64), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(mha_bwd_kernel<16>, dim3(B * heads), dim3(64), lds, (hipStream_t)stream, a);
     R3D_LAUNCH_CHECK();
     return R3D_OK;
 }

@@ -20,7 +20,7 @@ namespace r3d {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 16;
+constexpr int BK_MIN = 16;       // split-K slab granularity
 
 // ---------------------------------------------------------------------------------------------------------
 // epilogue shared by the GEMM kernel and the split-K reducer
@@ -45,19 +45,20 @@ __device__ __forceinline__ void gemm_epilogue(const r3d_gemm_desc& d, int m, int
 // ---------------------------------------------------------------------------------------------------------
 // staging helpers
 // ---------------------------------------------------------------------------------------------------------
-// K-contiguous source: tile of R rows x 16 k.  f indexes float4s: row = f/4, kq = f%4.
-template <int R, int NT, bool VEC, bool PROLOGUE>
+// K-contiguous source: tile of R rows x BK k.  f indexes float4s: row = f/(BK/4), kq = f%(BK/4).
+template <int R, int BK, int NT, bool VEC, bool PROLOGUE>
 struct StageKC {
-    static constexpr int NLD = (R * 4) / NT;
-    static_assert(NLD >= 1 && (R * 4) % NT == 0, "tile too small for the workgroup");
+    static constexpr int Q4 = BK / 4;
+    static constexpr int NLD = (R * Q4) / NT;
+    static_assert(NLD >= 1 && (R * Q4) % NT == 0, "tile too small for the workgroup");
     float4 v[NLD];
     __device__ __forceinline__ void load(const float* __restrict__ base, int ld, int row0, int rows_total,
                                          int k0, int k_end, const r3d_gemm_desc& d) {
 #pragma unroll
         for (int p = 0; p < NLD; ++p) {
             const int f = threadIdx.x + p * NT;
-            const int row = row0 + (f >> 2);
-            const int k = k0 + ((f & 3) << 2);
+            const int row = row0 + f / Q4;
+            const int k = k0 + ((f % Q4) << 2);
             float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
             if (row < rows_total && k < k_end) {
                 int srow = row;
@@ -82,13 +83,13 @@ struct StageKC {
             v[p] = x;
         }
     }
-    // LDS image [16][R + 2]
+    // LDS image [BK][R + 2]
     __device__ __forceinline__ void store(float* __restrict__ s) const {
         constexpr int S = R + 2;
 #pragma unroll
         for (int p = 0; p < NLD; ++p) {
             const int f = threadIdx.x + p * NT;
-            const int row = f >> 2, kq = (f & 3) << 2;
+            const int row = f / Q4, kq = (f % Q4) << 2;
             s[(kq + 0) * S + row] = v[p].x;
             s[(kq + 1) * S + row] = v[p].y;
             s[(kq + 2) * S + row] = v[p].z;
@@ -97,11 +98,11 @@ struct StageKC {
     }
 };
 
-// M/N-contiguous source: tile of 16 k-rows x R columns.  f indexes float4s: krow = f/(R/4), cq = f%(R/4).
-template <int R, int NT, bool VEC>
+// M/N-contiguous source: tile of BK k-rows x R columns.  f indexes float4s: krow = f/(R/4), cq = f%(R/4).
+template <int R, int BK, int NT, bool VEC>
 struct StageMC {
-    static constexpr int NLD = (R * 4) / NT;
-    static_assert(NLD >= 1 && (R * 4) % NT == 0, "tile too small for the workgroup");
+    static constexpr int NLD = (R * BK / 4) / NT;
+    static_assert(NLD >= 1 && (R * BK / 4) % NT == 0, "tile too small for the workgroup");
     float4 v[NLD];
     __device__ __forceinline__ void load(const float* __restrict__ base, int ld, int col0, int cols_total,
                                          int k0, int k_end) {
@@ -125,7 +126,7 @@ struct StageMC {
             v[p] = x;
         }
     }
-    // LDS image [16][R + 4]
+    // LDS image [BK][R + 4]
     __device__ __forceinline__ void store(float* __restrict__ s) const {
         constexpr int S = R + 4;
 #pragma unroll
@@ -140,7 +141,7 @@ struct StageMC {
 // ---------------------------------------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------------------------------------
-template <int LA, int LB, int BM, int BN, int WM, int WN, bool VEC>
+template <int LA, int LB, int BM, int BN, int BK, int WM, int WN, bool VEC>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const r3d_gemm_desc d) {
     constexpr int NT = 64 * WM * WN;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -177,10 +178,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const r3d_gemm_d
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    StageKC<BM, NT, VEC, true> a_kc;
-    StageMC<BM, NT, VEC> a_mc;
-    StageKC<BN, NT, VEC, false> b_kc;
-    StageMC<BN, NT, VEC> b_mc;
+    StageKC<BM, BK, NT, VEC, true> a_kc;
+    StageMC<BM, BK, NT, VEC> a_mc;
+    StageKC<BN, BK, NT, VEC, false> b_kc;
+    StageMC<BN, BK, NT, VEC> b_mc;
+    float asum[TM];                    // TN only: column sums of A = the bias gradient (d.bias_grad)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) asum[i] = 0.f;
 
     auto load_tiles = [&](int kt) {
         const int k0 = k_begin + kt * BK;
@@ -210,7 +214,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const r3d_gemm_d
             const int kr = kk * 2 + lhi;
             float a[TM], b[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = as[kr * SA + wm_off + i * 32 + l31];
+            for (int i = 0; i < TM; ++i) {
+                a[i] = as[kr * SA + wm_off + i * 32 + l31];
+                if (LA == 1) asum[i] += a[i];
+            }
 #pragma unroll
             for (int j = 0; j < TN; ++j) b[j] = bs[kr * SB + wn_off + j * 32 + l31];
 #pragma unroll
@@ -221,6 +228,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const r3d_gemm_d
         }
         if (more) store_tiles((kt & 1) ? As0 : As1, (kt & 1) ? Bs0 : Bs1);
         __syncthreads();
+    }
+
+    if (LA == 1 && d.bias_grad && n0 == 0 && wn_off == 0) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const float t = asum[i] + __shfl_xor(asum[i], 32, 64);
+            const int m = m0 + wm_off + i * 32 + l31;
+            if (lhi == 0 && m < d.M) d.bias_grad[m] = t;
+        }
     }
 
     // Epilogue through LDS: each wave parks one 32x32 accumulator tile in its own [32][33] LDS patch (C/D map of the
@@ -261,12 +277,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const r3d_gemm_desc 
 // ---------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------
-template <int LA, int LB, int BM, int BN, int WM, int WN>
+template <int LA, int LB, int BM, int BN, int BK, int WM, int WN>
 static int launch_cfg(const r3d_gemm_desc& d, bool vec, int nsplit, hipStream_t s) {
     dim3 grid(r3d_cdiv(d.M, BM) * r3d_cdiv(d.N, BN), nsplit, 1);
     dim3 block(64 * WM * WN, 1, 1);
-    if (vec) hipLaunchKernelGGL((gemm_f32_kernel<LA, LB, BM, BN, WM, WN, true>), grid, block, 0, s, d);
-    else hipLaunchKernelGGL((gemm_f32_kernel<LA, LB, BM, BN, WM, WN, false>), grid, block, 0, s, d);
+    if (vec) hipLaunchKernelGGL((gemm_f32_kernel<LA, LB, BM, BN, BK, WM, WN, true>), grid, block, 0, s, d);
+    else hipLaunchKernelGGL((gemm_f32_kernel<LA, LB, BM, BN, BK, WM, WN, false>), grid, block, 0, s, d);
     R3D_LAUNCH_CHECK();
     return R3D_OK;
 }
@@ -274,9 +290,9 @@ static int launch_cfg(const r3d_gemm_desc& d, bool vec, int nsplit, hipStream_t 
 template <int LA, int LB>
 static int launch_layout(const r3d_gemm_desc& d, bool vec, int nsplit, hipStream_t s) {
     switch (d.tile) {
-        case 1: return launch_cfg<LA, LB, 32, 32, 1, 1>(d, vec, nsplit, s);
-        case 2: return launch_cfg<LA, LB, 64, 64, 2, 2>(d, vec, nsplit, s);
-        case 3: return launch_cfg<LA, LB, 128, 128, 2, 2>(d, vec, nsplit, s);
+        case 1: return launch_cfg<LA, LB, 32, 32, 64, 1, 1>(d, vec, nsplit, s);
+        case 2: return launch_cfg<LA, LB, 64, 64, 64, 2, 2>(d, vec, nsplit, s);
+        case 3: return launch_cfg<LA, LB, 128, 128, 32, 2, 2>(d, vec, nsplit, s);
         default: return R3D_EINVAL;
     }
 }
@@ -305,13 +321,13 @@ R3D_EXPORT int r3d_gemm_plan(r3d_gemm_desc* d) {
     for (int t = 1; t <= 3; ++t) {
         const long tiles = (long)r3d_cdiv(d->M, tile_sz[t]) * r3d_cdiv(d->N, tile_sz[t]);
         for (int sk = 1; sk <= 256; sk *= 2) {
-            int kps = r3d_cdiv(r3d_cdiv(d->K, sk), BK) * BK;
-            if (sk > 1 && kps < 4 * BK) break;
+            int kps = r3d_cdiv(r3d_cdiv(d->K, sk), BK_MIN) * BK_MIN;
+            if (sk > 1 && kps < 128) break;
             const int ns = r3d_cdiv(d->K, kps);
             if (sk > 1 && ns < 2) continue;
             const long waves = tiles * ns * tile_waves[t];
             const double rounds = (double)((waves + 1023) / 1024);
-            const double per_wave = (double)r3d_cdiv(kps, BK) * tile_cyc[t] + 4000.0;
+            const double per_wave = (double)r3d_cdiv(kps, BK_MIN) * tile_cyc[t] + 4000.0;
             // slab write + read at ~4 TB/s ~= 0.6 cycle/KB-per-CU-equivalent; expressed in cycles @2.4 GHz
             const double slab = (ns > 1) ? 2.0 * ns * (double)d->M * d->N * 4.0 / 4.0e12 * 2.4e9 + 4500.0 : 0.0;
             // wasted MFMA work in ragged edge tiles is already inside `tiles`
@@ -339,6 +355,7 @@ static int gemm_validate(const r3d_gemm_desc* d) {
     if (d->c_row_xor < 0 || d->c_row_xor > 1) return R3D_EINVAL;
     if (d->a_row_xor < 0 || d->a_row_xor > 1) return R3D_EINVAL;
     if (d->mul && !d->aux) return R3D_EINVAL;
+    if (d->bias_grad && (d->layout != R3D_GEMM_TN || d->splitk > 1)) return R3D_EINVAL;
     if (d->splitk > 1) {
         if (!d->partial || d->k_per_split <= 0 || (d->k_per_split % 16) != 0) return R3D_EINVAL;
         if (r3d_cdiv(d->K, d->k_per_split) > d->splitk) return R3D_EINVAL;

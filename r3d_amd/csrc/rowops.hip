@@ -165,15 +165,22 @@ __global__ __launch_bounds__(256) void chunk_sum_kernel(const float* ws, int nch
     out[i] = s;
 }
 
-// ws: [blocks][2][H] -> dgamma[H], dbeta[H]
+// ws: [blocks][2][H] -> dgamma[H], dbeta[H].  Block = 64 consecutive entries of the 2H outputs; its 4 waves split
+// the partial range (fixed order -> reproducible), lane = output entry (coalesced 256-B reads).
 __global__ __launch_bounds__(256) void ln_param_finalize_kernel(const float* ws, int blocks, int H, float* dgamma,
                                                                 float* dbeta) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= 2 * H) return;
-    const int which = i / H, col = i % H;
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;
     float s = 0.f;
-    for (int p = 0; p < blocks; ++p) s += ws[((size_t)p * 2 + which) * H + col];
-    (which == 0 ? dgamma : dbeta)[col] = s;
+    if (i < 2 * H)
+        for (int p = wave; p < blocks; p += 4) s += ws[(size_t)p * 2 * H + i];
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && i < 2 * H) {
+        const float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        (i < H ? dgamma : dbeta)[i < H ? i : i - H] = t;
+    }
 }
 
 // column sums of x[rows, cols]: grid (colblocks of 64, rowchunks); wave w of the block takes rows w, w+4, ...
@@ -247,8 +254,15 @@ R3D_EXPORT int r3d_layernorm_fwd(const float* x, int ldx, int nsplit, const floa
                       dim3(r3d_cdiv(units, 4)), 0, (hipStream_t)stream, a);
 }
 
+// One row per wave (4 rows per block) up to 1024 rows -- the row path is latency-bound, so rows must not queue
+// behind each other inside a wave; beyond that, at most 256 blocks of partial parameter gradients.
+static int ln_bwd_rows_per_block(int rows) {
+    const int rpb = (r3d_cdiv(rows, 256) + 3) / 4 * 4;
+    return rpb < 4 ? 4 : rpb;
+}
+
 R3D_EXPORT int64_t r3d_layernorm_bwd_ws_floats(int rows, int H) {
-    const int rpb = rows <= 64 ? rows : (r3d_cdiv(rows, 64) < 16 ? 16 : r3d_cdiv(rows, 64));
+    const int rpb = ln_bwd_rows_per_block(rows);
     const int blocks = r3d_cdiv(rows, rpb);
     return blocks > 1 ? (int64_t)blocks * 2 * H : 0;
 }
@@ -264,7 +278,7 @@ R3D_EXPORT int r3d_layernorm_bwd(const float* dy, int lddy, int pair_in, const f
     R3D_REQUIRE((dgamma == nullptr) == (dbeta == nullptr));
     R3D_REQUIRE(!pair_in || (rows % 2) == 0);
     R3D_REQUIRE(!dy2 || (lddy2 >= H && !pair_in));
-    const int rpb = rows <= 64 ? rows : (r3d_cdiv(rows, 64) < 16 ? 16 : r3d_cdiv(rows, 64));
+    const int rpb = ln_bwd_rows_per_block(rows);
     const int blocks = r3d_cdiv(rows, rpb);
     R3D_REQUIRE(blocks == 1 || !dgamma || ws);
     LnBwdArgs a{dy, lddy, pair_in, dy2, lddy2, x, ldx, mean, rstd, gamma, beta, relu, add1, ldadd1, add2, ldadd2, dx, lddx,
@@ -275,7 +289,7 @@ R3D_EXPORT int r3d_layernorm_bwd(const float* dy, int lddy, int pair_in, const f
                         shmem, s, a);
     if (rc != R3D_OK) return rc;
     if (dgamma && blocks > 1) {
-        hipLaunchKernelGGL(ln_param_finalize_kernel, dim3(r3d_cdiv(2 * H, 256)), dim3(256), 0, s, ws, blocks, H,
+        hipLaunchKernelGGL(ln_param_finalize_kernel, dim3(r3d_cdiv(2 * H, 64)), dim3(256), 0, s, ws, blocks, H,
                            dgamma, dbeta);
         R3D_LAUNCH_CHECK();
     }

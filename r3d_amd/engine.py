@@ -124,15 +124,19 @@ class _Shape:
         self.actdur = f(BQ, K + 1)
         self.seg = f(N, K)
         self.loss = f(4)
+        self.loss_ws = f(4 * (N + BQ + B))
         self.counts = torch.zeros(4, dtype=torch.int64, device=dev)
         if train:
             self.d_actdur, self.d_seg = torch.zeros(BQ, K + 1, dtype=torch.float32, device=dev), f(N, K)
             self.d_tgtF, self.d_t = f(BQ, H), f(BQ, H)
-            self.g_a, self.g_b, self.g_c, self.g_d = f(BQ, H), f(BQ, H), f(BQ, H), f(BQ, H)
-            self.d_ff1, self.d_sa_qkv, self.d_cakv, self.g_kv = f(BQ, 4 * H), f(BQ, 3 * H), f(N, 2 * H), f(N, H)
+            # one buffer per gradient tensor: nothing is reused inside a step, so weight-gradient kernels on the side
+            # stream can keep reading a tensor while the main stream moves on
+            self.glayers = [dict(t3pre=f(BQ, H), ff2=f(BQ, H), ff1=f(BQ, 4 * H), t2=f(BQ, H), t2pre=f(BQ, H), cap=f(BQ, H),
+                                 cao=f(BQ, H), caq=f(BQ, H), cakv=f(N, 2 * H), caqin=f(BQ, H), t1pre=f(BQ, H), sap=f(BQ, H),
+                                 sao=f(BQ, H), saqkv=f(BQ, 3 * H), sain=f(BQ, H)) for _ in range(L)]
             self.d_fused = f(N, H)
-            self.d_x3, self.d_u, self.d_h, self.d_x1, self.d_v, self.d_x0 = (f(2 * N, H), f(2 * N, 4 * H), f(2 * N, H),
-                                                                              f(2 * N, H), f(2 * N, H), f(2 * N, H))
+            self.d_x3, self.d_u, self.d_h1, self.d_h2, self.d_x1, self.d_v, self.d_x0 = (
+                f(2 * N, H), f(2 * N, 4 * H), f(2 * N, H), f(2 * N, H), f(2 * N, H), f(2 * N, H), f(2 * N, H))
             self.d_rgb_pre, self.d_dep, self.d_dep_pre = f(N, H), f(N, H), f(N, H)
             # dropout keep-masks (one Philox launch fills the whole pool)
             sizes = dict(x0=2 * N * H)
@@ -161,6 +165,9 @@ class FusionEngine:
         assert self.H % 8 == 0 and self.H % self.heads == 0
         self.arena = ParamArena(list(module.named_parameters()), self.device)
         self.ws = ops.GemmWorkspace(self.device)
+        self.ws_side = ops.GemmWorkspace(self.device)
+        self.side = torch.cuda.Stream(self.device)      # weight-gradient stream: off the backward's critical path
+        self.use_side_stream = True
         self.shapes = {}
         self.train_mask = None            # cached train-mode selection (data independent)
         self.drop_seed = 0x5EED
@@ -312,7 +319,7 @@ class FusionEngine:
                            target_dur, w.B, w.S, self.Q, K, self.pad_idx, EXCLUDE_CLASS_IDX, w.loss, w.counts,
                            val_mode=val_mode, dur_den=self.dur_den,
                            d_seg=w.d_seg if with_grad else None, d_act=w.d_actdur[:, :K] if with_grad else None,
-                           d_dur=w.d_actdur[:, K:] if with_grad else None, ld_ddur=K + 1)
+                           d_dur=w.d_actdur[:, K:] if with_grad else None, ld_ddur=K + 1, ws=w.loss_ws)
         return w.loss, w.counts
 
     # ------------------------------------------------------------------------------------------------------
@@ -332,6 +339,10 @@ class FusionEngine:
         ops.gemm(GEMM_TN, st["w"].d_dep_pre, st["x_dep"], self.arena.g("depth_projection.weight"), ws=self.ws)
 
     def backward_main(self, d_seg=None, d_actdur=None):
+        """Everything of the backward except depth_projection.weight.  The chain of input gradients (the critical path)
+        runs on the current stream; every weight / bias gradient is enqueued on a second HIP stream as soon as its
+        operands exist and joins back before the function returns (also under hipGraph capture, where the two streams
+        become parallel branches of the graph)."""
         st = self.last
         w, a, H, Q, K, heads, dh, ws = st["w"], self.arena, self.H, self.Q, self.K, self.heads, self.dh, self.ws
         B, S, N, BQ = w.B, w.S, w.N, w.BQ
@@ -341,71 +352,80 @@ class FusionEngine:
         dsc = 1.0 / (1.0 - DROP_P)
         dm = (lambda k, r, c: w.drop[k].view(r, c)) if drop else (lambda k, r, c: None)
         dmf = (lambda k: w.drop[k]) if drop else (lambda k: None)
+        main = torch.cuda.current_stream()
+        side = self.side if self.use_side_stream else main
+        wss = self.ws_side if self.use_side_stream else ws
+
+        def wgrad(dy, x, gw, gb):
+            """gw = dy^T . x  (+ gb = column sums of dy, fused into the same launch) on the side stream"""
+            if side is not main:
+                side.wait_stream(main)
+            with torch.cuda.stream(side):
+                ops.gemm(GEMM_TN, dy, x, gw, bias_grad=gb, ws=wss)
+
+        def on_side(fn):
+            if side is not main:
+                side.wait_stream(main)
+            with torch.cuda.stream(side):
+                fn()
+
         # ---- heads
-        ops.gemm(GEMM_TN, d_actdur, w.tgtF, self.gw_head, ws=ws)
-        ops.colsum(d_actdur, self.gb_head, ws=ws)
         ops.gemm(GEMM_NN, d_actdur, self.w_head, w.d_tgtF, ws=ws)
-        ops.gemm(GEMM_TN, d_seg, w.fused, a.g("fc_seg.weight"), ws=ws)
-        ops.colsum(d_seg, a.g("fc_seg.bias"), ws=ws)
+        wgrad(d_actdur, w.tgtF, self.gw_head, self.gb_head)
+        wgrad(d_seg, w.fused, a.g("fc_seg.weight"), a.g("fc_seg.bias"))
         # ---- decoder
         last = w.layers[-1]
         ops.layernorm_bwd(w.d_tgtF, last["t3"], w.mF, w.rF, a.p("transformer.decoder.norm.weight"),
                           a.p("transformer.decoder.norm.bias"), w.d_t, a.g("transformer.decoder.norm.weight"),
                           a.g("transformer.decoder.norm.bias"), ws=ws)
         dy, dy2 = w.d_t, None                 # gradient w.r.t. t3 of the current layer (= dy + dy2)
-        qpos = a.p("query_embed.weight")
         g_qe = a.g("query_embed.weight")
         first_qe, first_fused = True, True
         for l in reversed(range(self.L)):
-            c, pl = w.layers[l], f"transformer.decoder.layers.{l}."
+            c, gl, pl = w.layers[l], w.glayers[l], f"transformer.decoder.layers.{l}."
             g = lambda n: a.g(pl + n)         # noqa: E731
             p = lambda n: a.p(pl + n)         # noqa: E731
             # norm3 -> (t2 residual, FFN)
-            ops.layernorm_bwd(dy, c["t3_pre"], c["m3"], c["r3"], p("norm3.weight"), p("norm3.bias"), w.g_a,
-                              g("norm3.weight"), g("norm3.bias"), dy2=dy2, dx2=w.g_b, drop_mask=dm(f"d3_{l}", BQ, H),
-                              drop_scale=dsc, ws=ws)                           # g_a = d t3_pre ; g_b = d(linear2 out)
-            ops.gemm(GEMM_TN, w.g_b, c["ff1"], g("linear2.weight"), ws=ws)
-            ops.colsum(w.g_b, g("linear2.bias"), ws=ws)
-            ops.gemm(GEMM_NN, w.g_b, p("linear2.weight"), w.d_ff1, drop_mask=dm(f"ff_{l}", BQ, 4 * H), drop_scale=dsc,
-                     aux=c["ff1"], mul=1, ws=ws)
-            ops.gemm(GEMM_TN, w.d_ff1, c["t2"], g("linear1.weight"), ws=ws)
-            ops.colsum(w.d_ff1, g("linear1.bias"), ws=ws)
-            ops.gemm(GEMM_NN, w.d_ff1, p("linear1.weight"), w.g_c, res1=w.g_a, ws=ws)          # g_c = d t2
+            ops.layernorm_bwd(dy, c["t3_pre"], c["m3"], c["r3"], p("norm3.weight"), p("norm3.bias"), gl["t3pre"],
+                              g("norm3.weight"), g("norm3.bias"), dy2=dy2, dx2=gl["ff2"], drop_mask=dm(f"d3_{l}", BQ, H),
+                              drop_scale=dsc, ws=ws)
+            ops.gemm(GEMM_NN, gl["ff2"], p("linear2.weight"), gl["ff1"], drop_mask=dm(f"ff_{l}", BQ, 4 * H),
+                     drop_scale=dsc, aux=c["ff1"], mul=1, ws=ws)
+            wgrad(gl["ff2"], c["ff1"], g("linear2.weight"), g("linear2.bias"))
+            ops.gemm(GEMM_NN, gl["ff1"], p("linear1.weight"), gl["t2"], res1=gl["t3pre"], ws=ws)
+            wgrad(gl["ff1"], c["t2"], g("linear1.weight"), g("linear1.bias"))
             # norm2 -> (t1 residual, cross attention)
-            ops.layernorm_bwd(w.g_c, c["t2_pre"], c["m2"], c["r2"], p("norm2.weight"), p("norm2.bias"), w.g_a,
-                              g("norm2.weight"), g("norm2.bias"), dx2=w.g_b, drop_mask=dm(f"d2_{l}", BQ, H),
-                              drop_scale=dsc, ws=ws)                           # g_a = d t2_pre ; g_b = d(out_proj out)
-            ops.gemm(GEMM_TN, w.g_b, c["ca_o"], g("multihead_attn.out_proj.weight"), ws=ws)
-            ops.colsum(w.g_b, g("multihead_attn.out_proj.bias"), ws=ws)
-            ops.gemm(GEMM_NN, w.g_b, p("multihead_attn.out_proj.weight"), w.g_c, ws=ws)        # g_c = d ca_o
-            ops.mha_core_bwd(c["caq"], c["cakv"][:, :H], c["cakv"][:, H:], c["p_ca"], w.g_c, w.g_d, w.d_cakv[:, :H],
-                             w.d_cakv[:, H:], B, heads, Q, S, dh, drop_mask=dmf(f"ca_p{l}"), drop_scale=dsc)
+            ops.layernorm_bwd(gl["t2"], c["t2_pre"], c["m2"], c["r2"], p("norm2.weight"), p("norm2.bias"), gl["t2pre"],
+                              g("norm2.weight"), g("norm2.bias"), dx2=gl["cap"], drop_mask=dm(f"d2_{l}", BQ, H),
+                              drop_scale=dsc, ws=ws)
+            ops.gemm(GEMM_NN, gl["cap"], p("multihead_attn.out_proj.weight"), gl["cao"], ws=ws)
+            wgrad(gl["cap"], c["ca_o"], g("multihead_attn.out_proj.weight"), g("multihead_attn.out_proj.bias"))
+            ops.mha_core_bwd(c["caq"], c["cakv"][:, :H], c["cakv"][:, H:], c["p_ca"], gl["cao"], gl["caq"],
+                             gl["cakv"][:, :H], gl["cakv"][:, H:], B, heads, Q, S, dh, drop_mask=dmf(f"ca_p{l}"),
+                             drop_scale=dsc)
             wi = p("multihead_attn.in_proj_weight")
             gwi, gbi = g("multihead_attn.in_proj_weight"), g("multihead_attn.in_proj_bias")
-            ops.gemm(GEMM_TN, w.g_d, c["caq_in"], gwi[:H], ws=ws)
-            ops.colsum(w.g_d, gbi[:H], ws=ws)
-            ops.gemm(GEMM_NN, w.g_d, wi[:H], w.g_c, ws=ws)                                    # g_c = d caq_in
-            ops.rowmod_sum(w.g_c, Q, g_qe, accumulate=not first_qe)
-            first_qe = False
-            ops.gemm(GEMM_TN, w.d_cakv, w.kv_in, gwi[H:], ws=ws)
-            ops.colsum(w.d_cakv, gbi[H:], ws=ws)
-            ops.gemm(GEMM_NN, w.d_cakv, wi[H:], w.d_fused, accumulate=not first_fused, ws=ws)   # d kv_in
+            ops.gemm(GEMM_NN, gl["caq"], wi[:H], gl["caqin"], ws=ws)
+            wgrad(gl["caq"], c["caq_in"], gwi[:H], gbi[:H])
+            wgrad(gl["cakv"], w.kv_in, gwi[H:], gbi[H:])
+            ops.gemm(GEMM_NN, gl["cakv"], wi[H:], w.d_fused, accumulate=not first_fused, ws=ws)   # d kv_in
             first_fused = False
-            # norm1 -> (tgt residual, self attention);  d t1 = g_c (query path) + g_a (residual into t2_pre)
-            ops.layernorm_bwd(w.g_c, c["t1_pre"], c["m1"], c["r1"], p("norm1.weight"), p("norm1.bias"), w.g_d,
-                              g("norm1.weight"), g("norm1.bias"), dy2=w.g_a, dx2=w.g_b, drop_mask=dm(f"d1_{l}", BQ, H),
-                              drop_scale=dsc, ws=ws)                           # g_d = d t1_pre ; g_b = d(out_proj out)
-            ops.gemm(GEMM_TN, w.g_b, c["sa_o"], g("self_attn.out_proj.weight"), ws=ws)
-            ops.colsum(w.g_b, g("self_attn.out_proj.bias"), ws=ws)
-            ops.gemm(GEMM_NN, w.g_b, p("self_attn.out_proj.weight"), w.g_c, ws=ws)             # g_c = d sa_o
-            ops.mha_core_bwd(c["sa_qkv"][:, :H], c["sa_qkv"][:, H:2 * H], c["sa_qkv"][:, 2 * H:], c["p_sa"], w.g_c,
-                             w.d_sa_qkv[:, :H], w.d_sa_qkv[:, H:2 * H], w.d_sa_qkv[:, 2 * H:], B, heads, Q, Q, dh,
+            acc_qe = not first_qe
+            on_side(lambda gl=gl, acc_qe=acc_qe: ops.rowmod_sum(gl["caqin"], Q, g_qe, accumulate=acc_qe))
+            first_qe = False
+            # norm1 -> (tgt residual, self attention);  d t1 = caqin (query path) + t2pre (residual into t2_pre)
+            ops.layernorm_bwd(gl["caqin"], c["t1_pre"], c["m1"], c["r1"], p("norm1.weight"), p("norm1.bias"), gl["t1pre"],
+                              g("norm1.weight"), g("norm1.bias"), dy2=gl["t2pre"], dx2=gl["sap"],
+                              drop_mask=dm(f"d1_{l}", BQ, H), drop_scale=dsc, ws=ws)
+            ops.gemm(GEMM_NN, gl["sap"], p("self_attn.out_proj.weight"), gl["sao"], ws=ws)
+            wgrad(gl["sap"], c["sa_o"], g("self_attn.out_proj.weight"), g("self_attn.out_proj.bias"))
+            ops.mha_core_bwd(c["sa_qkv"][:, :H], c["sa_qkv"][:, H:2 * H], c["sa_qkv"][:, 2 * H:], c["p_sa"], gl["sao"],
+                             gl["saqkv"][:, :H], gl["saqkv"][:, H:2 * H], gl["saqkv"][:, 2 * H:], B, heads, Q, Q, dh,
                              drop_mask=dmf(f"sa_p{l}"), drop_scale=dsc)
-            ops.gemm(GEMM_TN, w.d_sa_qkv, c["sa_in"], g("self_attn.in_proj_weight"), ws=ws)
-            ops.colsum(w.d_sa_qkv, g("self_attn.in_proj_bias"), ws=ws)
-            ops.gemm(GEMM_NN, w.d_sa_qkv, p("self_attn.in_proj_weight"), w.g_c, ws=ws)         # g_c = d sa_in
-            ops.rowmod_sum(w.g_c, Q, g_qe, accumulate=True)
-            dy, dy2 = w.g_c, w.g_d             # d t3 of layer l-1 = g_c (through sa_in) + g_d (residual into t1_pre)
+            ops.gemm(GEMM_NN, gl["saqkv"], p("self_attn.in_proj_weight"), gl["sain"], ws=ws)
+            wgrad(gl["saqkv"], c["sa_in"], g("self_attn.in_proj_weight"), g("self_attn.in_proj_bias"))
+            on_side(lambda gl=gl: ops.rowmod_sum(gl["sain"], Q, g_qe, accumulate=True))
+            dy, dy2 = gl["sain"], gl["t1pre"]  # d t3 of layer l-1 = sain (through sa_in) + t1pre (residual into t1_pre)
         # ---- positional embedding gradient: sum over clips of d kv_in, before the seg head joins d_fused (:190)
         ops.rowmod_sum(w.d_fused, S, a.g("pos_embedding")[0, :S])
         ops.gemm(GEMM_NN, d_seg, a.p("fc_seg.weight"), w.d_fused, accumulate=True, ws=ws)
@@ -413,31 +433,29 @@ class FusionEngine:
         pre = "fuser.blocks.0."
         ops.layernorm_bwd(w.d_fused, w.x3, w.mf, w.rf, a.p("fuser.norm.weight"), a.p("fuser.norm.bias"), w.d_x3,
                           a.g("fuser.norm.weight"), a.g("fuser.norm.bias"), pair_in=True, ws=ws)
-        ops.gemm(GEMM_TN, w.d_x3, w.f1, a.g(pre + "mlp.mlp.2.weight"), ws=ws)
-        ops.colsum(w.d_x3, a.g(pre + "mlp.mlp.2.bias"), ws=ws)
         ops.gemm(GEMM_NN, w.d_x3, a.p(pre + "mlp.mlp.2.weight"), w.d_u, aux=w.u, mul=2, ws=ws)
-        ops.gemm(GEMM_TN, w.d_u, w.h2, a.g(pre + "mlp.mlp.0.weight"), ws=ws)
-        ops.colsum(w.d_u, a.g(pre + "mlp.mlp.0.bias"), ws=ws)
-        ops.gemm(GEMM_NN, w.d_u, a.p(pre + "mlp.mlp.0.weight"), w.d_h, ws=ws)
-        ops.layernorm_bwd(w.d_h, w.x1, w.m2, w.r2, a.p(pre + "norm2.weight"), a.p(pre + "norm2.bias"), w.d_x1,
+        wgrad(w.d_x3, w.f1, a.g(pre + "mlp.mlp.2.weight"), a.g(pre + "mlp.mlp.2.bias"))
+        ops.gemm(GEMM_NN, w.d_u, a.p(pre + "mlp.mlp.0.weight"), w.d_h2, ws=ws)
+        wgrad(w.d_u, w.h2, a.g(pre + "mlp.mlp.0.weight"), a.g(pre + "mlp.mlp.0.bias"))
+        ops.layernorm_bwd(w.d_h2, w.x1, w.m2, w.r2, a.p(pre + "norm2.weight"), a.p(pre + "norm2.bias"), w.d_x1,
                           a.g(pre + "norm2.weight"), a.g(pre + "norm2.bias"), add1=w.d_x3, ws=ws)
-        ops.gemm(GEMM_TN, w.d_x1, w.vsw, a.g(pre + "attn.proj.weight"), ws=ws)
-        ops.colsum(w.d_x1, a.g(pre + "attn.proj.bias"), ws=ws)
         ops.gemm(GEMM_NN, w.d_x1, a.p(pre + "attn.proj.weight"), w.d_v, c_row_xor=1, ws=ws)     # un-swap
+        wgrad(w.d_x1, w.vsw, a.g(pre + "attn.proj.weight"), a.g(pre + "attn.proj.bias"))
         gqkv = a.g(pre + "attn.qkv.weight")                                   # rows [0,2H) (Q,K) stay exactly zero
-        ops.gemm(GEMM_TN, w.d_v, w.h1, gqkv[2 * H:], ws=ws)
-        ops.gemm(GEMM_NN, w.d_v, a.p(pre + "attn.qkv.weight")[2 * H:], w.d_h, ws=ws)
-        ops.layernorm_bwd(w.d_h, w.x0, w.m1, w.r1, a.p(pre + "norm1.weight"), a.p(pre + "norm1.bias"), w.d_x0,
+        ops.gemm(GEMM_NN, w.d_v, a.p(pre + "attn.qkv.weight")[2 * H:], w.d_h1, ws=ws)
+        wgrad(w.d_v, w.h1, gqkv[2 * H:], None)
+        ops.layernorm_bwd(w.d_h1, w.x0, w.m1, w.r1, a.p(pre + "norm1.weight"), a.p(pre + "norm1.bias"), w.d_x0,
                           a.g(pre + "norm1.weight"), a.g(pre + "norm1.bias"), add1=w.d_x1, add2=w.d_x3, ws=ws)
         mask = st["mask"]
         ops.token_exchange_bwd(w.d_x0, w.rgb, mask[0], mask[1], w.d_rgb_pre, w.d_dep, drop_mask=dmf("x0"), drop_scale=dsc)
         # ---- embeddings
-        ops.gemm(GEMM_TN, w.d_rgb_pre, st["x_rgb"], a.g("input_embed.weight"), ws=ws)
-        ops.colsum(w.d_rgb_pre, a.g("input_embed.bias"), ws=ws)
+        wgrad(w.d_rgb_pre, st["x_rgb"], a.g("input_embed.weight"), a.g("input_embed.bias"))
         ops.layernorm_bwd(w.d_dep, w.dep_pre, w.mean_d, w.rstd_d, a.p("depth_layernorm.weight"),
                           a.p("depth_layernorm.bias"), w.d_dep_pre, a.g("depth_layernorm.weight"),
                           a.g("depth_layernorm.bias"), relu=True, ws=ws)
         ops.colsum(w.d_dep_pre, a.g("depth_projection.bias"), ws=ws)
+        if side is not main:
+            main.wait_stream(side)
 
     # ------------------------------------------------------------------------------------------------------
     def adamw(self, lr, weight_decay, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):

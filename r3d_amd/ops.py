@@ -50,7 +50,7 @@ class GemmWorkspace:
 
 def gemm(layout, a, b, c, *, bias=None, act=0, pre_out=None, a_add=None, a_add_mod=0, a_row_xor=0,
          drop_mask=None, drop_scale=1.0, aux=None, mul=0, res1=None, res2=None, alpha=1.0, accumulate=False,
-         c_row_xor=0, ws=None, tile=0, splitk=0, defer_reduce=False):
+         c_row_xor=0, bias_grad=None, ws=None, tile=0, splitk=0, defer_reduce=False):
     """C = epilogue(A op B), see r3d_gemm_desc.  Shapes: NT a[M,K] b[N,K]; NN a[M,K] b[K,N]; TN a[K,M] b[K,N].
     Returns the (filled) descriptor; with defer_reduce=True and split-K the caller reduces the slabs itself
     (e.g. through layernorm_fwd(nsplit=...))."""
@@ -94,6 +94,9 @@ def gemm(layout, a, b, c, *, bias=None, act=0, pre_out=None, a_add=None, a_add_m
         d.res2, d.ldr2 = res2.data_ptr(), _ld(res2)
     d.alpha, d.accumulate = alpha, 1 if accumulate else 0
     d.c_row_xor = c_row_xor
+    if bias_grad is not None:
+        assert layout == GEMM_TN and bias_grad.numel() == M
+        d.bias_grad = bias_grad.data_ptr()
     check(lib.r3d_gemm_plan(C.byref(d)), "r3d_gemm_plan")
     if tile:
         d.tile = tile
@@ -105,6 +108,8 @@ def gemm(layout, a, b, c, *, bias=None, act=0, pre_out=None, a_add=None, a_add_m
             d.splitk, d.k_per_split = (K + kps - 1) // kps, kps
             if d.splitk < 2:
                 d.splitk, d.k_per_split = 1, K
+    if bias_grad is not None and d.splitk > 1:          # the fused column sum needs the whole K range in one block
+        d.splitk, d.k_per_split = 1, K
     if d.splitk > 1:
         assert ws is not None, "split-K needs a GemmWorkspace"
         d.partial = ws.get(lib.r3d_gemm_partial_floats(M, N, d.splitk)).data_ptr()
@@ -223,16 +228,19 @@ def mha_core_bwd(q, k, v, probs, d_o, dq, dk, dv, B, heads, Lq, Lk, dh, *, drop_
 # ----------------------------------------------------------------------------------------------------------
 def losses_fwd_bwd(seg, act, dur, ld_dur, past_label, target, target_dur, B, S, Q, K, pad_idx, exclude_idx, loss_out,
                    counts, *, val_mode=False, dur_den=None, grad_scale=1.0, d_seg=None, d_act=None, d_dur=None,
-                   ld_ddur=1):
+                   ld_ddur=1, ws=None):
     lib = _lib.load()
     assert past_label.dtype == torch.int64 and target.dtype == torch.int64 and target_dur.dtype == torch.float32
     assert past_label.is_contiguous() and target.is_contiguous() and target_dur.is_contiguous()
     assert counts.dtype == torch.int64 and loss_out.dtype == torch.float32
+    need = lib.r3d_losses_ws_floats(B, S, Q)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.float32, device=act.device)
     check(lib.r3d_losses_fwd_bwd(_p(seg), _ld(seg) if seg is not None else 0, _p(act), _ld(act), _p(dur), ld_dur,
                                  _p(past_label), _p(target), _p(target_dur), B, S, Q, K, pad_idx, exclude_idx,
                                  1 if val_mode else 0, _p(dur_den), grad_scale, _p(d_seg),
                                  _ld(d_seg) if d_seg is not None else 0, _p(d_act), _ld(d_act) if d_act is not None else 0,
-                                 _p(d_dur), ld_ddur, _p(loss_out), _p(counts), _stream()), "r3d_losses_fwd_bwd")
+                                 _p(d_dur), ld_ddur, _p(loss_out), _p(counts), _p(ws), _stream()), "r3d_losses_fwd_bwd")
 
 
 def adamw_flat(p, g, m, v, lr_t, step_t, *, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, grad_scale=1.0):

@@ -127,6 +127,17 @@ def test_gemm_c_row_xor_is_pair_swap(ops):
     assert_close(Cd.cpu(), ref, 1e-4, 1e-4, "c_row_xor")
 
 
+def test_gemm_tn_fused_bias_grad(ops):
+    for tile in (1, 2, 3):
+        Kc, M, N = 200, 70, 96                       # dW[M,N] = dY[Kc,M]^T . X[Kc,N];  db[M] = column sums of dY
+        dY, X = rnd(Kc, M, seed=1), rnd(Kc, N, seed=2)
+        dW, db = torch.empty(M, N, device="cuda"), torch.full((M,), float("nan"), device="cuda")
+        ops.gemm(2, dev(dY), dev(X), dW, bias_grad=db, tile=tile)
+        torch.cuda.synchronize()
+        assert_close(dW.cpu(), dY.double().t() @ X.double(), 1e-4, 1e-3, "dW")
+        assert_close(db.cpu(), dY.double().sum(0), 1e-4, 1e-4, "fused bias grad")
+
+
 def test_add_rowbcast(ops):
     x, add = rnd(24, 40, seed=1), rnd(8, 40, seed=2)
     out = torch.empty(24, 40, device="cuda")
