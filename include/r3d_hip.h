@@ -69,6 +69,7 @@ typedef struct r3d_gemm_desc {
     int32_t layout, M, N, K;
     int32_t lda, ldb, ldc;
     const float* a_add; int32_t a_add_mod, a_add_ld, a_row_xor;
+    const float* b_add; int32_t b_add_mod, b_add_ld;   /* NN/TN only: B'[k,:] = B[k,:] + b_add[k % mod,:] */
     const float* bias;
     float* pre_out; int32_t ldpre;
     int32_t act;
@@ -118,7 +119,10 @@ int r3d_layernorm_bwd(const float* dy, int lddy, int pair_in, const float* dy2, 
                       const float* rstd, const float* gamma, const float* beta, int relu, const float* add1, int ldadd1,
                       const float* add2, int ldadd2, float* dx, int lddx, float* dx2, int lddx2,
                       const uint8_t* drop_mask, int lddrop, float drop_scale, float* dgamma, float* dbeta, float* ws,
-                      int rows, int H, void* stream);
+                      int rows, int H, int defer_finalize, void* stream);
+/* With defer_finalize != 0 the reduction of the per-block partial dgamma/dbeta left in ws is done later by this call
+ * (so the host can take it off the critical path). */
+int r3d_layernorm_bwd_finalize(const float* ws, int rows, int H, float* dgamma, float* dbeta, void* stream);
 /* out[c] (+)= sum_r x[r,c]: bias gradients.  ws: r3d_colsum_ws_floats(rows, cols) floats. */
 int64_t r3d_colsum_ws_floats(int rows, int cols);
 int r3d_colsum(const float* x, int ld, int rows, int cols, float* out, float* ws, int accumulate, void* stream);

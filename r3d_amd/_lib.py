@@ -17,6 +17,7 @@ class GemmDesc(C.Structure):
         ("layout", C.c_int32), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
         ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32),
         ("a_add", C.c_void_p), ("a_add_mod", C.c_int32), ("a_add_ld", C.c_int32), ("a_row_xor", C.c_int32),
+        ("b_add", C.c_void_p), ("b_add_mod", C.c_int32), ("b_add_ld", C.c_int32),
         ("bias", C.c_void_p),
         ("pre_out", C.c_void_p), ("ldpre", C.c_int32),
         ("act", C.c_int32),
@@ -47,7 +48,8 @@ _SIGNATURES = {
     "r3d_layernorm_bwd_ws_floats": ([_I, _I], C.c_int64),
     "r3d_add_rowbcast": ([_P, _I, _P, _I, _I, _P, _I, _I, _I, _P], C.c_int),
     "r3d_layernorm_bwd": ([_P, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _F,
-                           _P, _P, _P, _I, _I, _P], C.c_int),
+                           _P, _P, _P, _I, _I, _I, _P], C.c_int),
+    "r3d_layernorm_bwd_finalize": ([_P, _I, _I, _P, _P, _P], C.c_int),
     "r3d_colsum_ws_floats": ([_I, _I], C.c_int64),
     "r3d_colsum": ([_P, _I, _I, _I, _P, _P, _I, _P], C.c_int),
     "r3d_rowmod_sum": ([_P, _I, _I, _I, _I, _P, _I, _I, _P], C.c_int),

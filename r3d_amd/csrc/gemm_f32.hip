@@ -42,6 +42,85 @@ __device__ __forceinline__ void gemm_epilogue(const r3d_gemm_desc& d, int m, int
     *c = v;
 }
 
+// Staged epilogue of one 32x32 accumulator tile held by a wave (see the kernel's comment).  mb already contains the
+// lane's 4*(lane>>5) row offset; n is this lane's column.
+__device__ __forceinline__ void gemm_epilogue_tile(const r3d_gemm_desc& d, const f32x16& acc, int mb, int n, int split) {
+    if (n >= d.N) return;
+    int m[16];
+    bool ok[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int mr = mb + (r & 3) + 8 * (r >> 2);
+        ok[r] = mr < d.M;
+        m[r] = mr ^ d.c_row_xor;
+    }
+    if (d.splitk > 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (ok[r]) d.partial[((size_t)split * d.M + (m[r] ^ d.c_row_xor)) * d.N + n] = acc[r];
+        return;
+    }
+    float v[16];
+    const float bias = d.bias ? d.bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = d.alpha * acc[r] + bias;
+    if (d.pre_out) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (ok[r]) d.pre_out[(size_t)m[r] * d.ldpre + n] = v[r];
+    }
+    if (d.act == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.0f);
+    } else if (d.act == 2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = gelu_f(v[r]);
+    }
+    if (d.drop_mask) {
+        float k[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) k[r] = ok[r] ? (float)d.drop_mask[(size_t)m[r] * d.lddrop + n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] *= d.drop_scale * k[r];
+    }
+    if (d.mul) {
+        float x[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = ok[r] ? d.aux[(size_t)m[r] * d.ldaux + n] : 0.f;
+        if (d.mul == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = (x[r] > 0.0f) ? v[r] : 0.0f;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] *= gelu_grad_f(x[r]);
+        }
+    }
+    if (d.res1) {
+        float x[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = ok[r] ? d.res1[(size_t)m[r] * d.ldr1 + n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] += x[r];
+    }
+    if (d.res2) {
+        float x[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = ok[r] ? d.res2[(size_t)m[r] * d.ldr2 + n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] += x[r];
+    }
+    if (d.accumulate) {
+        float x[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = ok[r] ? d.C[(size_t)m[r] * d.ldc + n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] += x[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        if (ok[r]) d.C[(size_t)m[r] * d.ldc + n] = v[r];
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // staging helpers
 // ---------------------------------------------------------------------------------------------------------
@@ -105,7 +184,7 @@ struct StageMC {
     static_assert(NLD >= 1 && (R * BK / 4) % NT == 0, "tile too small for the workgroup");
     float4 v[NLD];
     __device__ __forceinline__ void load(const float* __restrict__ base, int ld, int col0, int cols_total,
-                                         int k0, int k_end) {
+                                         int k0, int k_end, const float* add = nullptr, int add_mod = 1, int add_ld = 0) {
 #pragma unroll
         for (int p = 0; p < NLD; ++p) {
             const int f = threadIdx.x + p * NT;
@@ -121,6 +200,13 @@ struct StageMC {
                     if (c + 1 < cols_total) x.y = src[1];
                     if (c + 2 < cols_total) x.z = src[2];
                     if (c + 3 < cols_total) x.w = src[3];
+                }
+                if (add) {                       // B'[k, :] = B[k, :] + add[k % mod, :]
+                    const float* ad = add + (size_t)(k % add_mod) * add_ld + c;
+                    x.x += ad[0];
+                    if (c + 1 < cols_total) x.y += ad[1];
+                    if (c + 2 < cols_total) x.z += ad[2];
+                    if (c + 3 < cols_total) x.w += ad[3];
                 }
             }
             v[p] = x;
@@ -191,7 +277,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const r3d_gemm_d
         if (LA == 0) a_kc.load(d.A, d.lda, m0, d.M, k0, k_end, d);
         else a_mc.load(d.A, d.lda, m0, d.M, k0, k_end);
         if (LB == 0) b_kc.load(d.B, d.ldb, n0, d.N, k0, k_end, d);
-        else b_mc.load(d.B, d.ldb, n0, d.N, k0, k_end);
+        else b_mc.load(d.B, d.ldb, n0, d.N, k0, k_end, d.b_add, d.b_add_mod, d.b_add_ld);
     };
     auto store_tiles = [&](float* as, float* bs) {
         if (LA == 0) a_kc.store(as); else a_mc.store(as);
@@ -239,30 +325,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const r3d_gemm_d
         }
     }
 
-    // Epilogue through LDS: each wave parks one 32x32 accumulator tile in its own [32][33] LDS patch (C/D map of the
-    // 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)), then walks it row-major so the
-    // (long, fully optional) epilogue is a compact runtime loop with statically indexed accumulators.
-    static_assert(2 * (A_FLOATS + B_FLOATS) >= WM * WN * 32 * 33, "epilogue patch does not fit the staging LDS");
-    float* patch = smem + wave * (32 * 33);
+    // Epilogue straight from the accumulators.  C/D map of the 32x32 MFMA: col = lane & 31 (fixed per lane),
+    // row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).  Every optional operand is fetched in its own fully unrolled
+    // stage (16 independent loads in flight) -- an element-at-a-time epilogue serialises 16 memory round trips.
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            __syncthreads();                       // previous patch consumed / main-loop LDS reads finished
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                patch[((r & 3) + 8 * (r >> 2) + 4 * lhi) * 33 + l31] = acc[i][j][r];
-            __syncthreads();
-            const int mb = m0 + wm_off + i * 32, nb = n0 + wn_off + j * 32;
-            for (int e = lane; e < 1024; e += 64) {
-                const int m = mb + (e >> 5), n = nb + (e & 31);
-                if (m < d.M && n < d.N) {
-                    const float v = patch[(e >> 5) * 33 + (e & 31)];
-                    if (d.splitk > 1) d.partial[((size_t)split * d.M + m) * d.N + n] = v;
-                    else gemm_epilogue(d, m, n, v);
-                }
-            }
-        }
+        for (int j = 0; j < TN; ++j)
+            gemm_epilogue_tile(d, acc[i][j], m0 + wm_off + i * 32 + 4 * lhi, n0 + wn_off + j * 32 + l31, split);
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const r3d_gemm_desc d, int nsplit) {
@@ -351,6 +421,7 @@ static int gemm_validate(const r3d_gemm_desc* d) {
     if (d->lda < a_min || d->ldb < b_min || d->ldc < d->N) return R3D_EINVAL;
     if (d->layout == R3D_GEMM_TN && (d->a_add || d->a_row_xor)) return R3D_EINVAL;
     if (d->a_add && (d->a_add_mod <= 0 || d->a_add_ld < d->K)) return R3D_EINVAL;
+    if (d->b_add && (d->layout == R3D_GEMM_NT || d->b_add_mod <= 0 || d->b_add_ld < d->N)) return R3D_EINVAL;
     if ((d->a_row_xor || d->c_row_xor) && (d->M & 1)) return R3D_EINVAL;   // pair swap needs an even row count
     if (d->c_row_xor < 0 || d->c_row_xor > 1) return R3D_EINVAL;
     if (d->a_row_xor < 0 || d->a_row_xor > 1) return R3D_EINVAL;

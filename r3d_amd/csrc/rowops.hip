@@ -25,7 +25,18 @@ __device__ __forceinline__ void ln_fwd_row(const LnFwdArgs& a, int row, int lane
         float t = 0.f;
         if (c < a.H) {
             if (a.nsplit > 0) {
-                for (int p = 0; p < a.nsplit; ++p) t += a.x[((size_t)p * a.rows + row) * a.H + c];
+                // split-K slabs: 8 independent partial sums keep 8 loads in flight (a serial chain pays one
+                // memory round trip per slab)
+                const float* px = a.x + (size_t)row * a.H + c;
+                const size_t stride = (size_t)a.rows * a.H;
+                float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                int p = 0;
+                for (; p + 8 <= a.nsplit; p += 8) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) s8[q] += px[(size_t)(p + q) * stride];
+                }
+                for (; p < a.nsplit; ++p) s8[0] += px[(size_t)p * stride];
+                t = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
                 if (a.bias) t += a.bias[c];
                 if (a.pre_out) a.pre_out[(size_t)row * a.H + c] = t;
             } else {
@@ -272,7 +283,8 @@ R3D_EXPORT int r3d_layernorm_bwd(const float* dy, int lddy, int pair_in, const f
                                  const float* rstd, const float* gamma, const float* beta, int relu,
                                  const float* add1, int ldadd1, const float* add2, int ldadd2, float* dx, int lddx,
                                  float* dx2, int lddx2, const uint8_t* drop_mask, int lddrop, float drop_scale,
-                                 float* dgamma, float* dbeta, float* ws, int rows, int H, void* stream) {
+                                 float* dgamma, float* dbeta, float* ws, int rows, int H, int defer_finalize,
+                                 void* stream) {
     R3D_REQUIRE(dy && x && mean && rstd && gamma && beta && dx);
     R3D_REQUIRE(rows > 0 && H > 0 && H <= 2048 && ldx >= H && lddx >= H && lddy >= H);
     R3D_REQUIRE((dgamma == nullptr) == (dbeta == nullptr));
@@ -288,7 +300,7 @@ R3D_EXPORT int r3d_layernorm_bwd(const float* dy, int lddy, int pair_in, const f
     int rc = launch_epl(ln_bwd_kernel<32>, ln_bwd_kernel<16>, ln_bwd_kernel<8>, ln_bwd_kernel<2>, H, dim3(blocks),
                         shmem, s, a);
     if (rc != R3D_OK) return rc;
-    if (dgamma && blocks > 1) {
+    if (dgamma && blocks > 1 && !defer_finalize) {
         hipLaunchKernelGGL(ln_param_finalize_kernel, dim3(r3d_cdiv(2 * H, 64)), dim3(256), 0, s, ws, blocks, H,
                            dgamma, dbeta);
         R3D_LAUNCH_CHECK();
@@ -341,6 +353,19 @@ R3D_EXPORT int r3d_add_rowbcast(const float* x, int ldx, const float* add, int l
     const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
     hipLaunchKernelGGL(add_rowbcast_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, add, ldadd, mod, out,
                        ldo, rows, cols);
+    R3D_LAUNCH_CHECK();
+    return R3D_OK;
+}
+
+/* Second half of r3d_layernorm_bwd(..., defer_finalize=1): reduces the per-block partial parameter gradients left in
+ * ws.  Separate so the host can put it on a stream off the backward's critical path.  No-op when rows <= 4. */
+R3D_EXPORT int r3d_layernorm_bwd_finalize(const float* ws, int rows, int H, float* dgamma, float* dbeta, void* stream) {
+    R3D_REQUIRE(dgamma && dbeta && rows > 0 && H > 0 && H <= 2048);
+    const int blocks = r3d_cdiv(rows, ln_bwd_rows_per_block(rows));
+    if (blocks <= 1) return R3D_OK;
+    R3D_REQUIRE(ws);
+    hipLaunchKernelGGL(ln_param_finalize_kernel, dim3(r3d_cdiv(2 * H, 64)), dim3(256), 0, (hipStream_t)stream, ws, blocks, H,
+                       dgamma, dbeta);
     R3D_LAUNCH_CHECK();
     return R3D_OK;
 }

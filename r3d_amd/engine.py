@@ -111,12 +111,12 @@ class _Shape:
         self.u, self.f1 = f(2 * N, 4 * H), f(2 * N, 4 * H)
         self.x3, self.y = f(2 * N, H), f(2 * N, H)
         self.m1, self.r1, self.m2, self.r2, self.mf, self.rf = f(2 * N), f(2 * N), f(2 * N), f(2 * N), f(2 * N), f(2 * N)
-        self.fused, self.kv_in = f(N, H), f(N, H)
+        self.fused = f(N, H)
         self.tgt0 = torch.zeros(BQ, H, dtype=torch.float32, device=dev)
         self.layers = []
         for _ in range(L):
-            d = dict(sa_in=f(BQ, H), sa_qkv=f(BQ, 3 * H), sa_o=f(BQ, H), p_sa=f(B, heads, Q, Q), t1_pre=f(BQ, H),
-                     t1=f(BQ, H), m1=f(BQ), r1=f(BQ), caq_in=f(BQ, H), caq=f(BQ, H), cakv=f(N, 2 * H), ca_o=f(BQ, H),
+            d = dict(sa_qkv=f(BQ, 3 * H), sa_o=f(BQ, H), p_sa=f(B, heads, Q, Q), t1_pre=f(BQ, H),
+                     t1=f(BQ, H), m1=f(BQ), r1=f(BQ), caq=f(BQ, H), cakv=f(N, 2 * H), ca_o=f(BQ, H),
                      p_ca=f(B, heads, Q, S), t2_pre=f(BQ, H), t2=f(BQ, H), m2=f(BQ), r2=f(BQ), ff1=f(BQ, 4 * H),
                      t3_pre=f(BQ, H), t3=f(BQ, H), m3=f(BQ), r3=f(BQ))
             self.layers.append(d)
@@ -134,7 +134,11 @@ class _Shape:
             self.glayers = [dict(t3pre=f(BQ, H), ff2=f(BQ, H), ff1=f(BQ, 4 * H), t2=f(BQ, H), t2pre=f(BQ, H), cap=f(BQ, H),
                                  cao=f(BQ, H), caq=f(BQ, H), cakv=f(N, 2 * H), caqin=f(BQ, H), t1pre=f(BQ, H), sap=f(BQ, H),
                                  sao=f(BQ, H), saqkv=f(BQ, 3 * H), sain=f(BQ, H)) for _ in range(L)]
-            self.d_fused = f(N, H)
+            self.d_fused, self.d_fused2 = f(N, H), f(N, H)
+            lnw = lambda rows: f(max(ops.layernorm_bwd_ws_floats(rows, H), 4))       # noqa: E731
+            self.lnp = dict(final=lnw(BQ), nf=lnw(2 * N), n2=lnw(2 * N), n1=lnw(2 * N), dep=lnw(N))
+            for l in range(L):
+                self.lnp.update({f"d3_{l}": lnw(BQ), f"d2_{l}": lnw(BQ), f"d1_{l}": lnw(BQ)})
             self.d_x3, self.d_u, self.d_h1, self.d_h2, self.d_x1, self.d_v, self.d_x0 = (
                 f(2 * N, H), f(2 * N, 4 * H), f(2 * N, H), f(2 * N, H), f(2 * N, H), f(2 * N, H), f(2 * N, H))
             self.d_rgb_pre, self.d_dep, self.d_dep_pre = f(N, H), f(N, H), f(N, H)
@@ -167,6 +171,8 @@ class FusionEngine:
         self.ws = ops.GemmWorkspace(self.device)
         self.ws_side = ops.GemmWorkspace(self.device)
         self.side = torch.cuda.Stream(self.device)      # weight-gradient stream: off the backward's critical path
+        self.side2 = torch.cuda.Stream(self.device)     # independent branch (self-attention of the queries)
+        self.ws_side2 = ops.GemmWorkspace(self.device)
         self.use_side_stream = True
         self.shapes = {}
         self.train_mask = None            # cached train-mode selection (data independent)
@@ -230,17 +236,47 @@ class FusionEngine:
         if mode == "train":                     # get_pad_mask (:168,243-244) is evaluated inside the attention kernel
             assert labels.dtype == torch.int64 and labels.is_cuda and labels.is_contiguous()
             key_labels = labels
-        # ---- per-modality embeddings (:179-183, :194-197)
-        ops.gemm(GEMM_NT, x_rgb, a.p("input_embed.weight"), w.rgb, bias=a.p("input_embed.bias"), act=1, ws=self.ws)
+        main = torch.cuda.current_stream()
+        multi = self.use_side_stream
+        s1, s2 = (self.side, self.side2) if multi else (main, main)
+        ws1, ws2 = (self.ws_side, self.ws_side2) if multi else (self.ws, self.ws)
+        qpos = a.p("query_embed.weight")
+        pos = a.p("pos_embedding")[0, :S]
+
+        def sa_block(l, tgt_in, wsx):
+            """self-attention sub-layer of decoder layer l + the query projection of its cross-attention
+            (transformer.py:289-293,300); for layer 0 (tgt = 0) it depends on parameters only."""
+            c, pl = w.layers[l], f"transformer.decoder.layers.{l}."
+            ops.gemm(GEMM_NT, tgt_in, a.p(pl + "self_attn.in_proj_weight"), c["sa_qkv"], a_add=qpos, a_add_mod=Q,
+                     bias=a.p(pl + "self_attn.in_proj_bias"), ws=wsx)
+            ops.mha_core_fwd(c["sa_qkv"][:, :H], c["sa_qkv"][:, H:2 * H], c["sa_qkv"][:, 2 * H:], c["p_sa"], c["sa_o"], B,
+                             heads, Q, Q, dh, drop_mask=dm(f"sa_p{l}"), drop_scale=dsc)
+            ops.gemm(GEMM_NT, c["sa_o"], a.p(pl + "self_attn.out_proj.weight"), c["t1_pre"],
+                     bias=a.p(pl + "self_attn.out_proj.bias"), drop_mask=self._dm2(dm(f"d1_{l}"), BQ, H), drop_scale=dsc,
+                     res1=None if l == 0 else tgt_in, ws=wsx)                 # layer 0: tgt = 0 (:209)
+            ops.layernorm_fwd(c["t1_pre"], a.p(pl + "norm1.weight"), a.p(pl + "norm1.bias"), c["t1"], c["m1"], c["r1"])
+            wi, bi = a.p(pl + "multihead_attn.in_proj_weight"), a.p(pl + "multihead_attn.in_proj_bias")
+            ops.gemm(GEMM_NT, c["t1"], wi[:H], c["caq"], a_add=qpos, a_add_mod=Q, bias=bi[:H], ws=wsx)
+
+        # ---- branch s1: RGB embedding (:179-183);  branch s2: layer-0 query self-attention;  main: depth embedding
+        if multi:
+            s1.wait_stream(main)
+            s2.wait_stream(main)
+        with torch.cuda.stream(s1):
+            ops.gemm(GEMM_NT, x_rgb, a.p("input_embed.weight"), w.rgb, bias=a.p("input_embed.bias"), act=1, ws=ws1)
+        with torch.cuda.stream(s2):
+            sa_block(0, w.tgt0, ws2)
         d = ops.gemm(GEMM_NT, x_dep, a.p("depth_projection.weight"), w.dep_pre, bias=a.p("depth_projection.bias"),
-                     ws=self.ws, defer_reduce=True)
+                     ws=self.ws, defer_reduce=True)                              # (:194-195)
         if d.splitk > 1:
             ops.layernorm_fwd(self.ws.buf, a.p("depth_layernorm.weight"), a.p("depth_layernorm.bias"), w.dep, w.mean_d,
                               w.rstd_d, relu=True, nsplit=d.splitk, bias=a.p("depth_projection.bias"),
-                              pre_out=w.dep_pre, rows=N, H=H)
+                              pre_out=w.dep_pre, rows=N, H=H)                    # (:196-197)
         else:
             ops.layernorm_fwd(w.dep_pre, a.p("depth_layernorm.weight"), a.p("depth_layernorm.bias"), w.dep, w.mean_d,
                               w.rstd_d, relu=True)
+        if multi:
+            main.wait_stream(s1)
         # ---- token selection + exchange (:33-66)
         if mode == "train":
             idx, mask = self._train_masks(B, S)
@@ -266,26 +302,23 @@ class FusionEngine:
         ops.gemm(GEMM_NT, w.f1, a.p(pre + "mlp.mlp.2.weight"), w.x3, bias=a.p(pre + "mlp.mlp.2.bias"), res1=w.x1,
                  res2=w.x0, ws=self.ws)
         ops.layernorm_fwd(w.x3, a.p("fuser.norm.weight"), a.p("fuser.norm.bias"), w.y, w.mf, w.rf, pair_out=w.fused)
+        # ---- segmentation head on s1 (:228-232): only needs the fused features
+        if multi:
+            s1.wait_stream(main)
+        with torch.cuda.stream(s1):
+            ops.gemm(GEMM_NT, w.fused, a.p("fc_seg.weight"), w.seg, bias=a.p("fc_seg.bias"), ws=ws1)
         # ---- decoder (transformer.py:75-128,161-191,281-330); memory = fused, encoder bypassed (:77-78)
-        qpos = a.p("query_embed.weight")
-        pos = a.p("pos_embedding")[0, :S]
-        ops.add_rowbcast(w.fused, pos, S, w.kv_in)
         tgt = None
         for l in range(self.L):
             c, pl = w.layers[l], f"transformer.decoder.layers.{l}."
-            ops.add_rowbcast(tgt, qpos, Q, c["sa_in"])
-            ops.gemm(GEMM_NT, c["sa_in"], a.p(pl + "self_attn.in_proj_weight"), c["sa_qkv"],
-                     bias=a.p(pl + "self_attn.in_proj_bias"), ws=self.ws)
-            ops.mha_core_fwd(c["sa_qkv"][:, :H], c["sa_qkv"][:, H:2 * H], c["sa_qkv"][:, 2 * H:], c["p_sa"], c["sa_o"], B,
-                             heads, Q, Q, dh, drop_mask=dm(f"sa_p{l}"), drop_scale=dsc)
-            ops.gemm(GEMM_NT, c["sa_o"], a.p(pl + "self_attn.out_proj.weight"), c["t1_pre"],
-                     bias=a.p(pl + "self_attn.out_proj.bias"), drop_mask=self._dm2(dm(f"d1_{l}"), BQ, H), drop_scale=dsc,
-                     res1=tgt, ws=self.ws)                                  # layer 0: tgt = 0 (:209)
-            ops.layernorm_fwd(c["t1_pre"], a.p(pl + "norm1.weight"), a.p(pl + "norm1.bias"), c["t1"], c["m1"], c["r1"])
-            ops.add_rowbcast(c["t1"], qpos, Q, c["caq_in"])
             wi, bi = a.p(pl + "multihead_attn.in_proj_weight"), a.p(pl + "multihead_attn.in_proj_bias")
-            ops.gemm(GEMM_NT, c["caq_in"], wi[:H], c["caq"], bias=bi[:H], ws=self.ws)
-            ops.gemm(GEMM_NT, w.kv_in, wi[H:], c["cakv"], bias=bi[H:], ws=self.ws)
+            # key = value = memory + pos (:300-302): the broadcast add is the GEMM's A-operand prologue
+            ops.gemm(GEMM_NT, w.fused, wi[H:], c["cakv"], a_add=pos, a_add_mod=S, bias=bi[H:], ws=self.ws)
+            if l == 0:
+                if multi:
+                    main.wait_stream(s2)
+            else:
+                sa_block(l, tgt, self.ws)
             ops.mha_core_fwd(c["caq"], c["cakv"][:, :H], c["cakv"][:, H:], c["p_ca"], c["ca_o"], B, heads, Q, S, dh,
                              key_labels=key_labels, pad_idx=self.pad_idx, drop_mask=dm(f"ca_p{l}"), drop_scale=dsc)
             ops.gemm(GEMM_NT, c["ca_o"], a.p(pl + "multihead_attn.out_proj.weight"), c["t2_pre"],
@@ -300,9 +333,10 @@ class FusionEngine:
             tgt = c["t3"]
         ops.layernorm_fwd(tgt, a.p("transformer.decoder.norm.weight"), a.p("transformer.decoder.norm.bias"), w.tgtF,
                           w.mF, w.rF)
-        # ---- heads (:219-232)
+        # ---- anticipation heads (:219-226): fc and fc_len as one [K+1, H] GEMM
         ops.gemm(GEMM_NT, w.tgtF, self.w_head, w.actdur, bias=self.b_head, ws=self.ws)
-        ops.gemm(GEMM_NT, w.fused, a.p("fc_seg.weight"), w.seg, bias=a.p("fc_seg.bias"), ws=self.ws)
+        if multi:
+            main.wait_stream(s1)
         self.last = dict(w=w, x_rgb=x_rgb, x_dep=x_dep, mask=mask, idx=idx, drop=drop, mode=mode)
         return dict(seg=w.seg.view(B, S, K), action=w.actdur[:, :K].view(B, Q, K), duration=w.actdur[:, K].view(B, Q))
 
@@ -339,10 +373,13 @@ class FusionEngine:
         ops.gemm(GEMM_TN, st["w"].d_dep_pre, st["x_dep"], self.arena.g("depth_projection.weight"), ws=self.ws)
 
     def backward_main(self, d_seg=None, d_actdur=None):
-        """Everything of the backward except depth_projection.weight.  The chain of input gradients (the critical path)
-        runs on the current stream; every weight / bias gradient is enqueued on a second HIP stream as soon as its
-        operands exist and joins back before the function returns (also under hipGraph capture, where the two streams
-        become parallel branches of the graph)."""
+        """Everything of the backward except depth_projection.weight, on three HIP streams that fork from and join
+        back into the current stream (under hipGraph capture they become parallel branches of the graph):
+          main : the chain of input gradients that leads to the fuser and the embeddings (the critical path);
+          s2   : the self-attention sub-layer of the decoder queries -- it only feeds parameter gradients
+                 (and, for stacked decoders, the previous layer);
+          s1   : every weight / bias gradient, LayerNorm parameter reduction and broadcast-parameter sum, each
+                 enqueued as soon as its operands exist."""
         st = self.last
         w, a, H, Q, K, heads, dh, ws = st["w"], self.arena, self.H, self.Q, self.K, self.heads, self.dh, self.ws
         B, S, N, BQ = w.B, w.S, w.N, w.BQ
@@ -353,21 +390,28 @@ class FusionEngine:
         dm = (lambda k, r, c: w.drop[k].view(r, c)) if drop else (lambda k, r, c: None)
         dmf = (lambda k: w.drop[k]) if drop else (lambda k: None)
         main = torch.cuda.current_stream()
-        side = self.side if self.use_side_stream else main
-        wss = self.ws_side if self.use_side_stream else ws
+        multi = self.use_side_stream
+        s1, s2 = (self.side, self.side2) if multi else (main, main)
+        ws1, ws2 = (self.ws_side, self.ws_side2) if multi else (ws, ws)
+        qpos = a.p("query_embed.weight")
+        pos = a.p("pos_embedding")[0, :S]
 
-        def wgrad(dy, x, gw, gb):
-            """gw = dy^T . x  (+ gb = column sums of dy, fused into the same launch) on the side stream"""
-            if side is not main:
-                side.wait_stream(main)
-            with torch.cuda.stream(side):
-                ops.gemm(GEMM_TN, dy, x, gw, bias_grad=gb, ws=wss)
-
-        def on_side(fn):
-            if side is not main:
-                side.wait_stream(main)
-            with torch.cuda.stream(side):
+        def on_s1(fn, after=None):
+            if multi:
+                s1.wait_stream(after if after is not None else torch.cuda.current_stream())
+            with torch.cuda.stream(s1):
                 fn()
+
+        def wgrad(dy, x, gw, gb, after=None, b_add=None, b_mod=0):
+            """gw = dy^T . (x [+ broadcast add]), gb = column sums of dy (fused into the same launch), on s1"""
+            on_s1(lambda: ops.gemm(GEMM_TN, dy, x, gw, bias_grad=gb, b_add=b_add, b_add_mod=b_mod, ws=ws1), after)
+
+        def ln_bwd(site, dy, x, mean, rstd, gname, bname, dx, rows, **kw):
+            """dx on the current stream; the parameter-gradient reduction of this LayerNorm site on s1"""
+            cur = torch.cuda.current_stream()
+            ops.layernorm_bwd(dy, x, mean, rstd, a.p(gname), a.p(bname), dx, a.g(gname), a.g(bname), partial=w.lnp[site],
+                              **kw)
+            on_s1(lambda: ops.layernorm_bwd_finalize(w.lnp[site], rows, H, a.g(gname), a.g(bname)), cur)
 
         # ---- heads
         ops.gemm(GEMM_NN, d_actdur, self.w_head, w.d_tgtF, ws=ws)
@@ -375,9 +419,8 @@ class FusionEngine:
         wgrad(d_seg, w.fused, a.g("fc_seg.weight"), a.g("fc_seg.bias"))
         # ---- decoder
         last = w.layers[-1]
-        ops.layernorm_bwd(w.d_tgtF, last["t3"], w.mF, w.rF, a.p("transformer.decoder.norm.weight"),
-                          a.p("transformer.decoder.norm.bias"), w.d_t, a.g("transformer.decoder.norm.weight"),
-                          a.g("transformer.decoder.norm.bias"), ws=ws)
+        ln_bwd("final", w.d_tgtF, last["t3"], w.mF, w.rF, "transformer.decoder.norm.weight",
+               "transformer.decoder.norm.bias", w.d_t, BQ)
         dy, dy2 = w.d_t, None                 # gradient w.r.t. t3 of the current layer (= dy + dy2)
         g_qe = a.g("query_embed.weight")
         first_qe, first_fused = True, True
@@ -385,19 +428,18 @@ class FusionEngine:
             c, gl, pl = w.layers[l], w.glayers[l], f"transformer.decoder.layers.{l}."
             g = lambda n: a.g(pl + n)         # noqa: E731
             p = lambda n: a.p(pl + n)         # noqa: E731
+            tgt_in = w.tgt0 if l == 0 else w.layers[l - 1]["t3"]
             # norm3 -> (t2 residual, FFN)
-            ops.layernorm_bwd(dy, c["t3_pre"], c["m3"], c["r3"], p("norm3.weight"), p("norm3.bias"), gl["t3pre"],
-                              g("norm3.weight"), g("norm3.bias"), dy2=dy2, dx2=gl["ff2"], drop_mask=dm(f"d3_{l}", BQ, H),
-                              drop_scale=dsc, ws=ws)
+            ln_bwd(f"d3_{l}", dy, c["t3_pre"], c["m3"], c["r3"], pl + "norm3.weight", pl + "norm3.bias", gl["t3pre"], BQ,
+                   dy2=dy2, dx2=gl["ff2"], drop_mask=dm(f"d3_{l}", BQ, H), drop_scale=dsc)
             ops.gemm(GEMM_NN, gl["ff2"], p("linear2.weight"), gl["ff1"], drop_mask=dm(f"ff_{l}", BQ, 4 * H),
                      drop_scale=dsc, aux=c["ff1"], mul=1, ws=ws)
             wgrad(gl["ff2"], c["ff1"], g("linear2.weight"), g("linear2.bias"))
             ops.gemm(GEMM_NN, gl["ff1"], p("linear1.weight"), gl["t2"], res1=gl["t3pre"], ws=ws)
             wgrad(gl["ff1"], c["t2"], g("linear1.weight"), g("linear1.bias"))
             # norm2 -> (t1 residual, cross attention)
-            ops.layernorm_bwd(gl["t2"], c["t2_pre"], c["m2"], c["r2"], p("norm2.weight"), p("norm2.bias"), gl["t2pre"],
-                              g("norm2.weight"), g("norm2.bias"), dx2=gl["cap"], drop_mask=dm(f"d2_{l}", BQ, H),
-                              drop_scale=dsc, ws=ws)
+            ln_bwd(f"d2_{l}", gl["t2"], c["t2_pre"], c["m2"], c["r2"], pl + "norm2.weight", pl + "norm2.bias", gl["t2pre"],
+                   BQ, dx2=gl["cap"], drop_mask=dm(f"d2_{l}", BQ, H), drop_scale=dsc)
             ops.gemm(GEMM_NN, gl["cap"], p("multihead_attn.out_proj.weight"), gl["cao"], ws=ws)
             wgrad(gl["cap"], c["ca_o"], g("multihead_attn.out_proj.weight"), g("multihead_attn.out_proj.bias"))
             ops.mha_core_bwd(c["caq"], c["cakv"][:, :H], c["cakv"][:, H:], c["p_ca"], gl["cao"], gl["caq"],
@@ -405,57 +447,63 @@ class FusionEngine:
                              drop_scale=dsc)
             wi = p("multihead_attn.in_proj_weight")
             gwi, gbi = g("multihead_attn.in_proj_weight"), g("multihead_attn.in_proj_bias")
-            ops.gemm(GEMM_NN, gl["caq"], wi[:H], gl["caqin"], ws=ws)
-            wgrad(gl["caq"], c["caq_in"], gwi[:H], gbi[:H])
-            wgrad(gl["cakv"], w.kv_in, gwi[H:], gbi[H:])
-            ops.gemm(GEMM_NN, gl["cakv"], wi[H:], w.d_fused, accumulate=not first_fused, ws=ws)   # d kv_in
+            ops.gemm(GEMM_NN, gl["cakv"], wi[H:], w.d_fused, accumulate=not first_fused, ws=ws)   # d (memory + pos)
             first_fused = False
-            acc_qe = not first_qe
-            on_side(lambda gl=gl, acc_qe=acc_qe: ops.rowmod_sum(gl["caqin"], Q, g_qe, accumulate=acc_qe))
-            first_qe = False
-            # norm1 -> (tgt residual, self attention);  d t1 = caqin (query path) + t2pre (residual into t2_pre)
-            ops.layernorm_bwd(gl["caqin"], c["t1_pre"], c["m1"], c["r1"], p("norm1.weight"), p("norm1.bias"), gl["t1pre"],
-                              g("norm1.weight"), g("norm1.bias"), dy2=gl["t2pre"], dx2=gl["sap"],
-                              drop_mask=dm(f"d1_{l}", BQ, H), drop_scale=dsc, ws=ws)
-            ops.gemm(GEMM_NN, gl["sap"], p("self_attn.out_proj.weight"), gl["sao"], ws=ws)
-            wgrad(gl["sap"], c["sa_o"], g("self_attn.out_proj.weight"), g("self_attn.out_proj.bias"))
-            ops.mha_core_bwd(c["sa_qkv"][:, :H], c["sa_qkv"][:, H:2 * H], c["sa_qkv"][:, 2 * H:], c["p_sa"], gl["sao"],
-                             gl["saqkv"][:, :H], gl["saqkv"][:, H:2 * H], gl["saqkv"][:, 2 * H:], B, heads, Q, Q, dh,
-                             drop_mask=dmf(f"sa_p{l}"), drop_scale=dsc)
-            ops.gemm(GEMM_NN, gl["saqkv"], p("self_attn.in_proj_weight"), gl["sain"], ws=ws)
-            wgrad(gl["saqkv"], c["sa_in"], g("self_attn.in_proj_weight"), g("self_attn.in_proj_bias"))
-            on_side(lambda gl=gl: ops.rowmod_sum(gl["sain"], Q, g_qe, accumulate=True))
-            dy, dy2 = gl["sain"], gl["t1pre"]  # d t3 of layer l-1 = sain (through sa_in) + t1pre (residual into t1_pre)
-        # ---- positional embedding gradient: sum over clips of d kv_in, before the seg head joins d_fused (:190)
-        ops.rowmod_sum(w.d_fused, S, a.g("pos_embedding")[0, :S])
-        ops.gemm(GEMM_NN, d_seg, a.p("fc_seg.weight"), w.d_fused, accumulate=True, ws=ws)
+            wgrad(gl["cakv"], w.fused, gwi[H:], gbi[H:], b_add=pos, b_mod=S)
+            wgrad(gl["caq"], c["t1"], gwi[:H], gbi[:H], b_add=qpos, b_mod=Q)
+            # ---- branch s2: query path of the cross attention + the self-attention sub-layer
+            if multi:
+                s2.wait_stream(main)
+            with torch.cuda.stream(s2):
+                ops.gemm(GEMM_NN, gl["caq"], wi[:H], gl["caqin"], ws=ws2)
+                acc_qe = not first_qe
+                on_s1(lambda gl=gl, acc_qe=acc_qe: ops.rowmod_sum(gl["caqin"], Q, g_qe, accumulate=acc_qe), s2)
+                first_qe = False
+                # norm1: d t1 = caqin (query path) + t2pre (residual into t2_pre)
+                ln_bwd(f"d1_{l}", gl["caqin"], c["t1_pre"], c["m1"], c["r1"], pl + "norm1.weight", pl + "norm1.bias",
+                       gl["t1pre"], BQ, dy2=gl["t2pre"], dx2=gl["sap"], drop_mask=dm(f"d1_{l}", BQ, H), drop_scale=dsc)
+                ops.gemm(GEMM_NN, gl["sap"], p("self_attn.out_proj.weight"), gl["sao"], ws=ws2)
+                wgrad(gl["sap"], c["sa_o"], g("self_attn.out_proj.weight"), g("self_attn.out_proj.bias"), after=s2)
+                ops.mha_core_bwd(c["sa_qkv"][:, :H], c["sa_qkv"][:, H:2 * H], c["sa_qkv"][:, 2 * H:], c["p_sa"], gl["sao"],
+                                 gl["saqkv"][:, :H], gl["saqkv"][:, H:2 * H], gl["saqkv"][:, 2 * H:], B, heads, Q, Q, dh,
+                                 drop_mask=dmf(f"sa_p{l}"), drop_scale=dsc)
+                ops.gemm(GEMM_NN, gl["saqkv"], p("self_attn.in_proj_weight"), gl["sain"], ws=ws2)
+                wgrad(gl["saqkv"], tgt_in, g("self_attn.in_proj_weight"), g("self_attn.in_proj_bias"), after=s2,
+                      b_add=qpos, b_mod=Q)
+                on_s1(lambda gl=gl: ops.rowmod_sum(gl["sain"], Q, g_qe, accumulate=True), s2)
+            if l > 0:                          # d t3 of layer l-1 = sain (through the queries) + t1pre (residual)
+                if multi:
+                    main.wait_stream(s2)
+                dy, dy2 = gl["sain"], gl["t1pre"]
+        # ---- positional embedding gradient: sum over clips of d(memory+pos), before the seg head joins d_fused (:190)
+        on_s1(lambda: ops.rowmod_sum(w.d_fused, S, a.g("pos_embedding")[0, :S]))
+        d_fz = w.d_fused2
+        ops.gemm(GEMM_NN, d_seg, a.p("fc_seg.weight"), d_fz, res1=w.d_fused, ws=ws)
         # ---- fuser
         pre = "fuser.blocks.0."
-        ops.layernorm_bwd(w.d_fused, w.x3, w.mf, w.rf, a.p("fuser.norm.weight"), a.p("fuser.norm.bias"), w.d_x3,
-                          a.g("fuser.norm.weight"), a.g("fuser.norm.bias"), pair_in=True, ws=ws)
+        ln_bwd("nf", d_fz, w.x3, w.mf, w.rf, "fuser.norm.weight", "fuser.norm.bias", w.d_x3, 2 * N, pair_in=True)
         ops.gemm(GEMM_NN, w.d_x3, a.p(pre + "mlp.mlp.2.weight"), w.d_u, aux=w.u, mul=2, ws=ws)
         wgrad(w.d_x3, w.f1, a.g(pre + "mlp.mlp.2.weight"), a.g(pre + "mlp.mlp.2.bias"))
         ops.gemm(GEMM_NN, w.d_u, a.p(pre + "mlp.mlp.0.weight"), w.d_h2, ws=ws)
         wgrad(w.d_u, w.h2, a.g(pre + "mlp.mlp.0.weight"), a.g(pre + "mlp.mlp.0.bias"))
-        ops.layernorm_bwd(w.d_h2, w.x1, w.m2, w.r2, a.p(pre + "norm2.weight"), a.p(pre + "norm2.bias"), w.d_x1,
-                          a.g(pre + "norm2.weight"), a.g(pre + "norm2.bias"), add1=w.d_x3, ws=ws)
+        ln_bwd("n2", w.d_h2, w.x1, w.m2, w.r2, pre + "norm2.weight", pre + "norm2.bias", w.d_x1, 2 * N, add1=w.d_x3)
         ops.gemm(GEMM_NN, w.d_x1, a.p(pre + "attn.proj.weight"), w.d_v, c_row_xor=1, ws=ws)     # un-swap
         wgrad(w.d_x1, w.vsw, a.g(pre + "attn.proj.weight"), a.g(pre + "attn.proj.bias"))
         gqkv = a.g(pre + "attn.qkv.weight")                                   # rows [0,2H) (Q,K) stay exactly zero
         ops.gemm(GEMM_NN, w.d_v, a.p(pre + "attn.qkv.weight")[2 * H:], w.d_h1, ws=ws)
         wgrad(w.d_v, w.h1, gqkv[2 * H:], None)
-        ops.layernorm_bwd(w.d_h1, w.x0, w.m1, w.r1, a.p(pre + "norm1.weight"), a.p(pre + "norm1.bias"), w.d_x0,
-                          a.g(pre + "norm1.weight"), a.g(pre + "norm1.bias"), add1=w.d_x1, add2=w.d_x3, ws=ws)
+        ln_bwd("n1", w.d_h1, w.x0, w.m1, w.r1, pre + "norm1.weight", pre + "norm1.bias", w.d_x0, 2 * N, add1=w.d_x1,
+               add2=w.d_x3)
         mask = st["mask"]
         ops.token_exchange_bwd(w.d_x0, w.rgb, mask[0], mask[1], w.d_rgb_pre, w.d_dep, drop_mask=dmf("x0"), drop_scale=dsc)
         # ---- embeddings
         wgrad(w.d_rgb_pre, st["x_rgb"], a.g("input_embed.weight"), a.g("input_embed.bias"))
-        ops.layernorm_bwd(w.d_dep, w.dep_pre, w.mean_d, w.rstd_d, a.p("depth_layernorm.weight"),
-                          a.p("depth_layernorm.bias"), w.d_dep_pre, a.g("depth_layernorm.weight"),
-                          a.g("depth_layernorm.bias"), relu=True, ws=ws)
-        ops.colsum(w.d_dep_pre, a.g("depth_projection.bias"), ws=ws)
-        if side is not main:
-            main.wait_stream(side)
+        ln_bwd("dep", w.d_dep, w.dep_pre, w.mean_d, w.rstd_d, "depth_layernorm.weight", "depth_layernorm.bias",
+               w.d_dep_pre, N, relu=True)
+        on_s1(lambda: ops.colsum(w.d_dep_pre, a.g("depth_projection.bias"), ws=ws1))
+        if multi:
+            main.wait_stream(s2)
+            main.wait_stream(s1)
 
     # ------------------------------------------------------------------------------------------------------
     def adamw(self, lr, weight_decay, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):

@@ -48,7 +48,7 @@ class GemmWorkspace:
         return self.buf
 
 
-def gemm(layout, a, b, c, *, bias=None, act=0, pre_out=None, a_add=None, a_add_mod=0, a_row_xor=0,
+def gemm(layout, a, b, c, *, bias=None, act=0, pre_out=None, a_add=None, a_add_mod=0, a_row_xor=0, b_add=None, b_add_mod=0,
          drop_mask=None, drop_scale=1.0, aux=None, mul=0, res1=None, res2=None, alpha=1.0, accumulate=False,
          c_row_xor=0, bias_grad=None, ws=None, tile=0, splitk=0, defer_reduce=False):
     """C = epilogue(A op B), see r3d_gemm_desc.  Shapes: NT a[M,K] b[N,K]; NN a[M,K] b[K,N]; TN a[K,M] b[K,N].
@@ -76,6 +76,8 @@ def gemm(layout, a, b, c, *, bias=None, act=0, pre_out=None, a_add=None, a_add_m
     if a_add is not None:
         d.a_add, d.a_add_mod, d.a_add_ld = a_add.data_ptr(), a_add_mod, _ld(a_add)
     d.a_row_xor = a_row_xor
+    if b_add is not None:
+        d.b_add, d.b_add_mod, d.b_add_ld = b_add.data_ptr(), b_add_mod, _ld(b_add)
     if bias is not None:
         assert bias.numel() == N
         d.bias = bias.data_ptr()
@@ -137,17 +139,32 @@ def layernorm_fwd(x, gamma, beta, y, mean, rstd, *, relu=False, pair_out=None, n
 
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, beta, dx, dgamma, dbeta, *, pair_in=False, relu=False, dy2=None, add1=None, add2=None,
-                  dx2=None, drop_mask=None, drop_scale=1.0, ws=None):
+                  dx2=None, drop_mask=None, drop_scale=1.0, ws=None, partial=None):
+    """partial: a dedicated [ws_floats] tensor -> the parameter-gradient reduction is deferred to
+    layernorm_bwd_finalize(partial, ...) (which may run on another stream)."""
     lib = _lib.load()
     rows, H = x.shape
     need = lib.r3d_layernorm_bwd_ws_floats(rows, H)
-    wsb = ws.get(need) if (need > 0 and dgamma is not None) else None
+    if partial is not None:
+        assert partial.numel() >= need
+        wsb = partial
+    else:
+        wsb = ws.get(need) if (need > 0 and dgamma is not None) else None
     check(lib.r3d_layernorm_bwd(_p(dy), _ld(dy), 1 if pair_in else 0, _p(dy2), _ld(dy2) if dy2 is not None else 0, _p(x), _ld(x), _p(mean), _p(rstd), _p(gamma), _p(beta),
                                 1 if relu else 0, _p(add1), _ld(add1) if add1 is not None else 0, _p(add2),
                                 _ld(add2) if add2 is not None else 0, _p(dx), _ld(dx), _p(dx2),
                                 _ld(dx2) if dx2 is not None else 0, _p(drop_mask),
                                 _ld(drop_mask) if drop_mask is not None else 0, drop_scale, _p(dgamma), _p(dbeta),
-                                _p(wsb), rows, H, _stream()), "r3d_layernorm_bwd")
+                                _p(wsb), rows, H, 1 if partial is not None else 0, _stream()), "r3d_layernorm_bwd")
+
+
+def layernorm_bwd_finalize(partial, rows, H, dgamma, dbeta):
+    lib = _lib.load()
+    check(lib.r3d_layernorm_bwd_finalize(_p(partial), rows, H, _p(dgamma), _p(dbeta), _stream()), "r3d_layernorm_bwd_finalize")
+
+
+def layernorm_bwd_ws_floats(rows, H):
+    return int(_lib.load().r3d_layernorm_bwd_ws_floats(rows, H))
 
 
 def add_rowbcast(x, add, mod, out):

@@ -136,6 +136,11 @@ def test_gemm_tn_fused_bias_grad(ops):
         torch.cuda.synchronize()
         assert_close(dW.cpu(), dY.double().t() @ X.double(), 1e-4, 1e-3, "dW")
         assert_close(db.cpu(), dY.double().sum(0), 1e-4, 1e-4, "fused bias grad")
+        add = rnd(8, N, seed=3)                      # B'[k,:] = X[k,:] + add[k % 8,:]  (with_pos_embed on the wgrad operand)
+        ops.gemm(2, dev(dY), dev(X), dW, b_add=dev(add), b_add_mod=8, tile=tile)
+        torch.cuda.synchronize()
+        Xp = X.double() + add.double()[torch.arange(Kc) % 8]
+        assert_close(dW.cpu(), dY.double().t() @ Xp, 1e-4, 1e-3, "dW with b_add")
 
 
 def test_add_rowbcast(ops):
