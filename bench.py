@@ -119,6 +119,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="enqueue every step from Python instead of replaying hipGraphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eval-dropout-off", action="store_true", help="bench the eval()-state step (dropout off)")
+    ap.add_argument("--no-side-stream", action="store_true", help="keep the query self-attention branch on the main stream")
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -136,6 +137,7 @@ def main():
     if a.eval_dropout_off:
         model.eval()
     eng = model.engine()
+    eng.use_side_stream = not a.no_side_stream
     from r3d_amd.parallel import DataParallelStep
     dp = DataParallelStep(eng) if world > 1 else None
     if dp is not None:

@@ -83,6 +83,7 @@ typedef struct r3d_gemm_desc {
     int32_t c_row_xor;       /* output (and pre_out/aux/res/drop operand) row index = m ^ c_row_xor: pair swap at store */
     int32_t splitk, k_per_split; float* partial;
     int32_t tile;            /* 0 = auto; 1 = 32x32, 2 = 64x64, 3 = 128x128 workgroup tile (testing / tuning) */
+    int32_t vec;             /* filled by the library: operands allow 16-byte loads */
 } r3d_gemm_desc;
 
 int r3d_gemm_f32(const r3d_gemm_desc* d, void* stream);
@@ -92,6 +93,13 @@ int r3d_splitk_reduce(const r3d_gemm_desc* d, void* stream);
 int64_t r3d_gemm_partial_floats(int32_t M, int32_t N, int32_t splitk);
 /* Heuristic the host uses to pick (tile, splitk, k_per_split) for a shape on a 256-CU part; fills the desc. */
 int r3d_gemm_plan(r3d_gemm_desc* d);
+/* Grouped launch: n independent problems of one layout in ONE kernel (all weight gradients of a step; each is
+ * latency-bound, so the ~5 us per-launch floor dominates, not the FLOPs).  prepare() (host only) validates the
+ * descriptors, fills tile/vec and prefix[0..n] (first workgroup of each problem; prefix[n] = grid size); the caller
+ * copies both arrays to device memory once per shape and calls launch() every step. */
+int r3d_gemm_grouped_prepare(r3d_gemm_desc* descs, int n, int tile, int32_t* prefix);
+int r3d_gemm_grouped_launch(const r3d_gemm_desc* dev_descs, const int32_t* dev_prefix, int n, int total_tiles, int layout,
+                            int tile, void* stream);
 
 /* ---- row-wise kernels ---------------------------------------------------------------------------------------
  * LayerNorm (eps 1e-5, biased variance, affine): depth_layernorm (model/futr_safuser_tokenfusion.py:147,196),
@@ -123,6 +131,9 @@ int r3d_layernorm_bwd(const float* dy, int lddy, int pair_in, const float* dy2, 
 /* With defer_finalize != 0 the reduction of the per-block partial dgamma/dbeta left in ws is done later by this call
  * (so the host can take it off the critical path). */
 int r3d_layernorm_bwd_finalize(const float* ws, int rows, int H, float* dgamma, float* dbeta, void* stream);
+/* The same for many LayerNorm sites in one launch; jobs live in device memory. */
+typedef struct r3d_ln_finalize_job { const float* ws; float* dgamma; float* dbeta; int32_t rows, H; } r3d_ln_finalize_job;
+int r3d_layernorm_bwd_finalize_batched(const r3d_ln_finalize_job* dev_jobs, int njobs, int max_H, void* stream);
 /* out[c] (+)= sum_r x[r,c]: bias gradients.  ws: r3d_colsum_ws_floats(rows, cols) floats. */
 int64_t r3d_colsum_ws_floats(int rows, int cols);
 int r3d_colsum(const float* x, int ld, int rows, int cols, float* out, float* ws, int accumulate, void* stream);

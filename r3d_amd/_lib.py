@@ -30,7 +30,13 @@ class GemmDesc(C.Structure):
         ("c_row_xor", C.c_int32),
         ("splitk", C.c_int32), ("k_per_split", C.c_int32), ("partial", C.c_void_p),
         ("tile", C.c_int32),
+        ("vec", C.c_int32),
     ]
+
+
+class LnFinalizeJob(C.Structure):
+    """struct r3d_ln_finalize_job"""
+    _fields_ = [("ws", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("rows", C.c_int32), ("H", C.c_int32)]
 
 
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
@@ -44,6 +50,9 @@ _SIGNATURES = {
     "r3d_splitk_reduce": ([C.POINTER(GemmDesc), _P], C.c_int),
     "r3d_gemm_partial_floats": ([C.c_int32, C.c_int32, C.c_int32], C.c_int64),
     "r3d_gemm_plan": ([C.POINTER(GemmDesc)], C.c_int),
+    "r3d_gemm_grouped_prepare": ([C.POINTER(GemmDesc), _I, _I, C.POINTER(C.c_int32)], C.c_int),
+    "r3d_gemm_grouped_launch": ([_P, _P, _I, _I, _I, _I, _P], C.c_int),
+    "r3d_layernorm_bwd_finalize_batched": ([_P, _I, _I, _P], C.c_int),
     "r3d_layernorm_fwd": ([_P, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P], C.c_int),
     "r3d_layernorm_bwd_ws_floats": ([_I, _I], C.c_int64),
     "r3d_add_rowbcast": ([_P, _I, _P, _I, _I, _P, _I, _I, _I, _P], C.c_int),

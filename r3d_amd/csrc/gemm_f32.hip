@@ -4,15 +4,20 @@
 // bf16 inputs cannot hold the 1e-3 parity budget there, and gfx950 has no TF32/xf32.  v_mfma_f32_32x32x2_f32 is an
 // exact fp32 fma chain at the f32 vector peak (157 TFLOP/s) with 1 operand VGPR per lane per 4096 FLOP.
 //
-// Tile scheme (per workgroup):  BM x BN output, BK = 16 k per step, waves laid out WM x WN, each wave owning
+// Tile scheme (per workgroup):  BM x BN output, BK k per step, waves laid out WM x WN, each wave owning
 // (BM/WM) x (BN/WN) as 32x32 MFMA tiles.  Both operands are staged into LDS K-MAJOR ([k][m] and [k][n]); an MFMA
 // fragment read is then 32 consecutive floats per half-wave (ds_read_b32, conflict-free) whatever the global layout:
 //   - a K-contiguous global operand (nn.Linear weights / activations in NT) is loaded as float4 along k and
-//     transposed by 4 ds_write_b32 (row stride = tile+2 floats -> conflict-free writes);
+//     transposed by 4 ds_write_b32 (row stride = tile+2 floats);
 //   - an M/N-contiguous operand (NN's B, TN's A and B) is copied with float4 loads + ds_write_b128 (stride tile+4).
-// Global loads for step t+1 are issued before the MFMAs of step t (register prefetch, double-buffered LDS, one
-// barrier per step).  Out-of-range rows / columns / k are zero-filled, so any M, N, K works; the float4 path needs
-// 16-byte aligned bases and leading dimensions that are multiples of 4, otherwise a scalar-load twin is used.
+// Software pipeline: global loads run TWO k-steps ahead of the MFMAs in two named register stages (the step is
+// latency-bound: a 64-deep step is ~1 us of MFMA against ~2 us of HBM latency), LDS is double-buffered, one
+// barrier per step.  Out-of-range rows / columns / k are zero-filled, so any M, N, K works; the float4 path needs
+// 16-byte aligned bases and leading dimensions that are multiples of 4 (d.vec, decided on the host), otherwise
+// element loads are used.
+// The epilogue runs straight from the accumulators in per-operand stages (16 independent loads in flight each).
+// gemm_grouped_kernel runs many independent problems of one layout/tile in ONE launch (all weight gradients of the
+// step): the per-kernel floor of ~5 us dominates these latency-bound problems, not their FLOPs.
 #include "common.h"
 #include "../../include/r3d_hip.h"
 
@@ -20,10 +25,8 @@ namespace r3d {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK_MIN = 16;       // split-K slab granularity
-
 // ---------------------------------------------------------------------------------------------------------
-// epilogue shared by the GEMM kernel and the split-K reducer
+// element-wise epilogue (split-K reducer)
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void gemm_epilogue(const r3d_gemm_desc& d, int m, int n, float acc) {
     m ^= d.c_row_xor;
@@ -42,8 +45,8 @@ __device__ __forceinline__ void gemm_epilogue(const r3d_gemm_desc& d, int m, int
     *c = v;
 }
 
-// Staged epilogue of one 32x32 accumulator tile held by a wave (see the kernel's comment).  mb already contains the
-// lane's 4*(lane>>5) row offset; n is this lane's column.
+// Staged epilogue of one 32x32 accumulator tile held by a wave.  C/D map of the 32x32 MFMA: col = lane & 31 (fixed
+// per lane), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); mb already contains the lane's 4*(lane>>5) offset.
 __device__ __forceinline__ void gemm_epilogue_tile(const r3d_gemm_desc& d, const f32x16& acc, int mb, int n, int split) {
     if (n >= d.N) return;
     int m[16];
@@ -122,17 +125,17 @@ __device__ __forceinline__ void gemm_epilogue_tile(const r3d_gemm_desc& d, const
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// staging helpers
+// staging: one register stage of a tile (two of them are alive in the pipeline)
 // ---------------------------------------------------------------------------------------------------------
 // K-contiguous source: tile of R rows x BK k.  f indexes float4s: row = f/(BK/4), kq = f%(BK/4).
-template <int R, int BK, int NT, bool VEC, bool PROLOGUE>
+template <int R, int BK, int NT>
 struct StageKC {
     static constexpr int Q4 = BK / 4;
     static constexpr int NLD = (R * Q4) / NT;
     static_assert(NLD >= 1 && (R * Q4) % NT == 0, "tile too small for the workgroup");
     float4 v[NLD];
-    __device__ __forceinline__ void load(const float* __restrict__ base, int ld, int row0, int rows_total,
-                                         int k0, int k_end, const r3d_gemm_desc& d) {
+    __device__ __forceinline__ void load(const float* __restrict__ base, int ld, int row0, int rows_total, int k0,
+                                         int k_end, bool vec, int row_xor, const float* add, int add_mod, int add_ld) {
 #pragma unroll
         for (int p = 0; p < NLD; ++p) {
             const int f = threadIdx.x + p * NT;
@@ -140,23 +143,19 @@ struct StageKC {
             const int k = k0 + ((f % Q4) << 2);
             float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
             if (row < rows_total && k < k_end) {
-                int srow = row;
-                if (PROLOGUE) srow = row ^ d.a_row_xor;
-                const float* src = base + (size_t)srow * ld + k;
-                if (VEC && k + 3 < k_end) {
+                const float* src = base + (size_t)(row ^ row_xor) * ld + k;
+                if (vec && k + 3 < k_end) {
                     x = *reinterpret_cast<const float4*>(src);
+                    if (add) {
+                        const float4 y = *reinterpret_cast<const float4*>(add + (size_t)(row % add_mod) * add_ld + k);
+                        x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
+                    }
                 } else {
-                    x.x = src[0];
-                    if (k + 1 < k_end) x.y = src[1];
-                    if (k + 2 < k_end) x.z = src[2];
-                    if (k + 3 < k_end) x.w = src[3];
-                }
-                if (PROLOGUE && d.a_add) {
-                    const float* ad = d.a_add + (size_t)(row % d.a_add_mod) * d.a_add_ld + k;
-                    x.x += ad[0];
-                    if (k + 1 < k_end) x.y += ad[1];
-                    if (k + 2 < k_end) x.z += ad[2];
-                    if (k + 3 < k_end) x.w += ad[3];
+                    const float* ad = add ? add + (size_t)(row % add_mod) * add_ld + k : nullptr;
+                    x.x = src[0] + (ad ? ad[0] : 0.f);
+                    if (k + 1 < k_end) x.y = src[1] + (ad ? ad[1] : 0.f);
+                    if (k + 2 < k_end) x.z = src[2] + (ad ? ad[2] : 0.f);
+                    if (k + 3 < k_end) x.w = src[3] + (ad ? ad[3] : 0.f);
                 }
             }
             v[p] = x;
@@ -178,13 +177,13 @@ struct StageKC {
 };
 
 // M/N-contiguous source: tile of BK k-rows x R columns.  f indexes float4s: krow = f/(R/4), cq = f%(R/4).
-template <int R, int BK, int NT, bool VEC>
+template <int R, int BK, int NT>
 struct StageMC {
     static constexpr int NLD = (R * BK / 4) / NT;
     static_assert(NLD >= 1 && (R * BK / 4) % NT == 0, "tile too small for the workgroup");
     float4 v[NLD];
-    __device__ __forceinline__ void load(const float* __restrict__ base, int ld, int col0, int cols_total,
-                                         int k0, int k_end, const float* add = nullptr, int add_mod = 1, int add_ld = 0) {
+    __device__ __forceinline__ void load(const float* __restrict__ base, int ld, int col0, int cols_total, int k0,
+                                         int k_end, bool vec, const float* add, int add_mod, int add_ld) {
 #pragma unroll
         for (int p = 0; p < NLD; ++p) {
             const int f = threadIdx.x + p * NT;
@@ -193,20 +192,18 @@ struct StageMC {
             float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
             if (k < k_end && c < cols_total) {
                 const float* src = base + (size_t)k * ld + c;
-                if (VEC && c + 3 < cols_total) {
+                const float* ad = add ? add + (size_t)(k % add_mod) * add_ld + c : nullptr;   // B'[k,:] = B[k,:] + add[k%mod,:]
+                if (vec && c + 3 < cols_total) {
                     x = *reinterpret_cast<const float4*>(src);
+                    if (ad) {
+                        const float4 y = *reinterpret_cast<const float4*>(ad);
+                        x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
+                    }
                 } else {
-                    x.x = src[0];
-                    if (c + 1 < cols_total) x.y = src[1];
-                    if (c + 2 < cols_total) x.z = src[2];
-                    if (c + 3 < cols_total) x.w = src[3];
-                }
-                if (add) {                       // B'[k, :] = B[k, :] + add[k % mod, :]
-                    const float* ad = add + (size_t)(k % add_mod) * add_ld + c;
-                    x.x += ad[0];
-                    if (c + 1 < cols_total) x.y += ad[1];
-                    if (c + 2 < cols_total) x.z += ad[2];
-                    if (c + 3 < cols_total) x.w += ad[3];
+                    x.x = src[0] + (ad ? ad[0] : 0.f);
+                    if (c + 1 < cols_total) x.y = src[1] + (ad ? ad[1] : 0.f);
+                    if (c + 2 < cols_total) x.z = src[2] + (ad ? ad[2] : 0.f);
+                    if (c + 3 < cols_total) x.w = src[3] + (ad ? ad[3] : 0.f);
                 }
             }
             v[p] = x;
@@ -224,28 +221,44 @@ struct StageMC {
     }
 };
 
+template <int LA, int LB, int BM, int BN, int BK, int NT>
+struct Stage {
+    StageKC<BM, BK, NT> a_kc;
+    StageMC<BM, BK, NT> a_mc;
+    StageKC<BN, BK, NT> b_kc;
+    StageMC<BN, BK, NT> b_mc;
+    __device__ __forceinline__ void load(const r3d_gemm_desc& d, int m0, int n0, int k0, int k_end) {
+        const bool vec = d.vec != 0;
+        if (LA == 0) a_kc.load(d.A, d.lda, m0, d.M, k0, k_end, vec, d.a_row_xor, d.a_add, d.a_add_mod, d.a_add_ld);
+        else a_mc.load(d.A, d.lda, m0, d.M, k0, k_end, vec, nullptr, 1, 0);
+        if (LB == 0) b_kc.load(d.B, d.ldb, n0, d.N, k0, k_end, vec, 0, nullptr, 1, 0);
+        else b_mc.load(d.B, d.ldb, n0, d.N, k0, k_end, vec, d.b_add, d.b_add_mod, d.b_add_ld);
+    }
+    __device__ __forceinline__ void store(float* as, float* bs) const {
+        if (LA == 0) a_kc.store(as); else a_mc.store(as);
+        if (LB == 0) b_kc.store(bs); else b_mc.store(bs);
+    }
+};
+
 // ---------------------------------------------------------------------------------------------------------
-// the kernel
+// one output tile of one problem
 // ---------------------------------------------------------------------------------------------------------
-template <int LA, int LB, int BM, int BN, int BK, int WM, int WN, bool VEC>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const r3d_gemm_desc d) {
+template <int LA, int LB, int BM, int BN, int BK, int WM, int WN>
+__device__ __forceinline__ void gemm_body(const r3d_gemm_desc& d, int tile, int split, float* smem) {
     constexpr int NT = 64 * WM * WN;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int SA = BM + (LA == 0 ? 2 : 4);
     constexpr int SB = BN + (LB == 0 ? 2 : 4);
     constexpr int A_FLOATS = BK * SA, B_FLOATS = BK * SB;
     static_assert(A_FLOATS % 4 == 0 && B_FLOATS % 4 == 0, "LDS carve must stay 16-byte aligned");
-    __shared__ __attribute__((aligned(16))) float smem[2 * (A_FLOATS + B_FLOATS)];
     float* As0 = smem;
     float* As1 = smem + A_FLOATS;
     float* Bs0 = smem + 2 * A_FLOATS;
     float* Bs1 = smem + 2 * A_FLOATS + B_FLOATS;
 
     const int tiles_n = (d.N + BN - 1) / BN;
-    const int tile = blockIdx.x;
     const int m0 = (tile / tiles_n) * BM;
     const int n0 = (tile % tiles_n) * BN;
-    const int split = blockIdx.y;
     const int k_begin = (d.splitk > 1) ? split * d.k_per_split : 0;
     const int k_end = (d.splitk > 1) ? min(d.K, k_begin + d.k_per_split) : d.K;
     const int nk = (k_end - k_begin + BK - 1) / BK;
@@ -263,38 +276,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const r3d_gemm_d
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    StageKC<BM, BK, NT, VEC, true> a_kc;
-    StageMC<BM, BK, NT, VEC> a_mc;
-    StageKC<BN, BK, NT, VEC, false> b_kc;
-    StageMC<BN, BK, NT, VEC> b_mc;
     float asum[TM];                    // TN only: column sums of A = the bias gradient (d.bias_grad)
 #pragma unroll
     for (int i = 0; i < TM; ++i) asum[i] = 0.f;
 
-    auto load_tiles = [&](int kt) {
-        const int k0 = k_begin + kt * BK;
-        if (LA == 0) a_kc.load(d.A, d.lda, m0, d.M, k0, k_end, d);
-        else a_mc.load(d.A, d.lda, m0, d.M, k0, k_end);
-        if (LB == 0) b_kc.load(d.B, d.ldb, n0, d.N, k0, k_end, d);
-        else b_mc.load(d.B, d.ldb, n0, d.N, k0, k_end, d.b_add, d.b_add_mod, d.b_add_ld);
-    };
-    auto store_tiles = [&](float* as, float* bs) {
-        if (LA == 0) a_kc.store(as); else a_mc.store(as);
-        if (LB == 0) b_kc.store(bs); else b_mc.store(bs);
-    };
-
-    if (nk > 0) {
-        load_tiles(0);
-        store_tiles(As0, Bs0);
-    }
-    __syncthreads();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool more = (kt + 1 < nk);
-        if (more) load_tiles(kt + 1);
-        const float* as = (kt & 1) ? As1 : As0;
-        const float* bs = (kt & 1) ? Bs1 : Bs0;
+    auto compute = [&](const float* as, const float* bs) {
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
             const int kr = kk * 2 + lhi;
@@ -312,8 +298,26 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const r3d_gemm_d
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        if (more) store_tiles((kt & 1) ? As0 : As1, (kt & 1) ? Bs0 : Bs1);
+    };
+
+    Stage<LA, LB, BM, BN, BK, NT> st0, st1;
+    if (nk > 0) st0.load(d, m0, n0, k_begin, k_end);
+    if (nk > 1) st1.load(d, m0, n0, k_begin + BK, k_end);
+    if (nk > 0) st0.store(As0, Bs0);
+    __syncthreads();
+    for (int kt = 0; kt < nk;) {
+        // even step: tile kt is in buffer 0, tile kt+1 in register stage 1; stage 0 is free for tile kt+2
+        if (kt + 2 < nk) st0.load(d, m0, n0, k_begin + (kt + 2) * BK, k_end);
+        compute(As0, Bs0);
+        if (kt + 1 < nk) st1.store(As1, Bs1);
         __syncthreads();
+        if (++kt >= nk) break;
+        // odd step: roles swapped
+        if (kt + 2 < nk) st1.load(d, m0, n0, k_begin + (kt + 2) * BK, k_end);
+        compute(As1, Bs1);
+        if (kt + 1 < nk) st0.store(As0, Bs0);
+        __syncthreads();
+        ++kt;
     }
 
     if (LA == 1 && d.bias_grad && n0 == 0 && wn_off == 0) {
@@ -324,15 +328,36 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const r3d_gemm_d
             if (lhi == 0 && m < d.M) d.bias_grad[m] = t;
         }
     }
-
-    // Epilogue straight from the accumulators.  C/D map of the 32x32 MFMA: col = lane & 31 (fixed per lane),
-    // row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).  Every optional operand is fetched in its own fully unrolled
-    // stage (16 independent loads in flight) -- an element-at-a-time epilogue serialises 16 memory round trips.
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
             gemm_epilogue_tile(d, acc[i][j], m0 + wm_off + i * 32 + 4 * lhi, n0 + wn_off + j * 32 + l31, split);
+}
+
+template <int LA, int LB, int BM, int BN, int BK>
+constexpr int gemm_lds_floats() {
+    return 2 * (BK * (BM + (LA == 0 ? 2 : 4)) + BK * (BN + (LB == 0 ? 2 : 4)));
+}
+
+template <int LA, int LB, int BM, int BN, int BK, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const r3d_gemm_desc d) {
+    __shared__ __attribute__((aligned(16))) float smem[gemm_lds_floats<LA, LB, BM, BN, BK>()];
+    gemm_body<LA, LB, BM, BN, BK, WM, WN>(d, blockIdx.x, blockIdx.y, smem);
+}
+
+// Many independent problems (same layout and tile config, splitk == 1) in one launch.  prefix[p] = first workgroup
+// of problem p, prefix[n] = grid size; descriptors live in device memory (uploaded once per shape by the host).
+template <int LA, int LB, int BM, int BN, int BK, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_grouped_kernel(const r3d_gemm_desc* __restrict__ descs,
+                                                                    const int* __restrict__ prefix, int n) {
+    __shared__ __attribute__((aligned(16))) float smem[gemm_lds_floats<LA, LB, BM, BN, BK>()];
+    int lo = 0, hi = n;                      // largest p with prefix[p] <= blockIdx.x
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (prefix[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
+    }
+    gemm_body<LA, LB, BM, BN, BK, WM, WN>(descs[lo], (int)blockIdx.x - prefix[lo], 0, smem);
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const r3d_gemm_desc d, int nsplit) {
@@ -347,68 +372,50 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const r3d_gemm_desc 
 // ---------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------
+static const int kTileSz[4] = {0, 32, 64, 128};
+
 template <int LA, int LB, int BM, int BN, int BK, int WM, int WN>
-static int launch_cfg(const r3d_gemm_desc& d, bool vec, int nsplit, hipStream_t s) {
+static int launch_cfg(const r3d_gemm_desc& d, int nsplit, hipStream_t s) {
     dim3 grid(r3d_cdiv(d.M, BM) * r3d_cdiv(d.N, BN), nsplit, 1);
-    dim3 block(64 * WM * WN, 1, 1);
-    if (vec) hipLaunchKernelGGL((gemm_f32_kernel<LA, LB, BM, BN, BK, WM, WN, true>), grid, block, 0, s, d);
-    else hipLaunchKernelGGL((gemm_f32_kernel<LA, LB, BM, BN, BK, WM, WN, false>), grid, block, 0, s, d);
+    hipLaunchKernelGGL((gemm_f32_kernel<LA, LB, BM, BN, BK, WM, WN>), grid, dim3(64 * WM * WN), 0, s, d);
     R3D_LAUNCH_CHECK();
     return R3D_OK;
 }
 
 template <int LA, int LB>
-static int launch_layout(const r3d_gemm_desc& d, bool vec, int nsplit, hipStream_t s) {
+static int launch_layout(const r3d_gemm_desc& d, int nsplit, hipStream_t s) {
     switch (d.tile) {
-        case 1: return launch_cfg<LA, LB, 32, 32, 64, 1, 1>(d, vec, nsplit, s);
-        case 2: return launch_cfg<LA, LB, 64, 64, 64, 2, 2>(d, vec, nsplit, s);
-        case 3: return launch_cfg<LA, LB, 128, 128, 32, 2, 2>(d, vec, nsplit, s);
+        case 1: return launch_cfg<LA, LB, 32, 32, 64, 1, 1>(d, nsplit, s);
+        case 2: return launch_cfg<LA, LB, 64, 64, 64, 2, 2>(d, nsplit, s);
+        case 3: return launch_cfg<LA, LB, 128, 128, 32, 2, 2>(d, nsplit, s);
         default: return R3D_EINVAL;
     }
+}
+
+template <int LA, int LB>
+static int launch_grouped(const r3d_gemm_desc* descs, const int* prefix, int n, int total, int tile, hipStream_t s) {
+    switch (tile) {
+        case 1:
+            hipLaunchKernelGGL((gemm_grouped_kernel<LA, LB, 32, 32, 64, 1, 1>), dim3(total), dim3(64), 0, s, descs, prefix, n);
+            break;
+        case 2:
+            hipLaunchKernelGGL((gemm_grouped_kernel<LA, LB, 64, 64, 64, 2, 2>), dim3(total), dim3(256), 0, s, descs, prefix, n);
+            break;
+        default: return R3D_EINVAL;
+    }
+    R3D_LAUNCH_CHECK();
+    return R3D_OK;
 }
 
 static int nsplits_of(const r3d_gemm_desc& d) {
     return (d.splitk > 1) ? r3d_cdiv(d.K, d.k_per_split) : 1;
 }
 
-}  // namespace r3d
-
-using namespace r3d;
-
-R3D_EXPORT int64_t r3d_gemm_partial_floats(int32_t M, int32_t N, int32_t splitk) {
-    return (splitk > 1) ? (int64_t)splitk * M * N : 0;
-}
-
-// Cost model for a 256-CU / 1024-SIMD part: pick the workgroup tile and the K split that minimise
-//   rounds(waves over SIMDs) * (k-steps * MFMA cycles per step + fixed overhead) + partial-slab traffic.
-R3D_EXPORT int r3d_gemm_plan(r3d_gemm_desc* d) {
-    if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0) return R3D_EINVAL;
-    static const int tile_sz[4] = {0, 32, 64, 128};
-    static const int tile_waves[4] = {0, 1, 4, 4};
-    static const int tile_cyc[4] = {0, 512, 512, 2048};   // MFMA cycles per 16-deep k-step per wave
-    double best = 1e300;
-    int bt = 1, bs = 1, bk = d->K;
-    for (int t = 1; t <= 3; ++t) {
-        const long tiles = (long)r3d_cdiv(d->M, tile_sz[t]) * r3d_cdiv(d->N, tile_sz[t]);
-        for (int sk = 1; sk <= 256; sk *= 2) {
-            int kps = r3d_cdiv(r3d_cdiv(d->K, sk), BK_MIN) * BK_MIN;
-            if (sk > 1 && kps < 128) break;
-            const int ns = r3d_cdiv(d->K, kps);
-            if (sk > 1 && ns < 2) continue;
-            const long waves = tiles * ns * tile_waves[t];
-            const double rounds = (double)((waves + 1023) / 1024);
-            const double per_wave = (double)r3d_cdiv(kps, BK_MIN) * tile_cyc[t] + 4000.0;
-            // slab write + read at ~4 TB/s ~= 0.6 cycle/KB-per-CU-equivalent; expressed in cycles @2.4 GHz
-            const double slab = (ns > 1) ? 2.0 * ns * (double)d->M * d->N * 4.0 / 4.0e12 * 2.4e9 + 4500.0 : 0.0;
-            // wasted MFMA work in ragged edge tiles is already inside `tiles`
-            const double cost = rounds * per_wave + slab;
-            if (cost < best) { best = cost; bt = t; bs = ns; bk = kps; }
-        }
-    }
-    d->tile = bt;
-    d->splitk = bs;
-    d->k_per_split = (bs > 1) ? bk : d->K;
-    return R3D_OK;
+static bool gemm_can_vec(const r3d_gemm_desc& d) {
+    bool vec = r3d_aligned16(d.A) && r3d_aligned16(d.B) && (d.lda % 4 == 0) && (d.ldb % 4 == 0);
+    if (d.a_add) vec = vec && r3d_aligned16(d.a_add) && (d.a_add_ld % 4 == 0);
+    if (d.b_add) vec = vec && r3d_aligned16(d.b_add) && (d.b_add_ld % 4 == 0);
+    return vec;
 }
 
 static int gemm_validate(const r3d_gemm_desc* d) {
@@ -434,18 +441,71 @@ static int gemm_validate(const r3d_gemm_desc* d) {
     return R3D_OK;
 }
 
+}  // namespace r3d
+
+using namespace r3d;
+
+R3D_EXPORT int64_t r3d_gemm_partial_floats(int32_t M, int32_t N, int32_t splitk) {
+    return (splitk > 1) ? (int64_t)splitk * M * N : 0;
+}
+
+// Cost model for a 256-CU / 1024-SIMD part.  These problems are latency-bound long before they are FLOP-bound:
+// a workgroup pays ~2 us per 64-deep k-step until enough independent waves share a CU, plus ~5 us per extra launch
+// (the split-K reducer).  Larger tiles cut the L2->LDS operand traffic (each element is re-fetched tiles_n or
+// tiles_m times), more splits add slab traffic.
+R3D_EXPORT int r3d_gemm_plan(r3d_gemm_desc* d) {
+    if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0) return R3D_EINVAL;
+    static const int tile_waves[4] = {0, 1, 4, 4};
+    static const int tile_bk[4] = {0, 64, 64, 32};
+    static const double mfma_us_per_step[4] = {0, 0.9, 0.9, 1.8};    // MFMA time of one k-step of one wave
+    const double flops = 2.0 * d->M * d->N * (double)d->K;
+    double best = 1e300;
+    int bt = 1, bs = 1, bk = d->K;
+    for (int t = 1; t <= 3; ++t) {
+        const long tm = r3d_cdiv(d->M, kTileSz[t]), tn = r3d_cdiv(d->N, kTileSz[t]);
+        const long tiles = tm * tn;
+        for (int sk = 1; sk <= 512; sk *= 2) {
+            int kps = r3d_cdiv(r3d_cdiv(d->K, sk), 64) * 64;
+            if (sk > 1 && kps < 128) break;
+            const int ns = r3d_cdiv(d->K, kps);
+            if (sk > 1 && ns < 2) continue;
+            const long waves = tiles * ns * tile_waves[t];
+            const double rounds = (double)((waves + 1023) / 1024);
+            const double occ = (double)waves / (1024.0 * rounds);                 // SIMD fill
+            const int steps = r3d_cdiv(kps, tile_bk[t]);
+            // a step is MFMA-bound only when a SIMD has other waves to run while one waits on HBM (~2 us)
+            const double lat = occ < 0.5 ? 2.0 : 1.2;
+            const double step_us = mfma_us_per_step[t] > lat ? mfma_us_per_step[t] : lat;
+            // operand re-fetch through L2 at ~10 TB/s aggregate, HBM once at ~5 TB/s
+            const double l2_us = 4.0 * ((double)d->M * d->K * tn + (double)d->N * d->K * tm) / 10.0e6;
+            const double hbm_us = 4.0 * ((double)d->M * d->K + (double)d->N * d->K) / 5.0e6;
+            const double slab_us = (ns > 1) ? 5.0 + 2.0 * 4.0 * ns * (double)d->M * d->N / 4.0e6 : 0.0;
+            const double mfma_us = flops / 140.0e6 / (occ < 1.0 ? occ : 1.0);
+            double t_us = rounds * steps * step_us + 3.0;
+            if (t_us < l2_us) t_us = l2_us;
+            if (t_us < hbm_us) t_us = hbm_us;
+            if (t_us < mfma_us) t_us = mfma_us;
+            t_us += slab_us;
+            if (t_us < best) { best = t_us; bt = t; bs = ns; bk = kps; }
+        }
+    }
+    d->tile = bt;
+    d->splitk = bs;
+    d->k_per_split = (bs > 1) ? bk : d->K;
+    return R3D_OK;
+}
+
 R3D_EXPORT int r3d_gemm_f32(const r3d_gemm_desc* dp, void* stream) {
     int rc = gemm_validate(dp);
     if (rc != R3D_OK) return rc;
-    const r3d_gemm_desc& d = *dp;
+    r3d_gemm_desc d = *dp;
+    d.vec = gemm_can_vec(d) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
-    bool vec = r3d_aligned16(d.A) && r3d_aligned16(d.B) && (d.lda % 4 == 0) && (d.ldb % 4 == 0);
-    if (d.a_add) vec = vec && r3d_aligned16(d.a_add) && (d.a_add_ld % 4 == 0);
     const int ns = nsplits_of(d);
     switch (d.layout) {
-        case R3D_GEMM_NT: return launch_layout<0, 0>(d, vec, ns, s);
-        case R3D_GEMM_NN: return launch_layout<0, 1>(d, vec, ns, s);
-        default: return launch_layout<1, 1>(d, vec, ns, s);
+        case R3D_GEMM_NT: return launch_layout<0, 0>(d, ns, s);
+        case R3D_GEMM_NN: return launch_layout<0, 1>(d, ns, s);
+        default: return launch_layout<1, 1>(d, ns, s);
     }
 }
 
@@ -458,4 +518,39 @@ R3D_EXPORT int r3d_splitk_reduce(const r3d_gemm_desc* dp, void* stream) {
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *dp, nsplits_of(*dp));
     R3D_LAUNCH_CHECK();
     return R3D_OK;
+}
+
+/* Host-side preparation of a problem group: validates the n descriptors (same layout, splitk == 1), fills their
+ * `tile` (all get `tile`) and `vec` fields in place and writes prefix[0..n] (first workgroup of each problem).
+ * The caller uploads descs and prefix to device memory once and replays r3d_gemm_grouped_launch every step. */
+R3D_EXPORT int r3d_gemm_grouped_prepare(r3d_gemm_desc* descs, int n, int tile, int32_t* prefix) {
+    if (!descs || !prefix || n <= 0 || (tile != 1 && tile != 2)) return R3D_EINVAL;
+    int total = 0;
+    for (int p = 0; p < n; ++p) {
+        r3d_gemm_desc& d = descs[p];
+        d.tile = tile;
+        d.splitk = 1;
+        d.k_per_split = d.K;
+        d.partial = nullptr;
+        int rc = gemm_validate(&d);
+        if (rc != R3D_OK) return rc;
+        if (d.layout != descs[0].layout) return R3D_EINVAL;
+        d.vec = gemm_can_vec(d) ? 1 : 0;
+        prefix[p] = total;
+        total += r3d_cdiv(d.M, kTileSz[tile]) * r3d_cdiv(d.N, kTileSz[tile]);
+    }
+    prefix[n] = total;
+    return R3D_OK;
+}
+
+R3D_EXPORT int r3d_gemm_grouped_launch(const r3d_gemm_desc* dev_descs, const int32_t* dev_prefix, int n, int total_tiles,
+                                       int layout, int tile, void* stream) {
+    if (!dev_descs || !dev_prefix || n <= 0 || total_tiles <= 0) return R3D_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    switch (layout) {
+        case R3D_GEMM_NT: return launch_grouped<0, 0>(dev_descs, dev_prefix, n, total_tiles, tile, s);
+        case R3D_GEMM_NN: return launch_grouped<0, 1>(dev_descs, dev_prefix, n, total_tiles, tile, s);
+        case R3D_GEMM_TN: return launch_grouped<1, 1>(dev_descs, dev_prefix, n, total_tiles, tile, s);
+        default: return R3D_EINVAL;
+    }
 }

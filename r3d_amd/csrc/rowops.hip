@@ -194,6 +194,26 @@ __global__ __launch_bounds__(256) void ln_param_finalize_kernel(const float* ws,
     }
 }
 
+__global__ __launch_bounds__(256) void ln_param_finalize_batched_kernel(const r3d_ln_finalize_job* jobs) {
+    __shared__ float red[4][64];
+    const r3d_ln_finalize_job j = jobs[blockIdx.y];
+    int rpb = ((j.rows + 255) / 256 + 3) / 4 * 4;
+    if (rpb < 4) rpb = 4;
+    const int blocks = (j.rows + rpb - 1) / rpb;
+    if (blocks <= 1) return;                               // the backward kernel already wrote the final values
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;
+    float s = 0.f;
+    if (i < 2 * j.H)
+        for (int p = wave; p < blocks; p += 4) s += j.ws[(size_t)p * 2 * j.H + i];
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && i < 2 * j.H) {
+        const float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        (i < j.H ? j.dgamma : j.dbeta)[i < j.H ? i : i - j.H] = t;
+    }
+}
+
 // column sums of x[rows, cols]: grid (colblocks of 64, rowchunks); wave w of the block takes rows w, w+4, ...
 __global__ __launch_bounds__(256) void colsum_kernel(const float* x, int ld, int rows, int cols, int rows_per_chunk,
                                                      float* out, float* ws, int accumulate) {
@@ -366,6 +386,14 @@ R3D_EXPORT int r3d_layernorm_bwd_finalize(const float* ws, int rows, int H, floa
     R3D_REQUIRE(ws);
     hipLaunchKernelGGL(ln_param_finalize_kernel, dim3(r3d_cdiv(2 * H, 64)), dim3(256), 0, (hipStream_t)stream, ws, blocks, H,
                        dgamma, dbeta);
+    R3D_LAUNCH_CHECK();
+    return R3D_OK;
+}
+
+R3D_EXPORT int r3d_layernorm_bwd_finalize_batched(const r3d_ln_finalize_job* dev_jobs, int njobs, int max_H, void* stream) {
+    R3D_REQUIRE(dev_jobs && njobs > 0 && max_H > 0 && max_H <= 2048);
+    hipLaunchKernelGGL(ln_param_finalize_batched_kernel, dim3(r3d_cdiv(2 * max_H, 64), njobs), dim3(256), 0,
+                       (hipStream_t)stream, dev_jobs);
     R3D_LAUNCH_CHECK();
     return R3D_OK;
 }

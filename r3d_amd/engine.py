@@ -238,8 +238,8 @@ class FusionEngine:
             key_labels = labels
         main = torch.cuda.current_stream()
         multi = self.use_side_stream
-        s1, s2 = (self.side, self.side2) if multi else (main, main)
-        ws1, ws2 = (self.ws_side, self.ws_side2) if multi else (self.ws, self.ws)
+        s2 = self.side2 if multi else main
+        ws2 = self.ws_side2 if multi else self.ws
         qpos = a.p("query_embed.weight")
         pos = a.p("pos_embedding")[0, :S]
 
@@ -260,12 +260,10 @@ class FusionEngine:
 
         # ---- branch s1: RGB embedding (:179-183);  branch s2: layer-0 query self-attention;  main: depth embedding
         if multi:
-            s1.wait_stream(main)
             s2.wait_stream(main)
-        with torch.cuda.stream(s1):
-            ops.gemm(GEMM_NT, x_rgb, a.p("input_embed.weight"), w.rgb, bias=a.p("input_embed.bias"), act=1, ws=ws1)
         with torch.cuda.stream(s2):
             sa_block(0, w.tgt0, ws2)
+        ops.gemm(GEMM_NT, x_rgb, a.p("input_embed.weight"), w.rgb, bias=a.p("input_embed.bias"), act=1, ws=self.ws)
         d = ops.gemm(GEMM_NT, x_dep, a.p("depth_projection.weight"), w.dep_pre, bias=a.p("depth_projection.bias"),
                      ws=self.ws, defer_reduce=True)                              # (:194-195)
         if d.splitk > 1:
@@ -275,8 +273,6 @@ class FusionEngine:
         else:
             ops.layernorm_fwd(w.dep_pre, a.p("depth_layernorm.weight"), a.p("depth_layernorm.bias"), w.dep, w.mean_d,
                               w.rstd_d, relu=True)
-        if multi:
-            main.wait_stream(s1)
         # ---- token selection + exchange (:33-66)
         if mode == "train":
             idx, mask = self._train_masks(B, S)
@@ -302,11 +298,8 @@ class FusionEngine:
         ops.gemm(GEMM_NT, w.f1, a.p(pre + "mlp.mlp.2.weight"), w.x3, bias=a.p(pre + "mlp.mlp.2.bias"), res1=w.x1,
                  res2=w.x0, ws=self.ws)
         ops.layernorm_fwd(w.x3, a.p("fuser.norm.weight"), a.p("fuser.norm.bias"), w.y, w.mf, w.rf, pair_out=w.fused)
-        # ---- segmentation head on s1 (:228-232): only needs the fused features
-        if multi:
-            s1.wait_stream(main)
-        with torch.cuda.stream(s1):
-            ops.gemm(GEMM_NT, w.fused, a.p("fc_seg.weight"), w.seg, bias=a.p("fc_seg.bias"), ws=ws1)
+        # ---- segmentation head (:228-232)
+        ops.gemm(GEMM_NT, w.fused, a.p("fc_seg.weight"), w.seg, bias=a.p("fc_seg.bias"), ws=self.ws)
         # ---- decoder (transformer.py:75-128,161-191,281-330); memory = fused, encoder bypassed (:77-78)
         tgt = None
         for l in range(self.L):
@@ -335,8 +328,6 @@ class FusionEngine:
                           w.mF, w.rF)
         # ---- anticipation heads (:219-226): fc and fc_len as one [K+1, H] GEMM
         ops.gemm(GEMM_NT, w.tgtF, self.w_head, w.actdur, bias=self.b_head, ws=self.ws)
-        if multi:
-            main.wait_stream(s1)
         self.last = dict(w=w, x_rgb=x_rgb, x_dep=x_dep, mask=mask, idx=idx, drop=drop, mode=mode)
         return dict(seg=w.seg.view(B, S, K), action=w.actdur[:, :K].view(B, Q, K), duration=w.actdur[:, K].view(B, Q))
 
@@ -372,138 +363,153 @@ class FusionEngine:
         st = self.last
         ops.gemm(GEMM_TN, st["w"].d_dep_pre, st["x_dep"], self.arena.g("depth_projection.weight"), ws=self.ws)
 
+    def _build_groups(self, w):
+        """Once per shape: every weight gradient whose operands live in the persistent workspace becomes one problem of
+        a grouped TN GEMM (bias gradient fused), every LayerNorm parameter reduction one job of a batched finalize."""
+        a, H, Q, S, N, BQ = self.arena, self.H, self.Q, w.S, w.N, w.BQ
+        qpos = a.p("query_embed.weight")
+        pos = a.p("pos_embedding")[0, :S]
+        pre = "fuser.blocks.0."
+        P = []
+
+        def add(dy, x, gw, gb=None, b_add=None, b_mod=0):
+            P.append(dict(a=dy, b=x, c=gw, bias_grad=gb, b_add=b_add, b_add_mod=b_mod))
+        add(w.d_actdur, w.tgtF, self.gw_head, self.gb_head)
+        add(w.d_seg, w.fused, a.g("fc_seg.weight"), a.g("fc_seg.bias"))
+        for l in range(self.L):
+            c, gl, pl = w.layers[l], w.glayers[l], f"transformer.decoder.layers.{l}."
+            g = lambda n: a.g(pl + n)         # noqa: E731
+            tgt_in = w.tgt0 if l == 0 else w.layers[l - 1]["t3"]
+            gwi, gbi = g("multihead_attn.in_proj_weight"), g("multihead_attn.in_proj_bias")
+            add(gl["ff2"], c["ff1"], g("linear2.weight"), g("linear2.bias"))
+            add(gl["ff1"], c["t2"], g("linear1.weight"), g("linear1.bias"))
+            add(gl["cap"], c["ca_o"], g("multihead_attn.out_proj.weight"), g("multihead_attn.out_proj.bias"))
+            add(gl["cakv"], w.fused, gwi[H:], gbi[H:], pos, S)
+            add(gl["caq"], c["t1"], gwi[:H], gbi[:H], qpos, Q)
+            add(gl["sap"], c["sa_o"], g("self_attn.out_proj.weight"), g("self_attn.out_proj.bias"))
+            add(gl["saqkv"], tgt_in, g("self_attn.in_proj_weight"), g("self_attn.in_proj_bias"), qpos, Q)
+        add(w.d_x3, w.f1, a.g(pre + "mlp.mlp.2.weight"), a.g(pre + "mlp.mlp.2.bias"))
+        add(w.d_u, w.h2, a.g(pre + "mlp.mlp.0.weight"), a.g(pre + "mlp.mlp.0.bias"))
+        add(w.d_x1, w.vsw, a.g(pre + "attn.proj.weight"), a.g(pre + "attn.proj.bias"))
+        add(w.d_v, w.h1, a.g(pre + "attn.qkv.weight")[2 * H:], None)          # rows [0,2H) (Q,K) stay exactly zero
+        w.wgrad_group = ops.GemmGroup(GEMM_TN, P, tile=1)
+        J = [(w.lnp["final"], BQ, H, a.g("transformer.decoder.norm.weight"), a.g("transformer.decoder.norm.bias")),
+             (w.lnp["nf"], 2 * N, H, a.g("fuser.norm.weight"), a.g("fuser.norm.bias")),
+             (w.lnp["n2"], 2 * N, H, a.g(pre + "norm2.weight"), a.g(pre + "norm2.bias")),
+             (w.lnp["n1"], 2 * N, H, a.g(pre + "norm1.weight"), a.g(pre + "norm1.bias")),
+             (w.lnp["dep"], N, H, a.g("depth_layernorm.weight"), a.g("depth_layernorm.bias"))]
+        for l in range(self.L):
+            pl = f"transformer.decoder.layers.{l}."
+            for k in (1, 2, 3):
+                J.append((w.lnp[f"d{k}_{l}"], BQ, H, a.g(pl + f"norm{k}.weight"), a.g(pl + f"norm{k}.bias")))
+        w.ln_group = ops.LnFinalizeGroup(J)
+
     def backward_main(self, d_seg=None, d_actdur=None):
-        """Everything of the backward except depth_projection.weight, on three HIP streams that fork from and join
-        back into the current stream (under hipGraph capture they become parallel branches of the graph):
-          main : the chain of input gradients that leads to the fuser and the embeddings (the critical path);
-          s2   : the self-attention sub-layer of the decoder queries -- it only feeds parameter gradients
-                 (and, for stacked decoders, the previous layer);
-          s1   : every weight / bias gradient, LayerNorm parameter reduction and broadcast-parameter sum, each
-                 enqueued as soon as its operands exist."""
+        """Everything of the backward except depth_projection.weight.
+        The chain of input gradients (the critical path) is a sequence of dependent, latency-bound launches; nothing
+        that only feeds a parameter gradient stays on it: all weight/bias gradients run as ONE grouped GEMM launch
+        and all LayerNorm parameter reductions as ONE batched launch after the chain.  With use_side_stream the
+        self-attention sub-layer of the decoder queries (which feeds only parameter gradients for a one-layer
+        decoder) runs on a second HIP stream -- a parallel branch under hipGraph capture."""
         st = self.last
         w, a, H, Q, K, heads, dh, ws = st["w"], self.arena, self.H, self.Q, self.K, self.heads, self.dh, self.ws
         B, S, N, BQ = w.B, w.S, w.N, w.BQ
-        d_seg = w.d_seg if d_seg is None else d_seg
-        d_actdur = w.d_actdur if d_actdur is None else d_actdur
+        if d_seg is not None and d_seg.data_ptr() != w.d_seg.data_ptr():
+            w.d_seg.copy_(d_seg)
+        if d_actdur is not None and d_actdur.data_ptr() != w.d_actdur.data_ptr():
+            w.d_actdur.copy_(d_actdur)
+        d_seg, d_actdur = w.d_seg, w.d_actdur
+        if not hasattr(w, "wgrad_group"):
+            self._build_groups(w)
         drop = st["drop"]
         dsc = 1.0 / (1.0 - DROP_P)
         dm = (lambda k, r, c: w.drop[k].view(r, c)) if drop else (lambda k, r, c: None)
         dmf = (lambda k: w.drop[k]) if drop else (lambda k: None)
         main = torch.cuda.current_stream()
         multi = self.use_side_stream
-        s1, s2 = (self.side, self.side2) if multi else (main, main)
-        ws1, ws2 = (self.ws_side, self.ws_side2) if multi else (ws, ws)
-        qpos = a.p("query_embed.weight")
-        pos = a.p("pos_embedding")[0, :S]
+        s2 = self.side2 if multi else main
+        ws2 = self.ws_side2 if multi else ws
+        joined = True
 
-        def on_s1(fn, after=None):
-            if multi:
-                s1.wait_stream(after if after is not None else torch.cuda.current_stream())
-            with torch.cuda.stream(s1):
-                fn()
-
-        def wgrad(dy, x, gw, gb, after=None, b_add=None, b_mod=0):
-            """gw = dy^T . (x [+ broadcast add]), gb = column sums of dy (fused into the same launch), on s1"""
-            on_s1(lambda: ops.gemm(GEMM_TN, dy, x, gw, bias_grad=gb, b_add=b_add, b_add_mod=b_mod, ws=ws1), after)
-
-        def ln_bwd(site, dy, x, mean, rstd, gname, bname, dx, rows, **kw):
-            """dx on the current stream; the parameter-gradient reduction of this LayerNorm site on s1"""
-            cur = torch.cuda.current_stream()
+        def ln_bwd(site, dy, x, mean, rstd, gname, bname, dx, **kw):
             ops.layernorm_bwd(dy, x, mean, rstd, a.p(gname), a.p(bname), dx, a.g(gname), a.g(bname), partial=w.lnp[site],
                               **kw)
-            on_s1(lambda: ops.layernorm_bwd_finalize(w.lnp[site], rows, H, a.g(gname), a.g(bname)), cur)
 
         # ---- heads
         ops.gemm(GEMM_NN, d_actdur, self.w_head, w.d_tgtF, ws=ws)
-        wgrad(d_actdur, w.tgtF, self.gw_head, self.gb_head)
-        wgrad(d_seg, w.fused, a.g("fc_seg.weight"), a.g("fc_seg.bias"))
         # ---- decoder
         last = w.layers[-1]
         ln_bwd("final", w.d_tgtF, last["t3"], w.mF, w.rF, "transformer.decoder.norm.weight",
-               "transformer.decoder.norm.bias", w.d_t, BQ)
+               "transformer.decoder.norm.bias", w.d_t)
         dy, dy2 = w.d_t, None                 # gradient w.r.t. t3 of the current layer (= dy + dy2)
-        g_qe = a.g("query_embed.weight")
-        first_qe, first_fused = True, True
+        first_fused = True
         for l in reversed(range(self.L)):
             c, gl, pl = w.layers[l], w.glayers[l], f"transformer.decoder.layers.{l}."
-            g = lambda n: a.g(pl + n)         # noqa: E731
             p = lambda n: a.p(pl + n)         # noqa: E731
-            tgt_in = w.tgt0 if l == 0 else w.layers[l - 1]["t3"]
             # norm3 -> (t2 residual, FFN)
-            ln_bwd(f"d3_{l}", dy, c["t3_pre"], c["m3"], c["r3"], pl + "norm3.weight", pl + "norm3.bias", gl["t3pre"], BQ,
+            ln_bwd(f"d3_{l}", dy, c["t3_pre"], c["m3"], c["r3"], pl + "norm3.weight", pl + "norm3.bias", gl["t3pre"],
                    dy2=dy2, dx2=gl["ff2"], drop_mask=dm(f"d3_{l}", BQ, H), drop_scale=dsc)
             ops.gemm(GEMM_NN, gl["ff2"], p("linear2.weight"), gl["ff1"], drop_mask=dm(f"ff_{l}", BQ, 4 * H),
                      drop_scale=dsc, aux=c["ff1"], mul=1, ws=ws)
-            wgrad(gl["ff2"], c["ff1"], g("linear2.weight"), g("linear2.bias"))
             ops.gemm(GEMM_NN, gl["ff1"], p("linear1.weight"), gl["t2"], res1=gl["t3pre"], ws=ws)
-            wgrad(gl["ff1"], c["t2"], g("linear1.weight"), g("linear1.bias"))
             # norm2 -> (t1 residual, cross attention)
             ln_bwd(f"d2_{l}", gl["t2"], c["t2_pre"], c["m2"], c["r2"], pl + "norm2.weight", pl + "norm2.bias", gl["t2pre"],
-                   BQ, dx2=gl["cap"], drop_mask=dm(f"d2_{l}", BQ, H), drop_scale=dsc)
+                   dx2=gl["cap"], drop_mask=dm(f"d2_{l}", BQ, H), drop_scale=dsc)
             ops.gemm(GEMM_NN, gl["cap"], p("multihead_attn.out_proj.weight"), gl["cao"], ws=ws)
-            wgrad(gl["cap"], c["ca_o"], g("multihead_attn.out_proj.weight"), g("multihead_attn.out_proj.bias"))
             ops.mha_core_bwd(c["caq"], c["cakv"][:, :H], c["cakv"][:, H:], c["p_ca"], gl["cao"], gl["caq"],
                              gl["cakv"][:, :H], gl["cakv"][:, H:], B, heads, Q, S, dh, drop_mask=dmf(f"ca_p{l}"),
                              drop_scale=dsc)
             wi = p("multihead_attn.in_proj_weight")
-            gwi, gbi = g("multihead_attn.in_proj_weight"), g("multihead_attn.in_proj_bias")
-            ops.gemm(GEMM_NN, gl["cakv"], wi[H:], w.d_fused, accumulate=not first_fused, ws=ws)   # d (memory + pos)
-            first_fused = False
-            wgrad(gl["cakv"], w.fused, gwi[H:], gbi[H:], b_add=pos, b_mod=S)
-            wgrad(gl["caq"], c["t1"], gwi[:H], gbi[:H], b_add=qpos, b_mod=Q)
-            # ---- branch s2: query path of the cross attention + the self-attention sub-layer
+            # ---- query path of the cross attention + the self-attention sub-layer (branch s2)
             if multi:
                 s2.wait_stream(main)
+                joined = False
             with torch.cuda.stream(s2):
                 ops.gemm(GEMM_NN, gl["caq"], wi[:H], gl["caqin"], ws=ws2)
-                acc_qe = not first_qe
-                on_s1(lambda gl=gl, acc_qe=acc_qe: ops.rowmod_sum(gl["caqin"], Q, g_qe, accumulate=acc_qe), s2)
-                first_qe = False
                 # norm1: d t1 = caqin (query path) + t2pre (residual into t2_pre)
                 ln_bwd(f"d1_{l}", gl["caqin"], c["t1_pre"], c["m1"], c["r1"], pl + "norm1.weight", pl + "norm1.bias",
-                       gl["t1pre"], BQ, dy2=gl["t2pre"], dx2=gl["sap"], drop_mask=dm(f"d1_{l}", BQ, H), drop_scale=dsc)
+                       gl["t1pre"], dy2=gl["t2pre"], dx2=gl["sap"], drop_mask=dm(f"d1_{l}", BQ, H), drop_scale=dsc)
                 ops.gemm(GEMM_NN, gl["sap"], p("self_attn.out_proj.weight"), gl["sao"], ws=ws2)
-                wgrad(gl["sap"], c["sa_o"], g("self_attn.out_proj.weight"), g("self_attn.out_proj.bias"), after=s2)
                 ops.mha_core_bwd(c["sa_qkv"][:, :H], c["sa_qkv"][:, H:2 * H], c["sa_qkv"][:, 2 * H:], c["p_sa"], gl["sao"],
                                  gl["saqkv"][:, :H], gl["saqkv"][:, H:2 * H], gl["saqkv"][:, 2 * H:], B, heads, Q, Q, dh,
                                  drop_mask=dmf(f"sa_p{l}"), drop_scale=dsc)
                 ops.gemm(GEMM_NN, gl["saqkv"], p("self_attn.in_proj_weight"), gl["sain"], ws=ws2)
-                wgrad(gl["saqkv"], tgt_in, g("self_attn.in_proj_weight"), g("self_attn.in_proj_bias"), after=s2,
-                      b_add=qpos, b_mod=Q)
-                on_s1(lambda gl=gl: ops.rowmod_sum(gl["sain"], Q, g_qe, accumulate=True), s2)
+            ops.gemm(GEMM_NN, gl["cakv"], wi[H:], w.d_fused, accumulate=not first_fused, ws=ws)   # d (memory + pos)
+            first_fused = False
             if l > 0:                          # d t3 of layer l-1 = sain (through the queries) + t1pre (residual)
                 if multi:
                     main.wait_stream(s2)
+                    joined = True
                 dy, dy2 = gl["sain"], gl["t1pre"]
-        # ---- positional embedding gradient: sum over clips of d(memory+pos), before the seg head joins d_fused (:190)
-        on_s1(lambda: ops.rowmod_sum(w.d_fused, S, a.g("pos_embedding")[0, :S]))
-        d_fz = w.d_fused2
-        ops.gemm(GEMM_NN, d_seg, a.p("fc_seg.weight"), d_fz, res1=w.d_fused, ws=ws)
+        # ---- the seg head joins d(memory): d_fused itself is kept for the positional-embedding gradient (:190)
+        ops.gemm(GEMM_NN, d_seg, a.p("fc_seg.weight"), w.d_fused2, res1=w.d_fused, ws=ws)
         # ---- fuser
         pre = "fuser.blocks.0."
-        ln_bwd("nf", d_fz, w.x3, w.mf, w.rf, "fuser.norm.weight", "fuser.norm.bias", w.d_x3, 2 * N, pair_in=True)
+        ln_bwd("nf", w.d_fused2, w.x3, w.mf, w.rf, "fuser.norm.weight", "fuser.norm.bias", w.d_x3, pair_in=True)
         ops.gemm(GEMM_NN, w.d_x3, a.p(pre + "mlp.mlp.2.weight"), w.d_u, aux=w.u, mul=2, ws=ws)
-        wgrad(w.d_x3, w.f1, a.g(pre + "mlp.mlp.2.weight"), a.g(pre + "mlp.mlp.2.bias"))
         ops.gemm(GEMM_NN, w.d_u, a.p(pre + "mlp.mlp.0.weight"), w.d_h2, ws=ws)
-        wgrad(w.d_u, w.h2, a.g(pre + "mlp.mlp.0.weight"), a.g(pre + "mlp.mlp.0.bias"))
-        ln_bwd("n2", w.d_h2, w.x1, w.m2, w.r2, pre + "norm2.weight", pre + "norm2.bias", w.d_x1, 2 * N, add1=w.d_x3)
+        ln_bwd("n2", w.d_h2, w.x1, w.m2, w.r2, pre + "norm2.weight", pre + "norm2.bias", w.d_x1, add1=w.d_x3)
         ops.gemm(GEMM_NN, w.d_x1, a.p(pre + "attn.proj.weight"), w.d_v, c_row_xor=1, ws=ws)     # un-swap
-        wgrad(w.d_x1, w.vsw, a.g(pre + "attn.proj.weight"), a.g(pre + "attn.proj.bias"))
-        gqkv = a.g(pre + "attn.qkv.weight")                                   # rows [0,2H) (Q,K) stay exactly zero
         ops.gemm(GEMM_NN, w.d_v, a.p(pre + "attn.qkv.weight")[2 * H:], w.d_h1, ws=ws)
-        wgrad(w.d_v, w.h1, gqkv[2 * H:], None)
-        ln_bwd("n1", w.d_h1, w.x0, w.m1, w.r1, pre + "norm1.weight", pre + "norm1.bias", w.d_x0, 2 * N, add1=w.d_x1,
-               add2=w.d_x3)
+        ln_bwd("n1", w.d_h1, w.x0, w.m1, w.r1, pre + "norm1.weight", pre + "norm1.bias", w.d_x0, add1=w.d_x1, add2=w.d_x3)
         mask = st["mask"]
         ops.token_exchange_bwd(w.d_x0, w.rgb, mask[0], mask[1], w.d_rgb_pre, w.d_dep, drop_mask=dmf("x0"), drop_scale=dsc)
         # ---- embeddings
-        wgrad(w.d_rgb_pre, st["x_rgb"], a.g("input_embed.weight"), a.g("input_embed.bias"))
         ln_bwd("dep", w.d_dep, w.dep_pre, w.mean_d, w.rstd_d, "depth_layernorm.weight", "depth_layernorm.bias",
-               w.d_dep_pre, N, relu=True)
-        on_s1(lambda: ops.colsum(w.d_dep_pre, a.g("depth_projection.bias"), ws=ws1))
-        if multi:
+               w.d_dep_pre, relu=True)
+        if not joined:
             main.wait_stream(s2)
-            main.wait_stream(s1)
+        # ---- everything that only feeds parameter gradients: 2 launches + the broadcast-parameter sums
+        w.wgrad_group.launch()
+        w.ln_group.launch()
+        ops.gemm(GEMM_TN, w.d_rgb_pre, st["x_rgb"], a.g("input_embed.weight"), bias_grad=a.g("input_embed.bias"), ws=ws)
+        g_qe = a.g("query_embed.weight")
+        for i, l in enumerate(reversed(range(self.L))):
+            gl = w.glayers[l]
+            ops.rowmod_sum(gl["caqin"], Q, g_qe, accumulate=i > 0)
+            ops.rowmod_sum(gl["sain"], Q, g_qe, accumulate=True)
+        ops.rowmod_sum(w.d_fused, S, a.g("pos_embedding")[0, :S])
+        ops.colsum(w.d_dep_pre, a.g("depth_projection.bias"), ws=ws)
 
     # ------------------------------------------------------------------------------------------------------
     def adamw(self, lr, weight_decay, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):

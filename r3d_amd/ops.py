@@ -122,6 +122,69 @@ def gemm(layout, a, b, c, *, bias=None, act=0, pre_out=None, a_add=None, a_add_m
     return d
 
 
+class GemmGroup:
+    """A set of independent GEMMs of one layout that run as ONE launch (r3d_gemm_grouped_*).  Built once per shape:
+    descriptors and the workgroup prefix table are uploaded to device memory; launch() replays them."""
+
+    def __init__(self, layout, problems, tile=1):
+        """problems: list of dicts with the keyword arguments of gemm() (a, b, c required)."""
+        lib = _lib.load()
+        n = len(problems)
+        arr = (GemmDesc * n)()
+        self._keep = problems
+        for i, pr in enumerate(problems):
+            a, b, c = pr["a"], pr["b"], pr["c"]
+            d = arr[i]
+            if layout == GEMM_NT:
+                M, K = a.shape
+                N = b.shape[0]
+            elif layout == GEMM_NN:
+                M, K = a.shape
+                N = b.shape[1]
+            else:
+                K, M = a.shape
+                N = b.shape[1]
+            assert tuple(c.shape) == (M, N)
+            d.A, d.B, d.C = a.data_ptr(), b.data_ptr(), c.data_ptr()
+            d.layout, d.M, d.N, d.K = layout, M, N, K
+            d.lda, d.ldb, d.ldc = _ld(a), _ld(b), _ld(c)
+            d.alpha = 1.0
+            if pr.get("bias_grad") is not None:
+                assert layout == GEMM_TN and pr["bias_grad"].numel() == M
+                d.bias_grad = pr["bias_grad"].data_ptr()
+            if pr.get("b_add") is not None:
+                d.b_add, d.b_add_mod, d.b_add_ld = pr["b_add"].data_ptr(), pr["b_add_mod"], _ld(pr["b_add"])
+        prefix = (C.c_int32 * (n + 1))()
+        check(lib.r3d_gemm_grouped_prepare(arr, n, tile, prefix), "r3d_gemm_grouped_prepare")
+        dev = problems[0]["a"].device
+        self.descs = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+        self.prefix = torch.tensor(list(prefix), dtype=torch.int32, device=dev)
+        self.n, self.total, self.layout, self.tile = n, int(prefix[n]), layout, tile
+
+    def launch(self):
+        check(_lib.load().r3d_gemm_grouped_launch(_p(self.descs), _p(self.prefix), self.n, self.total, self.layout, self.tile,
+                                                  _stream()), "r3d_gemm_grouped_launch")
+
+
+class LnFinalizeGroup:
+    """All deferred LayerNorm parameter-gradient reductions of a step in one launch."""
+
+    def __init__(self, jobs):
+        """jobs: list of (partial_ws, rows, H, dgamma, dbeta) tensors."""
+        from ._lib import LnFinalizeJob
+        n = len(jobs)
+        arr = (LnFinalizeJob * n)()
+        self._keep = jobs
+        for i, (wsb, rows, H, dg, db) in enumerate(jobs):
+            arr[i].ws, arr[i].dgamma, arr[i].dbeta, arr[i].rows, arr[i].H = wsb.data_ptr(), dg.data_ptr(), db.data_ptr(), rows, H
+        self.jobs = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(jobs[0][0].device)
+        self.n, self.max_h = n, max(j[2] for j in jobs)
+
+    def launch(self):
+        check(_lib.load().r3d_layernorm_bwd_finalize_batched(_p(self.jobs), self.n, self.max_h, _stream()),
+              "r3d_layernorm_bwd_finalize_batched")
+
+
 # ----------------------------------------------------------------------------------------------------------
 # row-wise
 # ----------------------------------------------------------------------------------------------------------

@@ -143,6 +143,52 @@ def test_gemm_tn_fused_bias_grad(ops):
         assert_close(dW.cpu(), dY.double().t() @ Xp, 1e-4, 1e-3, "dW with b_add")
 
 
+def test_gemm_grouped_matches_individual(ops):
+    shapes = [(200, 70, 96), (64, 18, 128), (256, 512, 128), (33, 40, 50)]          # (Kc, M, N) of TN problems
+    probs, refs = [], []
+    for i, (Kc, M, N) in enumerate(shapes):
+        dY, X = rnd(Kc, M, seed=10 + i), rnd(Kc, N, seed=20 + i)
+        add = rnd(8, N, seed=30 + i) if i % 2 == 0 else None
+        pr = dict(a=dev(dY), b=dev(X), c=torch.full((M, N), float("nan"), device="cuda"),
+                  bias_grad=torch.full((M,), float("nan"), device="cuda") if i != 3 else None,
+                  b_add=dev(add) if add is not None else None, b_add_mod=8)
+        probs.append(pr)
+        Xp = X.double() + (add.double()[torch.arange(Kc) % 8] if add is not None else 0)
+        refs.append((dY.double().t() @ Xp, dY.double().sum(0)))
+    for tile in (1, 2):
+        for pr in probs:
+            pr["c"].fill_(float("nan"))
+        grp = ops.GemmGroup(2, probs, tile=tile)
+        grp.launch()
+        torch.cuda.synchronize()
+        for pr, (rw, rb) in zip(probs, refs):
+            assert_close(pr["c"].cpu(), rw, 1e-4, 1e-3, f"grouped dW tile{tile}")
+            if pr["bias_grad"] is not None:
+                assert_close(pr["bias_grad"].cpu(), rb, 1e-4, 1e-4, "grouped db")
+
+
+def test_layernorm_deferred_and_batched_finalize(ops):
+    jobs, refs = [], []
+    for i, (rows, H) in enumerate([(256, 128), (64, 128), (3, 128)]):
+        x, g, b, dy = rnd(rows, H, seed=i), 1 + 0.2 * rnd(H, seed=i + 5), 0.1 * rnd(H, seed=i + 9), rnd(rows, H, seed=i + 13)
+        xr = x.double().requires_grad_(True)
+        gr, br = g.double().requires_grad_(True), b.double().requires_grad_(True)
+        F.layer_norm(xr, (H,), gr, br, 1e-5).backward(dy.double())
+        yd, mean, rstd = torch.empty(rows, H, device="cuda"), torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
+        ops.layernorm_fwd(dev(x), dev(g), dev(b), yd, mean, rstd)
+        part = torch.empty(max(ops.layernorm_bwd_ws_floats(rows, H), 4), device="cuda")
+        dx, dg, db = torch.empty(rows, H, device="cuda"), torch.full((H,), float("nan"), device="cuda"), torch.full((H,), float("nan"), device="cuda")
+        ops.layernorm_bwd(dev(dy), dev(x), mean, rstd, dev(g), dev(b), dx, dg, db, partial=part)
+        jobs.append((part, rows, H, dg, db))
+        refs.append((xr.grad, gr.grad, br.grad, dx))
+    ops.LnFinalizeGroup(jobs).launch()
+    torch.cuda.synchronize()
+    for (part, rows, H, dg, db), (rx, rg, rb, dx) in zip(jobs, refs):
+        assert_close(dx.cpu(), rx, 1e-3, 1e-4, "dx")
+        assert_close(dg.cpu(), rg, 1e-3, 1e-3, f"batched dgamma rows={rows}")
+        assert_close(db.cpu(), rb, 1e-3, 1e-3, f"batched dbeta rows={rows}")
+
+
 def test_add_rowbcast(ops):
     x, add = rnd(24, 40, seed=1), rnd(8, 40, seed=2)
     out = torch.empty(24, 40, device="cuda")
