@@ -243,9 +243,13 @@ struct Stage {
 // ---------------------------------------------------------------------------------------------------------
 // one output tile of one problem
 // ---------------------------------------------------------------------------------------------------------
-template <int LA, int LB, int BM, int BN, int BK, int WM, int WN>
+// WK > 1 (only with WM = WN = 1): the WK waves of the workgroup share ONE 32x32 output tile and split every k-step
+// between them (intra-workgroup split-K, reduced through LDS at the end).  The step's many tiny GEMMs have fewer tiles
+// than the chip has CUs; what they need is more loads in flight and a shorter MFMA chain per wave, not more tiles.
+template <int LA, int LB, int BM, int BN, int BK, int WM, int WN, int WK>
 __device__ __forceinline__ void gemm_body(const r3d_gemm_desc& d, int tile, int split, float* smem) {
-    constexpr int NT = 64 * WM * WN;
+    static_assert(WK == 1 || (WM == 1 && WN == 1), "k-split waves share a single 32x32 tile");
+    constexpr int NT = 64 * WM * WN * WK;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int SA = BM + (LA == 0 ? 2 : 4);
     constexpr int SB = BN + (LB == 0 ? 2 : 4);
@@ -265,9 +269,11 @@ __device__ __forceinline__ void gemm_body(const r3d_gemm_desc& d, int tile, int 
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int wm_off = (wave / WN) * (BM / WM);
-    const int wn_off = (wave % WN) * (BN / WN);
+    const int wm_off = (WK > 1) ? 0 : (wave / WN) * (BM / WM);
+    const int wn_off = (WK > 1) ? 0 : (wave % WN) * (BN / WN);
     const int l31 = lane & 31, lhi = lane >> 5;
+    constexpr int KK_PER_WAVE = BK / 2 / WK;
+    const int kk0 = (WK > 1) ? wave * KK_PER_WAVE : 0;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -282,8 +288,8 @@ __device__ __forceinline__ void gemm_body(const r3d_gemm_desc& d, int tile, int 
 
     auto compute = [&](const float* as, const float* bs) {
 #pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
-            const int kr = kk * 2 + lhi;
+        for (int kq = 0; kq < KK_PER_WAVE; ++kq) {
+            const int kr = (kk0 + kq) * 2 + lhi;
             float a[TM], b[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -320,6 +326,24 @@ __device__ __forceinline__ void gemm_body(const r3d_gemm_desc& d, int tile, int 
         ++kt;
     }
 
+    if (WK > 1) {
+        // reduce the WK partial accumulators (and bias-gradient sums) into wave 0 through LDS (staging buffers are free:
+        // the loop ended with a barrier)
+        float* red = smem;                                  // [WK][17][64]
+        if (wave > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[(wave * 17 + r) * 64 + lane] = acc[0][0][r];
+            red[(wave * 17 + 16) * 64 + lane] = asum[0];
+        }
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int w = 1; w < WK; ++w) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][0][r] += red[(w * 17 + r) * 64 + lane];
+            asum[0] += red[(w * 17 + 16) * 64 + lane];
+        }
+    }
     if (LA == 1 && d.bias_grad && n0 == 0 && wn_off == 0) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -340,16 +364,16 @@ constexpr int gemm_lds_floats() {
     return 2 * (BK * (BM + (LA == 0 ? 2 : 4)) + BK * (BN + (LB == 0 ? 2 : 4)));
 }
 
-template <int LA, int LB, int BM, int BN, int BK, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const r3d_gemm_desc d) {
+template <int LA, int LB, int BM, int BN, int BK, int WM, int WN, int WK>
+__global__ __launch_bounds__(64 * WM * WN * WK) void gemm_f32_kernel(const r3d_gemm_desc d) {
     __shared__ __attribute__((aligned(16))) float smem[gemm_lds_floats<LA, LB, BM, BN, BK>()];
-    gemm_body<LA, LB, BM, BN, BK, WM, WN>(d, blockIdx.x, blockIdx.y, smem);
+    gemm_body<LA, LB, BM, BN, BK, WM, WN, WK>(d, blockIdx.x, blockIdx.y, smem);
 }
 
 // Many independent problems (same layout and tile config, splitk == 1) in one launch.  prefix[p] = first workgroup
 // of problem p, prefix[n] = grid size; descriptors live in device memory (uploaded once per shape by the host).
-template <int LA, int LB, int BM, int BN, int BK, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_grouped_kernel(const r3d_gemm_desc* __restrict__ descs,
+template <int LA, int LB, int BM, int BN, int BK, int WM, int WN, int WK>
+__global__ __launch_bounds__(64 * WM * WN * WK) void gemm_grouped_kernel(const r3d_gemm_desc* __restrict__ descs,
                                                                     const int* __restrict__ prefix, int n) {
     __shared__ __attribute__((aligned(16))) float smem[gemm_lds_floats<LA, LB, BM, BN, BK>()];
     int lo = 0, hi = n;                      // largest p with prefix[p] <= blockIdx.x
@@ -357,7 +381,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_grouped_kernel(const r3d_ge
         const int mid = (lo + hi) >> 1;
         if (prefix[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
     }
-    gemm_body<LA, LB, BM, BN, BK, WM, WN>(descs[lo], (int)blockIdx.x - prefix[lo], 0, smem);
+    gemm_body<LA, LB, BM, BN, BK, WM, WN, WK>(descs[lo], (int)blockIdx.x - prefix[lo], 0, smem);
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const r3d_gemm_desc d, int nsplit) {
@@ -374,10 +398,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const r3d_gemm_desc 
 // ---------------------------------------------------------------------------------------------------------
 static const int kTileSz[4] = {0, 32, 64, 128};
 
-template <int LA, int LB, int BM, int BN, int BK, int WM, int WN>
+template <int LA, int LB, int BM, int BN, int BK, int WM, int WN, int WK>
 static int launch_cfg(const r3d_gemm_desc& d, int nsplit, hipStream_t s) {
     dim3 grid(r3d_cdiv(d.M, BM) * r3d_cdiv(d.N, BN), nsplit, 1);
-    hipLaunchKernelGGL((gemm_f32_kernel<LA, LB, BM, BN, BK, WM, WN>), grid, dim3(64 * WM * WN), 0, s, d);
+    hipLaunchKernelGGL((gemm_f32_kernel<LA, LB, BM, BN, BK, WM, WN, WK>), grid, dim3(64 * WM * WN * WK), 0, s, d);
     R3D_LAUNCH_CHECK();
     return R3D_OK;
 }
@@ -385,9 +409,9 @@ static int launch_cfg(const r3d_gemm_desc& d, int nsplit, hipStream_t s) {
 template <int LA, int LB>
 static int launch_layout(const r3d_gemm_desc& d, int nsplit, hipStream_t s) {
     switch (d.tile) {
-        case 1: return launch_cfg<LA, LB, 32, 32, 64, 1, 1>(d, nsplit, s);
-        case 2: return launch_cfg<LA, LB, 64, 64, 64, 2, 2>(d, nsplit, s);
-        case 3: return launch_cfg<LA, LB, 128, 128, 32, 2, 2>(d, nsplit, s);
+        case 1: return launch_cfg<LA, LB, 32, 32, 64, 1, 1, 4>(d, nsplit, s);
+        case 2: return launch_cfg<LA, LB, 64, 64, 64, 2, 2, 1>(d, nsplit, s);
+        case 3: return launch_cfg<LA, LB, 128, 128, 32, 2, 2, 1>(d, nsplit, s);
         default: return R3D_EINVAL;
     }
 }
@@ -396,10 +420,10 @@ template <int LA, int LB>
 static int launch_grouped(const r3d_gemm_desc* descs, const int* prefix, int n, int total, int tile, hipStream_t s) {
     switch (tile) {
         case 1:
-            hipLaunchKernelGGL((gemm_grouped_kernel<LA, LB, 32, 32, 64, 1, 1>), dim3(total), dim3(64), 0, s, descs, prefix, n);
+            hipLaunchKernelGGL((gemm_grouped_kernel<LA, LB, 32, 32, 64, 1, 1, 4>), dim3(total), dim3(256), 0, s, descs, prefix, n);
             break;
         case 2:
-            hipLaunchKernelGGL((gemm_grouped_kernel<LA, LB, 64, 64, 64, 2, 2>), dim3(total), dim3(256), 0, s, descs, prefix, n);
+            hipLaunchKernelGGL((gemm_grouped_kernel<LA, LB, 64, 64, 64, 2, 2, 1>), dim3(total), dim3(256), 0, s, descs, prefix, n);
             break;
         default: return R3D_EINVAL;
     }
@@ -455,9 +479,9 @@ R3D_EXPORT int64_t r3d_gemm_partial_floats(int32_t M, int32_t N, int32_t splitk)
 // tiles_m times), more splits add slab traffic.
 R3D_EXPORT int r3d_gemm_plan(r3d_gemm_desc* d) {
     if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0) return R3D_EINVAL;
-    static const int tile_waves[4] = {0, 1, 4, 4};
+    static const int tile_waves[4] = {0, 4, 4, 4};
     static const int tile_bk[4] = {0, 64, 64, 32};
-    static const double mfma_us_per_step[4] = {0, 0.9, 0.9, 1.8};    // MFMA time of one k-step of one wave
+    static const double mfma_us_per_step[4] = {0, 0.25, 0.9, 1.8};    // MFMA time of one k-step of one wave
     const double flops = 2.0 * d->M * d->N * (double)d->K;
     double best = 1e300;
     int bt = 1, bs = 1, bk = d->K;
