@@ -5,11 +5,11 @@
 // exact fp32 fma chain at the f32 vector peak (157 TFLOP/s) with 1 operand VGPR per lane per 4096 FLOP.
 //
 // Tile scheme (per workgroup):  BM x BN output, BK k per step, waves laid out WM x WN, each wave owning
-// (BM/WM) x (BN/WN) as 32x32 MFMA tiles.  Both operands are staged into LDS K-MAJOR ([k][m] and [k][n]); an MFMA
-// fragment read is then 32 consecutive floats per half-wave (ds_read_b32, conflict-free) whatever the global layout:
-//   - a K-contiguous global operand (nn.Linear weights / activations in NT) is loaded as float4 along k and
-//     transposed by 4 ds_write_b32 (row stride = tile+2 floats);
-//   - an M/N-contiguous operand (NN's B, TN's A and B) is copied with float4 loads + ds_write_b128 (stride tile+4).
+// (BM/WM) x (BN/WN) as 32x32 MFMA tiles, operands staged through LDS:
+//   - a K-contiguous global operand (nn.Linear weights / activations in NT) keeps its layout in LDS ([rows][BK+4]);
+//     one ds_read_b128 then feeds FOUR MFMAs (the k order inside a step is permuted identically on both operands);
+//   - an M/N-contiguous operand (NN's B, TN's A and B) is staged k-major ([BK][cols+4]) and read with ds_read_b32.
+//   Both are copied with float4 global loads + ds_write_b128: no transposing scalar writes, no LDS bank conflicts.
 // Software pipeline: global loads run TWO k-steps ahead of the MFMAs in two named register stages (the step is
 // latency-bound: a 64-deep step is ~1 us of MFMA against ~2 us of HBM latency), LDS is double-buffered, one
 // barrier per step.  Out-of-range rows / columns / k are zero-filled, so any M, N, K works; the float4 path needs
@@ -161,17 +161,14 @@ struct StageKC {
             v[p] = x;
         }
     }
-    // LDS image [BK][R + 2]
+    // LDS image [R][BK + 4] (row-major like the source: no transpose on the way in, one ds_write_b128 per float4)
     __device__ __forceinline__ void store(float* __restrict__ s) const {
-        constexpr int S = R + 2;
+        constexpr int S = BK + 4;
 #pragma unroll
         for (int p = 0; p < NLD; ++p) {
             const int f = threadIdx.x + p * NT;
             const int row = f / Q4, kq = (f % Q4) << 2;
-            s[(kq + 0) * S + row] = v[p].x;
-            s[(kq + 1) * S + row] = v[p].y;
-            s[(kq + 2) * S + row] = v[p].z;
-            s[(kq + 3) * S + row] = v[p].w;
+            *reinterpret_cast<float4*>(s + row * S + kq) = v[p];
         }
     }
 };
@@ -251,9 +248,13 @@ __device__ __forceinline__ void gemm_body(const r3d_gemm_desc& d, int tile, int 
     static_assert(WK == 1 || (WM == 1 && WN == 1), "k-split waves share a single 32x32 tile");
     constexpr int NT = 64 * WM * WN * WK;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int SA = BM + (LA == 0 ? 2 : 4);
-    constexpr int SB = BN + (LB == 0 ? 2 : 4);
-    constexpr int A_FLOATS = BK * SA, B_FLOATS = BK * SB;
+    // LDS images: K-contiguous operand -> [rows][BK+4] (fragment = one ds_read_b128 of 4 consecutive k, conflict-free:
+    // row stride 68 floats puts the 16 lanes of a b128 group on 16 distinct 16-byte slots);
+    // M/N-contiguous operand -> [BK][cols+4] (fragment = ds_read_b32 of 32 consecutive floats).
+    constexpr int SA = (LA == 0) ? BK + 4 : BM + 4;
+    constexpr int SB = (LB == 0) ? BK + 4 : BN + 4;
+    constexpr int A_FLOATS = (LA == 0) ? BM * SA : BK * SA;
+    constexpr int B_FLOATS = (LB == 0) ? BN * SB : BK * SB;
     static_assert(A_FLOATS % 4 == 0 && B_FLOATS % 4 == 0, "LDS carve must stay 16-byte aligned");
     float* As0 = smem;
     float* As1 = smem + A_FLOATS;
@@ -272,8 +273,9 @@ __device__ __forceinline__ void gemm_body(const r3d_gemm_desc& d, int tile, int 
     const int wm_off = (WK > 1) ? 0 : (wave / WN) * (BM / WM);
     const int wn_off = (WK > 1) ? 0 : (wave % WN) * (BN / WN);
     const int l31 = lane & 31, lhi = lane >> 5;
-    constexpr int KK_PER_WAVE = BK / 2 / WK;
-    const int kk0 = (WK > 1) ? wave * KK_PER_WAVE : 0;
+    constexpr int G_PER_WAVE = BK / 8 / WK;             // groups of 8 k (4 MFMAs) per wave and k-step
+    static_assert(G_PER_WAVE >= 1, "BK too small for the k-split");
+    const int g0 = (WK > 1) ? wave * G_PER_WAVE : 0;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -286,23 +288,44 @@ __device__ __forceinline__ void gemm_body(const r3d_gemm_desc& d, int tile, int 
 #pragma unroll
     for (int i = 0; i < TM; ++i) asum[i] = 0.f;
 
+    // One group = 8 consecutive k.  MFMA t of a group (t = 0..3) contracts k = 8g + 4*(lane>>5) + t on BOTH operands:
+    // the k order inside a step is permuted (any order is a valid dot product) so that a K-contiguous operand feeds
+    // four MFMAs from one 16-byte LDS read.
     auto compute = [&](const float* as, const float* bs) {
 #pragma unroll
-        for (int kq = 0; kq < KK_PER_WAVE; ++kq) {
-            const int kr = (kk0 + kq) * 2 + lhi;
-            float a[TM], b[TN];
+        for (int gq = 0; gq < G_PER_WAVE; ++gq) {
+            const int kb = (g0 + gq) * 8 + 4 * lhi;
+            float a[TM][4], b[TN][4];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                a[i] = as[kr * SA + wm_off + i * 32 + l31];
-                if (LA == 1) asum[i] += a[i];
+                if (LA == 0) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(as + (wm_off + i * 32 + l31) * SA + kb);
+                    a[i][0] = t4.x; a[i][1] = t4.y; a[i][2] = t4.z; a[i][3] = t4.w;
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        a[i][t] = as[(kb + t) * SA + wm_off + i * 32 + l31];
+                        asum[i] += a[i][t];
+                    }
+                }
             }
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = bs[kr * SB + wn_off + j * 32 + l31];
+            for (int j = 0; j < TN; ++j) {
+                if (LB == 0) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(bs + (wn_off + j * 32 + l31) * SB + kb);
+                    b[j][0] = t4.x; b[j][1] = t4.y; b[j][2] = t4.z; b[j][3] = t4.w;
+                } else {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                    for (int t = 0; t < 4; ++t) b[j][t] = bs[(kb + t) * SB + wn_off + j * 32 + l31];
+                }
+            }
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
         }
     };
 
@@ -361,7 +384,7 @@ __device__ __forceinline__ void gemm_body(const r3d_gemm_desc& d, int tile, int 
 
 template <int LA, int LB, int BM, int BN, int BK>
 constexpr int gemm_lds_floats() {
-    return 2 * (BK * (BM + (LA == 0 ? 2 : 4)) + BK * (BN + (LB == 0 ? 2 : 4)));
+    return 2 * ((LA == 0 ? BM * (BK + 4) : BK * (BM + 4)) + (LB == 0 ? BN * (BK + 4) : BK * (BN + 4)));
 }
 
 template <int LA, int LB, int BM, int BN, int BK, int WM, int WN, int WK>
