@@ -379,8 +379,9 @@ def normalize_duration(x, mask):
     return F.normalize(torch.exp(x) * mask, p=1, dim=-1)
 
 
-def losses(out, past_label, trans_dur_future, trans_future_target, pad_idx):
-    """The loss composition of train_proposed_depth.py:139-213.  Returns dict of scalars + counts."""
+def losses(out, past_label, trans_dur_future, trans_future_target, pad_idx, dur_den=None):
+    """The loss composition of train_proposed_depth.py:139-213.  Returns dict of scalars + counts.
+    dur_den overrides the duration-loss denominator (data-parallel shards use global mask sum / world size)."""
     B = trans_dur_future.shape[0]
     dur_mask = (trans_dur_future != pad_idx).long()
     target_dur = trans_dur_future * dur_mask
@@ -399,7 +400,7 @@ def losses(out, past_label, trans_dur_future, trans_future_target, pad_idx):
     total = total + l_act
     od = normalize_duration(out["duration"], dur_mask)
     td = target_dur * dur_mask
-    l_dur = torch.sum((od - td) ** 2) / torch.sum(dur_mask)
+    l_dur = torch.sum((od - td) ** 2) / (torch.sum(dur_mask) if dur_den is None else dur_den)
     total = total + l_dur
     res.update(loss_seg=l_seg, loss_action=l_act, loss_dur=l_dur, loss=total)
     return res

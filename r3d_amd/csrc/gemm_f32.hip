@@ -521,12 +521,12 @@ R3D_EXPORT int r3d_gemm_plan(r3d_gemm_desc* d) {
             const double occ = (double)waves / (1024.0 * rounds);                 // SIMD fill
             const int steps = r3d_cdiv(kps, tile_bk[t]);
             // a step is MFMA-bound only when a SIMD has other waves to run while one waits on HBM (~2 us)
-            const double lat = occ < 0.5 ? 2.0 : 1.2;
+            const double lat = occ < 0.5 ? 0.7 : 0.5;        // measured with the depth-2 prefetch
             const double step_us = mfma_us_per_step[t] > lat ? mfma_us_per_step[t] : lat;
             // operand re-fetch through L2 at ~10 TB/s aggregate, HBM once at ~5 TB/s
             const double l2_us = 4.0 * ((double)d->M * d->K * tn + (double)d->N * d->K * tm) / 10.0e6;
             const double hbm_us = 4.0 * ((double)d->M * d->K + (double)d->N * d->K) / 5.0e6;
-            const double slab_us = (ns > 1) ? 5.0 + 2.0 * 4.0 * ns * (double)d->M * d->N / 4.0e6 : 0.0;
+            const double slab_us = (ns > 1) ? 7.0 + 2.0 * 4.0 * ns * (double)d->M * d->N / 4.0e6 : 0.0;   // extra launch
             const double mfma_us = flops / 140.0e6 / (occ < 1.0 ? occ : 1.0);
             double t_us = rounds * steps * step_us + 3.0;
             if (t_us < l2_us) t_us = l2_us;
