@@ -40,18 +40,27 @@ __global__ __launch_bounds__(64) void mha_fwd_kernel(const MhaArgs a) {
     const int Lq = a.Lq, Lk = a.Lk, dh = a.dh;
     float* qs = lds;                       // [Lq][dh]
     float* sc = qs + Lq * dh;              // [Lq][Lk]
-    float* kc = sc + Lq * Lk;              // [64][dh+1]
+    float* kc = sc + Lq * Lk;              // [64][dh+1]  K chunk
+    float* vc = kc + 64 * (dh + 1);        // [64][dh+1]  V chunk
+    float* keep = vc + 64 * (dh + 1);      // [Lq][Lk]    dropout keep * 1/(1-p)  (1 when dropout is off)
     const float* qb = a.q + (size_t)b * Lq * a.ldq + h * dh;
     const float* kb = a.k + (size_t)b * Lk * a.ldk + h * dh;
     const float* vb = a.v + (size_t)b * Lk * a.ldv + h * dh;
+    const size_t pbase = ((size_t)(b * a.heads + h) * Lq) * Lk;
+    const bool single = Lk <= 64;          // one chunk: q, K and V are all fetched in ONE memory round trip
     for (int e = lane; e < Lq * dh; e += 64) {
         const int i = e / dh, d = e - i * dh;
         qs[e] = qb[(size_t)i * a.ldq + d];
     }
+    for (int e = lane; e < Lq * Lk; e += 64) keep[e] = a.drop ? a.drop_scale * (float)a.drop[pbase + e] : 1.f;
+    if (single) {
+        load_chunk(kc, kb, a.ldk, 0, Lk, dh, lane);
+        load_chunk(vc, vb, a.ldv, 0, Lk, dh, lane);
+    }
     for (int c0 = 0; c0 < Lk; c0 += 64) {
         const int nrows = min(64, Lk - c0);
         __syncthreads();
-        load_chunk(kc, kb, a.ldk, c0, nrows, dh, lane);
+        if (!single) load_chunk(kc, kb, a.ldk, c0, nrows, dh, lane);
         __syncthreads();
         const int j = c0 + lane;
         if (j < Lk) {
@@ -65,7 +74,6 @@ __global__ __launch_bounds__(64) void mha_fwd_kernel(const MhaArgs a) {
         }
     }
     __syncthreads();
-    const size_t pbase = ((size_t)(b * a.heads + h) * Lq) * Lk;
     for (int i = 0; i < Lq; ++i) {
         float m = -INFINITY;
         for (int j = lane; j < Lk; j += 64) m = fmaxf(m, sc[i * Lk + j]);
@@ -80,7 +88,7 @@ __global__ __launch_bounds__(64) void mha_fwd_kernel(const MhaArgs a) {
         for (int j = lane; j < Lk; j += 64) {
             const float p = sc[i * Lk + j] / sum;
             a.probs[pbase + (size_t)i * Lk + j] = p;
-            sc[i * Lk + j] = a.drop ? p * a.drop_scale * (float)a.drop[pbase + (size_t)i * Lk + j] : p;
+            sc[i * Lk + j] = p * keep[i * Lk + j];
         }
     }
     // O = P_dropped . V : output element e = i*dh + d lives in lane e % 64, slot e / 64
@@ -90,7 +98,7 @@ __global__ __launch_bounds__(64) void mha_fwd_kernel(const MhaArgs a) {
     for (int c0 = 0; c0 < Lk; c0 += 64) {
         const int nrows = min(64, Lk - c0);
         __syncthreads();
-        load_chunk(kc, vb, a.ldv, c0, nrows, dh, lane);
+        if (!single) load_chunk(vc, vb, a.ldv, c0, nrows, dh, lane);
         __syncthreads();
 #pragma unroll
         for (int t = 0; t < MAXE; ++t) {
@@ -98,7 +106,7 @@ __global__ __launch_bounds__(64) void mha_fwd_kernel(const MhaArgs a) {
             if (e < Lq * dh) {
                 const int i = e / dh, d = e - i * dh;
                 float s = 0.f;
-                for (int r = 0; r < nrows; ++r) s += sc[i * Lk + c0 + r] * kc[r * (dh + 1) + d];
+                for (int r = 0; r < nrows; ++r) s += sc[i * Lk + c0 + r] * vc[r * (dh + 1) + d];
                 acc[t] += s;
             }
         }
@@ -123,31 +131,40 @@ __global__ __launch_bounds__(64) void mha_bwd_kernel(const MhaArgs a) {
     float* dos = qs + Lq * dh;             // [Lq][dh]
     float* P = dos + Lq * dh;              // [Lq][Lk]  softmax probs, later the dropped probs
     float* dS = P + Lq * Lk;               // [Lq][Lk]
-    float* kc = dS + Lq * Lk;              // [64][dh+1]
+    float* kc = dS + Lq * Lk;              // [64][dh+1]  K chunk
+    float* vc = kc + 64 * (dh + 1);        // [64][dh+1]  V chunk
+    float* keep = vc + 64 * (dh + 1);      // [Lq][Lk]    dropout keep * 1/(1-p)
     const float* qb = a.q + (size_t)b * Lq * a.ldq + h * dh;
     const float* kb = a.k + (size_t)b * Lk * a.ldk + h * dh;
     const float* vb = a.v + (size_t)b * Lk * a.ldv + h * dh;
     const float* dob = a.d_o + (size_t)b * Lq * a.lddo + h * dh;
     const size_t pbase = ((size_t)(b * a.heads + h) * Lq) * Lk;
+    const bool single = Lk <= 64;          // one chunk: every operand is fetched in ONE memory round trip
     for (int e = lane; e < Lq * dh; e += 64) {
         const int i = e / dh, d = e - i * dh;
         qs[e] = qb[(size_t)i * a.ldq + d];
         dos[e] = dob[(size_t)i * a.lddo + d];
     }
-    for (int e = lane; e < Lq * Lk; e += 64) P[e] = a.probs[pbase + e];
+    for (int e = lane; e < Lq * Lk; e += 64) {
+        P[e] = a.probs[pbase + e];
+        keep[e] = a.drop ? a.drop_scale * (float)a.drop[pbase + e] : 1.f;
+    }
+    if (single) {
+        load_chunk(vc, vb, a.ldv, 0, Lk, dh, lane);
+        load_chunk(kc, kb, a.ldk, 0, Lk, dh, lane);
+    }
     // dP = (dO . V^T) o keep*scale
     for (int c0 = 0; c0 < Lk; c0 += 64) {
         const int nrows = min(64, Lk - c0);
         __syncthreads();
-        load_chunk(kc, vb, a.ldv, c0, nrows, dh, lane);
+        if (!single) load_chunk(vc, vb, a.ldv, c0, nrows, dh, lane);
         __syncthreads();
         const int j = c0 + lane;
         if (j < Lk)
             for (int i = 0; i < Lq; ++i) {
                 float s = 0.f;
-                for (int d = 0; d < dh; ++d) s += dos[i * dh + d] * kc[lane * (dh + 1) + d];
-                if (a.drop) s *= a.drop_scale * (float)a.drop[pbase + (size_t)i * Lk + j];
-                dS[i * Lk + j] = s;
+                for (int d = 0; d < dh; ++d) s += dos[i * dh + d] * vc[lane * (dh + 1) + d];
+                dS[i * Lk + j] = s * keep[i * Lk + j];
             }
     }
     __syncthreads();
@@ -159,7 +176,7 @@ __global__ __launch_bounds__(64) void mha_bwd_kernel(const MhaArgs a) {
         for (int j = lane; j < Lk; j += 64) {
             const float p = P[i * Lk + j];
             dS[i * Lk + j] = p * (dS[i * Lk + j] - t) * a.scale;
-            if (a.drop) P[i * Lk + j] = p * a.drop_scale * (float)a.drop[pbase + (size_t)i * Lk + j];
+            P[i * Lk + j] = p * keep[i * Lk + j];
         }
     }
     // dq = dS . K ; dk = dS^T . q ; dv = P_dropped^T . dO   -- K chunk by chunk through LDS
@@ -169,7 +186,7 @@ __global__ __launch_bounds__(64) void mha_bwd_kernel(const MhaArgs a) {
     for (int c0 = 0; c0 < Lk; c0 += 64) {
         const int nrows = min(64, Lk - c0);
         __syncthreads();
-        load_chunk(kc, kb, a.ldk, c0, nrows, dh, lane);
+        if (!single) load_chunk(kc, kb, a.ldk, c0, nrows, dh, lane);
         __syncthreads();
 #pragma unroll
         for (int t = 0; t < MAXE; ++t) {
@@ -203,7 +220,7 @@ __global__ __launch_bounds__(64) void mha_bwd_kernel(const MhaArgs a) {
 }
 
 static size_t mha_lds_bytes(int Lq, int Lk, int dh, bool bwd) {
-    size_t f = (size_t)Lq * dh + (size_t)Lq * Lk + (size_t)64 * (dh + 1);
+    size_t f = (size_t)Lq * dh + (size_t)2 * Lq * Lk + (size_t)2 * 64 * (dh + 1);
     if (bwd) f += (size_t)Lq * dh + (size_t)Lq * Lk;
     return f * sizeof(float);
 }

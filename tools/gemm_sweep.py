@@ -1,48 +1,52 @@
 #!/usr/bin/env python3
-"""Times r3d_gemm_f32 over (tile, splitk) for the step's dominant shapes on the GPU box (tuning aid)."""
-import sys, os, json, itertools
+"""Times r3d_gemm_f32 over (tile, splitk) for the step's dominant shapes on the GPU box (tuning aid).
+Each configuration is captured into a hipGraph of 10 launches and replayed, so host launch cost does not pollute
+the small shapes."""
+import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from r3d_amd import ops
 
-def timeit(fn, iters=20, warm=3):
-    for _ in range(warm): fn()
-    torch.cuda.synchronize()
+def time_graph(fn, reps=10, replays=5):
+    fn(); torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(reps): fn()
+    g.replay(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(iters): fn()
+    for _ in range(replays): g.replay()
     e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters * 1e3   # us
+    return e0.elapsed_time(e1) / (reps * replays) * 1e3   # us
 
 def main():
     ws = ops.GemmWorkspace("cuda")
-    shapes = [("depth_fwd_cfg2", 0, 128, 128, 50176), ("depth_wgrad_cfg2", 2, 128, 50176, 128),
-              ("rgb_fwd_cfg2", 0, 128, 128, 2048), ("rgb_wgrad_cfg2", 2, 128, 2048, 128),
-              ("fuser_fc1_cfg2", 0, 256, 512, 128), ("fuser_fc2_cfg2", 0, 256, 128, 512),
-              ("depth_fwd_cfg4", 0, 512, 512, 50176), ("depth_wgrad_cfg4", 2, 512, 50176, 512)]
-    if len(sys.argv) > 1:
-        shapes = [s for s in shapes if s[0] in sys.argv[1:]]
+    ws.get(64 * 1024 * 1024)
+    shapes = {"depth_fwd_cfg2": (0, 128, 128, 50176), "depth_wgrad_cfg2": (2, 128, 50176, 128),
+              "rgb_fwd_cfg2": (0, 128, 128, 2048), "fuser_fc1_cfg2": (0, 256, 512, 128), "fuser_fc2_cfg2": (0, 256, 128, 512),
+              "dec_64x128x128": (0, 64, 128, 128), "depth_fwd_cfg4": (0, 512, 512, 50176), "depth_wgrad_cfg4": (2, 512, 50176, 512)}
+    names = sys.argv[1:] or list(shapes)
     out = {}
-    for name, layout, M, N, K in shapes:
+    for name in names:
+        layout, M, N, K = shapes[name]
         sa = (M, K) if layout in (0, 1) else (K, M)
         sb = (N, K) if layout == 0 else (K, N)
         A = torch.randn(*sa, device="cuda"); B = torch.randn(*sb, device="cuda"); Cm = torch.empty(M, N, device="cuda")
         res = []
         d = ops.gemm(layout, A, B, Cm, ws=ws)
-        t = timeit(lambda: ops.gemm(layout, A, B, Cm, ws=ws))
-        res.append(("auto", d.tile, d.splitk, round(t, 2)))
+        res.append(("auto", d.tile, d.splitk, round(time_graph(lambda: ops.gemm(layout, A, B, Cm, ws=ws)), 2)))
         for tile in (1, 2, 3):
-            for sk in (1, 2, 4, 8, 16, 32, 49, 64, 98, 128):
-                if sk > 1 and K // sk < 64: continue
+            for sk in (1, 2, 4, 8, 16, 32, 49, 61, 64, 98, 122, 128, 196, 256):
+                if sk > 1 and K // sk < 128: continue
                 if sk == 1 and K > 8192 and (M * N) // (32 * 32 * (4 ** (tile - 1))) < 64: continue
                 try:
-                    t = timeit(lambda: ops.gemm(layout, A, B, Cm, ws=ws, tile=tile, splitk=sk), iters=10, warm=2)
+                    t = time_graph(lambda: ops.gemm(layout, A, B, Cm, ws=ws, tile=tile, splitk=sk, defer_reduce=True))
                 except Exception as e:
                     continue
                 res.append((tile, sk, round(t, 2)))
         flops = 2.0 * M * N * K
-        best = min(res[1:], key=lambda r: r[-1])
-        print(f"{name}: auto={res[0]} best(tile,splitk,us)={best} -> {flops / best[-1] / 1e6:.1f} TFLOP/s", flush=True)
+        best = sorted(res[1:], key=lambda r: r[-1])[:5]
+        print(f"{name}: auto(with reduce)={res[0]} best GEMM-only (tile,splitk,us)={best} -> {flops / best[0][-1] / 1e6:.1f} TFLOP/s", flush=True)
         out[name] = res
     os.makedirs("gpurun_out", exist_ok=True)
     json.dump(out, open("gpurun_out/gemm_sweep.json", "w"))
