@@ -120,6 +120,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eval-dropout-off", action="store_true", help="bench the eval()-state step (dropout off)")
     ap.add_argument("--no-side-stream", action="store_true", help="keep the query self-attention branch on the main stream")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the "
+                                                      "multi-rank control flow on one GPU)")
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -127,11 +129,15 @@ def main():
     if a.gpus != world:
         if world == 1 and a.gpus > 1:
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(a.backend)
     c = CFG
     model = build_model(c, device)
     if a.eval_dropout_off:
@@ -150,13 +156,11 @@ def main():
         if dp is not None:
             dp.prepare_duration_denominator(dur, c["K"] + 1)
         eng.forward(feats, depth, lab, "train", training)
-        if eng.last["drop"]:
-            eng.drop_offset.add_(1)
         eng.losses(lab, tgt, dur)
         eng.backward()
         if dp is not None:
             dp.wait_grads()
-        eng.adamw(c["lr"], c["wd"], grad_scale=gscale)
+        eng.adamw(c["lr"], c["wd"], grad_scale=gscale, tick_dropout=eng.last["drop"])
 
     for _ in range(3):
         step_eager()
@@ -176,14 +180,12 @@ def main():
                 g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g1):
                     eng.forward(feats, depth, lab, "train", training)
-                    if eng.last["drop"]:
-                        eng.drop_offset.add_(1)
                     eng.losses(lab, tgt, dur)
                     eng.backward_main()
                 with torch.cuda.graph(g2):
                     eng.backward_depth_wgrad()
                 with torch.cuda.graph(g3):
-                    eng.adamw(c["lr"], c["wd"], grad_scale=gscale)
+                    eng.adamw(c["lr"], c["wd"], grad_scale=gscale, tick_dropout=training)
                 eng.grad_hook = hook
 
                 def run_step():

@@ -142,6 +142,11 @@ int r3d_colsum(const float* x, int ld, int rows, int cols, float* out, float* ws
 int r3d_rowmod_sum(const float* x, int ld, int rows, int cols, int mod, float* out, int ldo, int accumulate,
                    void* stream);
 
+/* Batched form: job j writes dst[r,:] = sum over rows with row % mod == r of (src1 [+ src2]); mod == 1 is a bias gradient. */
+typedef struct r3d_rowsum_job { const float* src1; const float* src2; float* dst; int32_t ld1, ld2, ldd, rows, cols, mod; } r3d_rowsum_job;
+int r3d_rowmod_sum_batched(const r3d_rowsum_job* dev_jobs, int njobs, int max_cols, int max_mod, void* stream);
+/* ++*a, ++*b (either may be NULL): step counter and dropout offset in one launch. */
+int r3d_tick(int64_t* a, int64_t* b, void* stream);
 /* out[r,:] = x[r,:] + add[r % mod,:]: with_pos_embed (model/extras/transformer.py:278-279,289,300-302); x may be NULL. */
 int r3d_add_rowbcast(const float* x, int ldx, const float* add, int ldadd, int mod, float* out, int ldo, int rows, int cols,
                      void* stream);

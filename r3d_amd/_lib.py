@@ -34,6 +34,12 @@ class GemmDesc(C.Structure):
     ]
 
 
+class RowsumJob(C.Structure):
+    """struct r3d_rowsum_job"""
+    _fields_ = [("src1", C.c_void_p), ("src2", C.c_void_p), ("dst", C.c_void_p), ("ld1", C.c_int32), ("ld2", C.c_int32),
+                ("ldd", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32), ("mod", C.c_int32)]
+
+
 class LnFinalizeJob(C.Structure):
     """struct r3d_ln_finalize_job"""
     _fields_ = [("ws", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("rows", C.c_int32), ("H", C.c_int32)]
@@ -62,6 +68,8 @@ _SIGNATURES = {
     "r3d_colsum_ws_floats": ([_I, _I], C.c_int64),
     "r3d_colsum": ([_P, _I, _I, _I, _P, _P, _I, _P], C.c_int),
     "r3d_rowmod_sum": ([_P, _I, _I, _I, _I, _P, _I, _I, _P], C.c_int),
+    "r3d_rowmod_sum_batched": ([_P, _I, _I, _I, _P], C.c_int),
+    "r3d_tick": ([_P, _P, _P], C.c_int),
     "r3d_colabssum": ([_P, _I, _I, _I, _P, _P], C.c_int),
     "r3d_token_select": ([_P, _P, _D, _I, _I, _I, _P, _P, _P, _P], C.c_int),
     "r3d_token_exchange_fwd": ([_P, _P, _P, _P, _P, _P, _F, _I, _I, _P], C.c_int),

@@ -258,6 +258,27 @@ __global__ __launch_bounds__(256) void add_rowbcast_kernel(const float* x, int l
     }
 }
 
+// Batched version: job j sums up to two sources over rows with (row % mod) == r into out[r, :].  mod == 1 is a column
+// sum (bias gradient).  One launch covers every broadcast-parameter / bias gradient left at the end of the backward.
+__global__ __launch_bounds__(256) void rowmod_sum_batched_kernel(const r3d_rowsum_job* jobs) {
+    const r3d_rowsum_job j = jobs[blockIdx.z];
+    const int r = blockIdx.y;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (r >= j.mod || c >= j.cols) return;
+    float s = 0.f;
+    for (int row = r; row < j.rows; row += j.mod) s += j.src1[(size_t)row * j.ld1 + c];
+    if (j.src2)
+        for (int row = r; row < j.rows; row += j.mod) s += j.src2[(size_t)row * j.ld2 + c];
+    j.dst[(size_t)r * j.ldd + c] = s;
+}
+
+__global__ void tick_kernel(int64_t* a, int64_t* b) {
+    if (threadIdx.x == 0) {
+        if (a) *a += 1;
+        if (b) *b += 1;
+    }
+}
+
 template <typename K, typename A>
 static int launch_epl(K k32, K k16, K k8, K k2, int H, dim3 grid, size_t shmem, hipStream_t s, const A& a) {
     if (H <= 128) hipLaunchKernelGGL(k2, grid, dim3(256), shmem, s, a);
@@ -394,6 +415,22 @@ R3D_EXPORT int r3d_layernorm_bwd_finalize_batched(const r3d_ln_finalize_job* dev
     R3D_REQUIRE(dev_jobs && njobs > 0 && max_H > 0 && max_H <= 2048);
     hipLaunchKernelGGL(ln_param_finalize_batched_kernel, dim3(r3d_cdiv(2 * max_H, 64), njobs), dim3(256), 0,
                        (hipStream_t)stream, dev_jobs);
+    R3D_LAUNCH_CHECK();
+    return R3D_OK;
+}
+
+R3D_EXPORT int r3d_rowmod_sum_batched(const r3d_rowsum_job* dev_jobs, int njobs, int max_cols, int max_mod, void* stream) {
+    R3D_REQUIRE(dev_jobs && njobs > 0 && max_cols > 0 && max_mod > 0);
+    hipLaunchKernelGGL(rowmod_sum_batched_kernel, dim3(r3d_cdiv(max_cols, 256), max_mod, njobs), dim3(256), 0,
+                       (hipStream_t)stream, dev_jobs);
+    R3D_LAUNCH_CHECK();
+    return R3D_OK;
+}
+
+/* ++*a, ++*b (either may be NULL): the step counter and the dropout offset, one launch. */
+R3D_EXPORT int r3d_tick(int64_t* a, int64_t* b, void* stream) {
+    R3D_REQUIRE(a || b);
+    hipLaunchKernelGGL(tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, b);
     R3D_LAUNCH_CHECK();
     return R3D_OK;
 }

@@ -403,6 +403,10 @@ class FusionEngine:
             for k in (1, 2, 3):
                 J.append((w.lnp[f"d{k}_{l}"], BQ, H, a.g(pl + f"norm{k}.weight"), a.g(pl + f"norm{k}.bias")))
         w.ln_group = ops.LnFinalizeGroup(J)
+        R = [(w.d_fused, None, S, a.g("pos_embedding")[0, :S]),
+             (w.d_dep_pre, None, 1, a.g("depth_projection.bias").view(1, H)),
+             (w.glayers[self.L - 1]["caqin"], w.glayers[self.L - 1]["sain"], Q, a.g("query_embed.weight"))]
+        w.rowsum_group = ops.RowsumGroup(R)
 
     def backward_main(self, d_seg=None, d_actdur=None):
         """Everything of the backward except depth_projection.weight.
@@ -503,31 +507,28 @@ class FusionEngine:
         w.wgrad_group.launch()
         w.ln_group.launch()
         ops.gemm(GEMM_TN, w.d_rgb_pre, st["x_rgb"], a.g("input_embed.weight"), bias_grad=a.g("input_embed.bias"), ws=ws)
+        w.rowsum_group.launch()            # pos_embedding (:190), depth_projection.bias, query_embed (top layer)
         g_qe = a.g("query_embed.weight")
-        for i, l in enumerate(reversed(range(self.L))):
+        for l in reversed(range(self.L - 1)):                       # stacked decoders: remaining layers accumulate
             gl = w.glayers[l]
-            ops.rowmod_sum(gl["caqin"], Q, g_qe, accumulate=i > 0)
+            ops.rowmod_sum(gl["caqin"], Q, g_qe, accumulate=True)
             ops.rowmod_sum(gl["sain"], Q, g_qe, accumulate=True)
-        ops.rowmod_sum(w.d_fused, S, a.g("pos_embedding")[0, :S])
-        ops.colsum(w.d_dep_pre, a.g("depth_projection.bias"), ws=ws)
 
     # ------------------------------------------------------------------------------------------------------
-    def adamw(self, lr, weight_decay, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
+    def adamw(self, lr, weight_decay, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0, tick_dropout=False):
         """One fused launch over the live prefix of the arena (main_darai.py:135; train_proposed_depth.py:215)."""
         a = self.arena
         if self._lr_host != float(lr):          # lr lives in device memory so a captured graph sees scheduler updates
             self.lr_t.fill_(float(lr))
             self._lr_host = float(lr)
-        self.step_t.add_(1)
+        ops.tick(self.step_t, self.drop_offset if tick_dropout else None)
         ops.adamw_flat(a.params[:a.n_live], a.grads, a.exp_avg, a.exp_avg_sq, self.lr_t, self.step_t, beta1=betas[0],
                        beta2=betas[1], eps=eps, weight_decay=weight_decay, grad_scale=grad_scale)
 
     def train_step(self, feats, depth, past_label, target_dur, target, lr, weight_decay, training=True):
         """forward + losses + backward + AdamW, all enqueued, no host sync.  Returns (loss[4], counts[4]) on device."""
         self.forward(feats, depth, past_label, "train", training)
-        if self.last["drop"]:
-            self.drop_offset.add_(1)
         loss, counts = self.losses(past_label, target, target_dur)
         self.backward()
-        self.adamw(lr, weight_decay)
+        self.adamw(lr, weight_decay, tick_dropout=self.last["drop"])
         return loss, counts

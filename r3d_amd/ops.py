@@ -166,6 +166,35 @@ class GemmGroup:
                                                   _stream()), "r3d_gemm_grouped_launch")
 
 
+class RowsumGroup:
+    """Bias / broadcast-parameter gradient sums in one launch (r3d_rowmod_sum_batched)."""
+
+    def __init__(self, jobs):
+        """jobs: list of (src1, src2 or None, mod, dst) 2-D tensors; dst is [mod, cols]."""
+        from ._lib import RowsumJob
+        n = len(jobs)
+        arr = (RowsumJob * n)()
+        self._keep = jobs
+        for i, (s1, s2, mod, dst) in enumerate(jobs):
+            rows, cols = s1.shape
+            assert tuple(dst.shape) == (mod, cols) and (s2 is None or s2.shape == s1.shape)
+            arr[i].src1, arr[i].src2, arr[i].dst = s1.data_ptr(), (s2.data_ptr() if s2 is not None else None), dst.data_ptr()
+            arr[i].ld1, arr[i].ld2, arr[i].ldd = _ld(s1), (_ld(s2) if s2 is not None else 0), _ld(dst)
+            arr[i].rows, arr[i].cols, arr[i].mod = rows, cols, mod
+        self.jobs = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(jobs[0][0].device)
+        self.n = n
+        self.max_cols = max(j[0].shape[1] for j in jobs)
+        self.max_mod = max(j[2] for j in jobs)
+
+    def launch(self):
+        check(_lib.load().r3d_rowmod_sum_batched(_p(self.jobs), self.n, self.max_cols, self.max_mod, _stream()),
+              "r3d_rowmod_sum_batched")
+
+
+def tick(a, b=None):
+    check(_lib.load().r3d_tick(_p(a), _p(b), _stream()), "r3d_tick")
+
+
 class LnFinalizeGroup:
     """All deferred LayerNorm parameter-gradient reductions of a step in one launch."""
 

@@ -117,20 +117,20 @@ def train(args, model, train_loader, optimizer, scheduler, criterion, model_save
             if dp is not None:
                 dp.prepare_duration_denominator(trans_dur_future, pad_idx)
             eng.forward(features, depth_features, past_label, "train", training=model.training)
-            if eng.last["drop"]:
-                eng.drop_offset.add_(1)
             loss, counts = eng.losses(past_label, trans_future_target, trans_dur_future)
             eng.backward()
             if dp is not None:
                 dp.wait_grads()
             if isinstance(optimizer, FlatAdamW):
                 eng.adamw(g["lr"], g["weight_decay"], betas=g["betas"], eps=g["eps"],
-                          grad_scale=dp.grad_scale if dp is not None else 1.0)
+                          grad_scale=dp.grad_scale if dp is not None else 1.0, tick_dropout=eng.last["drop"])
             else:                                   # any other torch optimiser: expose the arena gradients to it
                 if dp is not None:
                     eng.arena.grads.mul_(dp.grad_scale)
                 eng.arena.attach_grads(core.named_parameters())
                 optimizer.step()
+                if eng.last["drop"]:
+                    eng.drop_offset.add_(1)
             acc_loss += loss
             acc_cnt += counts
             n_steps += 1
