@@ -180,6 +180,25 @@ int r3d_mha_core_bwd(const float* q, int ldq, const float* k, int ldk, const flo
                      const uint8_t* drop_mask, float drop_scale, const float* d_o, int lddo, float* dq, int lddq, float* dk,
                      int lddk, float* dv, int lddv, int B, int heads, int Lq, int Lk, int dh, void* stream);
 
+/* ---- fused decoder layer, one workgroup per clip (TransformerDecoderLayer.forward_post, model/extras/transformer.py:
+ * 281-330; final decoder.norm :182-183; fc|fc_len head futr_safuser_tokenfusion.py:219-226) --------------------------
+ * Replaces ~17 dependent launches per layer by one.  Supported when one clip's layer fits a CU's LDS
+ * (r3d_decoder_fused_supported); otherwise the host composes the layer from the GEMM / attention / LayerNorm entry points.
+ * ptrs[R3D_DEC_FWD_NPTRS], in this order (N = optional, may be NULL):
+ *   0-17  parameters: self_attn.in_proj_weight, .in_proj_bias, .out_proj.weight, .out_proj.bias, norm1.weight, norm1.bias,
+ *         multihead_attn.in_proj_weight, .in_proj_bias, .out_proj.weight, .out_proj.bias, norm2.weight, norm2.bias,
+ *         linear1.weight, linear1.bias, linear2.weight, linear2.bias, norm3.weight, norm3.bias
+ *   18 memory [B*S,H]   19 pos [S,H]   20 query_pos [Q,H]   21 tgt_in [B*Q,H] (N: layer 0, tgt = 0)
+ *   22 key_label int64 [B*S] (N)       23-28 dropout keep masks uint8 (N): sa_p, ca_p, d1, d2, d3, ff
+ *   29-48 saved activations (outputs): sa_qkv [BQ,3H], p_sa [B,h,Q,Q], sa_o, t1_pre, t1 [BQ,H], m1, r1 [BQ], caq [BQ,H],
+ *         cakv [B*S,2H], p_ca [B,h,Q,S], ca_o, t2_pre, t2 [BQ,H], m2, r2 [BQ], ff1 [BQ,4H], t3_pre, t3 [BQ,H], m3, r3 [BQ]
+ *   49-56 tail of the last layer (all N together): decoder.norm.weight, .bias, tgtF [BQ,H], mF, rF [BQ],
+ *         head weight [n_head_out,H], head bias [n_head_out], actdur [BQ,n_head_out] */
+#define R3D_DEC_FWD_NPTRS 57
+int r3d_decoder_fused_supported(int S, int Q, int H, int heads);
+int r3d_decoder_layer_fwd(const void* const* ptrs, int nptrs, int B, int S, int Q, int H, int heads, int pad_idx,
+                          float drop_scale, int n_head_out, void* stream);
+
 /* ---- losses: utils.py:325-328,358-378,410-490 as composed at train/train_proposed_depth.py:171-213 ------------- */
 int r3d_losses_fwd_bwd(const float* seg_logits, int ld_seg, const float* act_logits, int ld_act, const float* dur,
                        int ld_dur, const int64_t* past_label, const int64_t* target, const float* target_dur, int B, int S,

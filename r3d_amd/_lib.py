@@ -77,6 +77,8 @@ _SIGNATURES = {
     "r3d_mha_core_fwd": ([_P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P, _F, _P, _I, _I, _I, _I, _I, _I, _P], C.c_int),
     "r3d_mha_core_bwd": ([_P, _I, _P, _I, _P, _I, _P, _P, _F, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
                          C.c_int),
+    "r3d_decoder_fused_supported": ([_I, _I, _I, _I], C.c_int),
+    "r3d_decoder_layer_fwd": ([_P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P], C.c_int),
     "r3d_losses_fwd_bwd": ([_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _F, _P, _I, _P, _I,
                             _P, _I, _P, _P, _P, _P], C.c_int),
     "r3d_losses_ws_floats": ([_I, _I, _I], C.c_int64),

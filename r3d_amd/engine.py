@@ -124,6 +124,7 @@ class _Shape:
         self.actdur = f(BQ, K + 1)
         self.seg = f(N, K)
         self.loss = f(4)
+        self.tables = {}
         self.loss_ws = f(4 * (N + BQ + B))
         self.counts = torch.zeros(4, dtype=torch.int64, device=dev)
         if train:
@@ -174,6 +175,7 @@ class FusionEngine:
         self.side2 = torch.cuda.Stream(self.device)     # independent branch (self-attention of the queries)
         self.ws_side2 = ops.GemmWorkspace(self.device)
         self.use_side_stream = True
+        self.use_fused_decoder = True           # one workgroup per clip and layer (decoder.hip) when the shape fits LDS
         self.shapes = {}
         self.train_mask = None            # cached train-mode selection (data independent)
         self.drop_seed = 0x5EED
@@ -258,11 +260,15 @@ class FusionEngine:
             wi, bi = a.p(pl + "multihead_attn.in_proj_weight"), a.p(pl + "multihead_attn.in_proj_bias")
             ops.gemm(GEMM_NT, c["t1"], wi[:H], c["caq"], a_add=qpos, a_add_mod=Q, bias=bi[:H], ws=wsx)
 
-        # ---- branch s1: RGB embedding (:179-183);  branch s2: layer-0 query self-attention;  main: depth embedding
+        fused_dec = self.use_fused_decoder and ops.decoder_fused_supported(S, Q, H, heads)
+        if fused_dec:
+            multi = False                     # the whole layer is one launch: nothing left to branch
+        # ---- branch s2: layer-0 query self-attention (depends on parameters only);  main: the embeddings
         if multi:
             s2.wait_stream(main)
-        with torch.cuda.stream(s2):
-            sa_block(0, w.tgt0, ws2)
+        if not fused_dec:
+            with torch.cuda.stream(s2):
+                sa_block(0, w.tgt0, ws2)
         ops.gemm(GEMM_NT, x_rgb, a.p("input_embed.weight"), w.rgb, bias=a.p("input_embed.bias"), act=1, ws=self.ws)
         d = ops.gemm(GEMM_NT, x_dep, a.p("depth_projection.weight"), w.dep_pre, bias=a.p("depth_projection.bias"),
                      ws=self.ws, defer_reduce=True)                              # (:194-195)
@@ -301,6 +307,18 @@ class FusionEngine:
         # ---- segmentation head (:228-232)
         ops.gemm(GEMM_NT, w.fused, a.p("fc_seg.weight"), w.seg, bias=a.p("fc_seg.bias"), ws=self.ws)
         # ---- decoder (transformer.py:75-128,161-191,281-330); memory = fused, encoder bypassed (:77-78)
+        if fused_dec:
+            self._decoder_fused(w, key_labels, drop, dsc)
+        else:
+            self._decoder_unfused(w, key_labels, dm, dsc, multi, main, s2, sa_block)
+        self.last = dict(w=w, x_rgb=x_rgb, x_dep=x_dep, mask=mask, idx=idx, drop=drop, mode=mode)
+        return dict(seg=w.seg.view(B, S, K), action=w.actdur[:, :K].view(B, Q, K), duration=w.actdur[:, K].view(B, Q))
+
+    def _decoder_unfused(self, w, key_labels, dm, dsc, multi, main, s2, sa_block):
+        """The decoder composed from the GEMM / attention / LayerNorm entry points (any shape)."""
+        a, H, Q, K, heads, dh = self.arena, self.H, self.Q, self.K, self.heads, self.dh
+        B, S, N, BQ = w.B, w.S, w.N, w.BQ
+        pos = a.p("pos_embedding")[0, :S]
         tgt = None
         for l in range(self.L):
             c, pl = w.layers[l], f"transformer.decoder.layers.{l}."
@@ -328,8 +346,39 @@ class FusionEngine:
                           w.mF, w.rF)
         # ---- anticipation heads (:219-226): fc and fc_len as one [K+1, H] GEMM
         ops.gemm(GEMM_NT, w.tgtF, self.w_head, w.actdur, bias=self.b_head, ws=self.ws)
-        self.last = dict(w=w, x_rgb=x_rgb, x_dep=x_dep, mask=mask, idx=idx, drop=drop, mode=mode)
-        return dict(seg=w.seg.view(B, S, K), action=w.actdur[:, :K].view(B, Q, K), duration=w.actdur[:, K].view(B, Q))
+
+    def _decoder_fused(self, w, key_labels, drop, dsc):
+        """One launch per decoder layer (decoder.hip): a workgroup keeps one clip's layer in LDS."""
+        a, H, Q, K, heads = self.arena, self.H, self.Q, self.K, self.heads
+        B, S = w.B, w.S
+        key = ("dec_fwd", bool(drop))
+        if key not in w.tables:
+            tabs = []
+            for l in range(self.L):
+                c, pl = w.layers[l], f"transformer.decoder.layers.{l}."
+                p = lambda n: a.p(pl + n)         # noqa: E731
+                dk = (lambda k: w.drop[k]) if drop else (lambda k: None)
+                last = l == self.L - 1
+                t = [p("self_attn.in_proj_weight"), p("self_attn.in_proj_bias"), p("self_attn.out_proj.weight"),
+                     p("self_attn.out_proj.bias"), p("norm1.weight"), p("norm1.bias"), p("multihead_attn.in_proj_weight"),
+                     p("multihead_attn.in_proj_bias"), p("multihead_attn.out_proj.weight"), p("multihead_attn.out_proj.bias"),
+                     p("norm2.weight"), p("norm2.bias"), p("linear1.weight"), p("linear1.bias"), p("linear2.weight"),
+                     p("linear2.bias"), p("norm3.weight"), p("norm3.bias"),
+                     w.fused, a.p("pos_embedding")[0, :S], a.p("query_embed.weight"),
+                     None if l == 0 else w.layers[l - 1]["t3"], None,
+                     dk(f"sa_p{l}"), dk(f"ca_p{l}"), dk(f"d1_{l}"), dk(f"d2_{l}"), dk(f"d3_{l}"), dk(f"ff_{l}"),
+                     c["sa_qkv"], c["p_sa"], c["sa_o"], c["t1_pre"], c["t1"], c["m1"], c["r1"], c["caq"], c["cakv"], c["p_ca"],
+                     c["ca_o"], c["t2_pre"], c["t2"], c["m2"], c["r2"], c["ff1"], c["t3_pre"], c["t3"], c["m3"], c["r3"]]
+                if last:
+                    t += [a.p("transformer.decoder.norm.weight"), a.p("transformer.decoder.norm.bias"), w.tgtF, w.mF, w.rF,
+                          self.w_head, self.b_head, w.actdur]
+                else:
+                    t += [None] * 8
+                tabs.append(ops.PtrTable(t))
+            w.tables[key] = tabs
+        for l, tab in enumerate(w.tables[key]):
+            tab.arr[22] = key_labels.data_ptr() if key_labels is not None else None
+            ops.decoder_layer_fwd(tab, B, S, Q, H, heads, self.pad_idx, dsc, K + 1)
 
     @staticmethod
     def _dm2(m, rows, cols):

@@ -333,6 +333,27 @@ def mha_core_bwd(q, k, v, probs, d_o, dq, dk, dv, B, heads, Lq, Lk, dh, *, drop_
 
 
 # ----------------------------------------------------------------------------------------------------------
+# fused decoder layer
+# ----------------------------------------------------------------------------------------------------------
+def decoder_fused_supported(S, Q, H, heads):
+    return bool(_lib.load().r3d_decoder_fused_supported(S, Q, H, heads))
+
+
+class PtrTable:
+    """A fixed array of device pointers (None -> NULL) for the entry points that take `const void* const*`."""
+
+    def __init__(self, tensors):
+        self._keep = tensors
+        self.n = len(tensors)
+        self.arr = (C.c_void_p * self.n)(*[(t.data_ptr() if t is not None else None) for t in tensors])
+
+
+def decoder_layer_fwd(table, B, S, Q, H, heads, pad_idx, drop_scale, n_head_out):
+    check(_lib.load().r3d_decoder_layer_fwd(table.arr, table.n, B, S, Q, H, heads, pad_idx, drop_scale, n_head_out, _stream()),
+          "r3d_decoder_layer_fwd")
+
+
+# ----------------------------------------------------------------------------------------------------------
 # losses / optimiser / dropout / erank
 # ----------------------------------------------------------------------------------------------------------
 def losses_fwd_bwd(seg, act, dur, ld_dur, past_label, target, target_dur, B, S, Q, K, pad_idx, exclude_idx, loss_out,

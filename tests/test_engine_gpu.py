@@ -166,3 +166,30 @@ def test_dropout_training_mode_statistics():
     loss, _ = eng.train_step(d[0], d[1], d[2], d[3], d[4], 1e-3, 5e-3, training=True)
     torch.cuda.synchronize()
     assert torch.isfinite(loss).all()
+
+
+@pytest.mark.parametrize("tag,training", [("step_tiny", False), ("step_cfg2", False), ("step_k122_dec2", False), ("step_cfg2", True)])
+def test_fused_decoder_equals_composed_decoder(tag, training):
+    """decoder.hip (one workgroup per clip) against the same layer composed from GEMM / attention / LayerNorm launches,
+    with identical dropout masks when training."""
+    fx = load_fixture(tag)
+    m = fx["meta"]
+    model = build_model(fx)
+    model.train(training)
+    eng = model.engine()
+    d = [t.cuda() for t in fixture_batch(fx)]
+    outs, acts = [], []
+    for fused in (False, True):
+        eng.use_fused_decoder = fused
+        out = eng.forward(d[0], d[1], d[2], "train", training=training)      # same drop_offset -> same masks
+        torch.cuda.synchronize()
+        w = eng.last["w"]
+        outs.append({k: v.clone() for k, v in out.items()})
+        acts.append([{k: v.clone() for k, v in layer.items()} for layer in w.layers] + [dict(tgtF=w.tgtF.clone())])
+    from r3d_amd import ops
+    assert ops.decoder_fused_supported(m["S"], m["n_query"], m["H"], m["n_head"])
+    for k in outs[0]:
+        close_rel(outs[1][k], outs[0][k], f"{tag}/{k} fused vs composed", rtol=2e-5)
+    for la, lb in zip(acts[0], acts[1]):
+        for k in la:
+            close_rel(lb[k], la[k], f"{tag}/act {k}", rtol=5e-5)
