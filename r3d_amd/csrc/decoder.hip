@@ -19,7 +19,8 @@ namespace r3d {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int DEC_THREADS = 256;
+constexpr int DEC_THREADS = 1024;     // 16 waves: the layer is a chain of latency-bound phases -- the weights stream
+                                      // from L2 per k-step, so what matters is loads in flight, not FLOPs per wave
 constexpr float kLnEpsD = 1e-5f;
 
 // ---- Y[16 x N] = X[16 x K] . W[N x K]^T : epi(row, col, value) for every element of the 16 x N result ------------
@@ -35,7 +36,7 @@ __device__ __forceinline__ void mm16_nt(const float* X, int ldx, int K, const fl
         const float* wrow = W + (size_t)(nok ? n : 0) * ldw + 4 * kq;
         const float* xrow = X + i * ldx + 4 * kq;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
+#pragma unroll 8
         for (int k0 = 0; k0 < K; k0 += 16) {
             const float4 a = *reinterpret_cast<const float4*>(xrow + k0);
             float4 b = *reinterpret_cast<const float4*>(wrow + k0);
@@ -65,7 +66,7 @@ __device__ __forceinline__ void mm16_nn(const float* dY, int ldy, int N, const f
         const bool kok = kc < K;
         const float* yrow = dY + i * ldy + 4 * kq;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
+#pragma unroll 4
         for (int n0 = 0; n0 < N; n0 += 16) {
             const float4 a = *reinterpret_cast<const float4*>(yrow + n0);
             const float* wp = W + (size_t)(n0 + 4 * kq) * ldw + (kok ? kc : 0);

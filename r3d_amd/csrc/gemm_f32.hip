@@ -128,37 +128,68 @@ __device__ __forceinline__ void gemm_epilogue_tile(const r3d_gemm_desc& d, const
 // staging: one register stage of a tile (two of them are alive in the pipeline)
 // ---------------------------------------------------------------------------------------------------------
 // K-contiguous source: tile of R rows x BK k.  f indexes float4s: row = f/(BK/4), kq = f%(BK/4).
-template <int R, int BK, int NT>
+template <int R, int BK, int NT, bool VEC>
 struct StageKC {
     static constexpr int Q4 = BK / 4;
     static constexpr int NLD = (R * Q4) / NT;
     static_assert(NLD >= 1 && (R * Q4) % NT == 0, "tile too small for the workgroup");
     float4 v[NLD];
+    // VEC: every load is an UNCONDITIONAL 16-byte load from a clamped (always valid) address, zeroed by a select when
+    // the element is outside the tile.  A load under a lane-dependent branch makes hipcc wait vmcnt(0) right behind it,
+    // which serialises the memory round trips of the whole tile (seen in the ISA: one s_waitcnt vmcnt(0) per load).
     __device__ __forceinline__ void load(const float* __restrict__ base, int ld, int row0, int rows_total, int k0,
-                                         int k_end, bool vec, int row_xor, const float* add, int add_mod, int add_ld) {
+                                         int k_end, int k_total, int row_xor, const float* add, int add_mod, int add_ld) {
+        if (VEC) {
+            // all loads of the stage back to back (first the operand, then -- under ONE uniform branch -- the addend)
+#pragma unroll
+            for (int p = 0; p < NLD; ++p) {
+                const int f = threadIdx.x + p * NT;
+                const int row = row0 + f / Q4;
+                const int k = k0 + ((f % Q4) << 2);
+                const int srow = (row < rows_total ? row : 0) ^ row_xor;
+                const int sk = k < k_total - 4 ? k : k_total - 4;
+                v[p] = *reinterpret_cast<const float4*>(base + (size_t)srow * ld + sk);
+            }
+            if (add) {
+                float4 y[NLD];
+#pragma unroll
+                for (int p = 0; p < NLD; ++p) {
+                    const int f = threadIdx.x + p * NT;
+                    const int row = row0 + f / Q4;
+                    const int k = k0 + ((f % Q4) << 2);
+                    const int sk = k < k_total - 4 ? k : k_total - 4;
+                    y[p] = *reinterpret_cast<const float4*>(add + (size_t)((row < rows_total ? row : 0) % add_mod) * add_ld + sk);
+                }
+#pragma unroll
+                for (int p = 0; p < NLD; ++p) { v[p].x += y[p].x; v[p].y += y[p].y; v[p].z += y[p].z; v[p].w += y[p].w; }
+            }
+#pragma unroll
+            for (int p = 0; p < NLD; ++p) {
+                const int f = threadIdx.x + p * NT;
+                const int row = row0 + f / Q4;
+                const int k = k0 + ((f % Q4) << 2);
+                const bool ok = row < rows_total && k < k_end;           // K % 4 == 0: a float4 is all in or all out
+                if (!ok) v[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            return;
+        }
 #pragma unroll
         for (int p = 0; p < NLD; ++p) {
             const int f = threadIdx.x + p * NT;
             const int row = row0 + f / Q4;
             const int k = k0 + ((f % Q4) << 2);
-            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < rows_total && k < k_end) {
-                const float* src = base + (size_t)(row ^ row_xor) * ld + k;
-                if (vec && k + 3 < k_end) {
-                    x = *reinterpret_cast<const float4*>(src);
-                    if (add) {
-                        const float4 y = *reinterpret_cast<const float4*>(add + (size_t)(row % add_mod) * add_ld + k);
-                        x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
-                    }
-                } else {
+            {
+                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row < rows_total && k < k_end) {
+                    const float* src = base + (size_t)(row ^ row_xor) * ld + k;
                     const float* ad = add ? add + (size_t)(row % add_mod) * add_ld + k : nullptr;
                     x.x = src[0] + (ad ? ad[0] : 0.f);
                     if (k + 1 < k_end) x.y = src[1] + (ad ? ad[1] : 0.f);
                     if (k + 2 < k_end) x.z = src[2] + (ad ? ad[2] : 0.f);
                     if (k + 3 < k_end) x.w = src[3] + (ad ? ad[3] : 0.f);
                 }
+                v[p] = x;
             }
-            v[p] = x;
         }
     }
     // LDS image [R][BK + 4] (row-major like the source: no transpose on the way in, one ds_write_b128 per float4)
@@ -174,36 +205,63 @@ struct StageKC {
 };
 
 // M/N-contiguous source: tile of BK k-rows x R columns.  f indexes float4s: krow = f/(R/4), cq = f%(R/4).
-template <int R, int BK, int NT>
+template <int R, int BK, int NT, bool VEC>
 struct StageMC {
     static constexpr int NLD = (R * BK / 4) / NT;
     static_assert(NLD >= 1 && (R * BK / 4) % NT == 0, "tile too small for the workgroup");
     float4 v[NLD];
     __device__ __forceinline__ void load(const float* __restrict__ base, int ld, int col0, int cols_total, int k0,
-                                         int k_end, bool vec, const float* add, int add_mod, int add_ld) {
+                                         int k_end, int k_total, const float* add, int add_mod, int add_ld) {
+        if (VEC) {                                                       // branch-free, see StageKC
+#pragma unroll
+            for (int p = 0; p < NLD; ++p) {
+                const int f = threadIdx.x + p * NT;
+                const int k = k0 + f / (R / 4);
+                const int c = col0 + ((f % (R / 4)) << 2);
+                const int sk = k < k_total ? k : k_total - 1;
+                const int sc = c < cols_total - 4 ? c : cols_total - 4;
+                v[p] = *reinterpret_cast<const float4*>(base + (size_t)sk * ld + sc);
+            }
+            if (add) {                                                   // B'[k,:] = B[k,:] + add[k % mod,:]
+                float4 y[NLD];
+#pragma unroll
+                for (int p = 0; p < NLD; ++p) {
+                    const int f = threadIdx.x + p * NT;
+                    const int k = k0 + f / (R / 4);
+                    const int c = col0 + ((f % (R / 4)) << 2);
+                    const int sk = k < k_total ? k : k_total - 1;
+                    const int sc = c < cols_total - 4 ? c : cols_total - 4;
+                    y[p] = *reinterpret_cast<const float4*>(add + (size_t)(sk % add_mod) * add_ld + sc);
+                }
+#pragma unroll
+                for (int p = 0; p < NLD; ++p) { v[p].x += y[p].x; v[p].y += y[p].y; v[p].z += y[p].z; v[p].w += y[p].w; }
+            }
+#pragma unroll
+            for (int p = 0; p < NLD; ++p) {
+                const int f = threadIdx.x + p * NT;
+                const int k = k0 + f / (R / 4);
+                const int c = col0 + ((f % (R / 4)) << 2);
+                if (!(k < k_end && c < cols_total)) v[p] = make_float4(0.f, 0.f, 0.f, 0.f);   // cols % 4 == 0
+            }
+            return;
+        }
 #pragma unroll
         for (int p = 0; p < NLD; ++p) {
             const int f = threadIdx.x + p * NT;
             const int k = k0 + f / (R / 4);
             const int c = col0 + ((f % (R / 4)) << 2);
-            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (k < k_end && c < cols_total) {
-                const float* src = base + (size_t)k * ld + c;
-                const float* ad = add ? add + (size_t)(k % add_mod) * add_ld + c : nullptr;   // B'[k,:] = B[k,:] + add[k%mod,:]
-                if (vec && c + 3 < cols_total) {
-                    x = *reinterpret_cast<const float4*>(src);
-                    if (ad) {
-                        const float4 y = *reinterpret_cast<const float4*>(ad);
-                        x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
-                    }
-                } else {
+            {
+                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k < k_end && c < cols_total) {
+                    const float* src = base + (size_t)k * ld + c;
+                    const float* ad = add ? add + (size_t)(k % add_mod) * add_ld + c : nullptr;
                     x.x = src[0] + (ad ? ad[0] : 0.f);
                     if (c + 1 < cols_total) x.y = src[1] + (ad ? ad[1] : 0.f);
                     if (c + 2 < cols_total) x.z = src[2] + (ad ? ad[2] : 0.f);
                     if (c + 3 < cols_total) x.w = src[3] + (ad ? ad[3] : 0.f);
                 }
+                v[p] = x;
             }
-            v[p] = x;
         }
     }
     // LDS image [BK][R + 4]
@@ -218,18 +276,17 @@ struct StageMC {
     }
 };
 
-template <int LA, int LB, int BM, int BN, int BK, int NT>
+template <int LA, int LB, int BM, int BN, int BK, int NT, bool VEC>
 struct Stage {
-    StageKC<BM, BK, NT> a_kc;
-    StageMC<BM, BK, NT> a_mc;
-    StageKC<BN, BK, NT> b_kc;
-    StageMC<BN, BK, NT> b_mc;
+    StageKC<BM, BK, NT, VEC> a_kc;
+    StageMC<BM, BK, NT, VEC> a_mc;
+    StageKC<BN, BK, NT, VEC> b_kc;
+    StageMC<BN, BK, NT, VEC> b_mc;
     __device__ __forceinline__ void load(const r3d_gemm_desc& d, int m0, int n0, int k0, int k_end) {
-        const bool vec = d.vec != 0;
-        if (LA == 0) a_kc.load(d.A, d.lda, m0, d.M, k0, k_end, vec, d.a_row_xor, d.a_add, d.a_add_mod, d.a_add_ld);
-        else a_mc.load(d.A, d.lda, m0, d.M, k0, k_end, vec, nullptr, 1, 0);
-        if (LB == 0) b_kc.load(d.B, d.ldb, n0, d.N, k0, k_end, vec, 0, nullptr, 1, 0);
-        else b_mc.load(d.B, d.ldb, n0, d.N, k0, k_end, vec, d.b_add, d.b_add_mod, d.b_add_ld);
+        if (LA == 0) a_kc.load(d.A, d.lda, m0, d.M, k0, k_end, d.K, d.a_row_xor, d.a_add, d.a_add_mod, d.a_add_ld);
+        else a_mc.load(d.A, d.lda, m0, d.M, k0, k_end, d.K, nullptr, 1, 0);
+        if (LB == 0) b_kc.load(d.B, d.ldb, n0, d.N, k0, k_end, d.K, 0, nullptr, 1, 0);
+        else b_mc.load(d.B, d.ldb, n0, d.N, k0, k_end, d.K, d.b_add, d.b_add_mod, d.b_add_ld);
     }
     __device__ __forceinline__ void store(float* as, float* bs) const {
         if (LA == 0) a_kc.store(as); else a_mc.store(as);
@@ -243,7 +300,7 @@ struct Stage {
 // WK > 1 (only with WM = WN = 1): the WK waves of the workgroup share ONE 32x32 output tile and split every k-step
 // between them (intra-workgroup split-K, reduced through LDS at the end).  The step's many tiny GEMMs have fewer tiles
 // than the chip has CUs; what they need is more loads in flight and a shorter MFMA chain per wave, not more tiles.
-template <int LA, int LB, int BM, int BN, int BK, int WM, int WN, int WK>
+template <int LA, int LB, int BM, int BN, int BK, int WM, int WN, int WK, bool VEC>
 __device__ __forceinline__ void gemm_body(const r3d_gemm_desc& d, int tile, int split, float* smem) {
     static_assert(WK == 1 || (WM == 1 && WN == 1), "k-split waves share a single 32x32 tile");
     constexpr int NT = 64 * WM * WN * WK;
@@ -329,7 +386,7 @@ __device__ __forceinline__ void gemm_body(const r3d_gemm_desc& d, int tile, int 
         }
     };
 
-    Stage<LA, LB, BM, BN, BK, NT> st0, st1;
+    Stage<LA, LB, BM, BN, BK, NT, VEC> st0, st1;
     if (nk > 0) st0.load(d, m0, n0, k_begin, k_end);
     if (nk > 1) st1.load(d, m0, n0, k_begin + BK, k_end);
     if (nk > 0) st0.store(As0, Bs0);
@@ -387,10 +444,10 @@ constexpr int gemm_lds_floats() {
     return 2 * ((LA == 0 ? BM * (BK + 4) : BK * (BM + 4)) + (LB == 0 ? BN * (BK + 4) : BK * (BN + 4)));
 }
 
-template <int LA, int LB, int BM, int BN, int BK, int WM, int WN, int WK>
+template <int LA, int LB, int BM, int BN, int BK, int WM, int WN, int WK, bool VEC>
 __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_f32_kernel(const r3d_gemm_desc d) {
     __shared__ __attribute__((aligned(16))) float smem[gemm_lds_floats<LA, LB, BM, BN, BK>()];
-    gemm_body<LA, LB, BM, BN, BK, WM, WN, WK>(d, blockIdx.x, blockIdx.y, smem);
+    gemm_body<LA, LB, BM, BN, BK, WM, WN, WK, VEC>(d, blockIdx.x, blockIdx.y, smem);
 }
 
 // Many independent problems (same layout and tile config, splitk == 1) in one launch.  prefix[p] = first workgroup
@@ -404,7 +461,9 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_grouped_kernel(const r
         const int mid = (lo + hi) >> 1;
         if (prefix[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
     }
-    gemm_body<LA, LB, BM, BN, BK, WM, WN, WK>(descs[lo], (int)blockIdx.x - prefix[lo], 0, smem);
+    const r3d_gemm_desc& d = descs[lo];
+    if (d.vec) gemm_body<LA, LB, BM, BN, BK, WM, WN, WK, true>(d, (int)blockIdx.x - prefix[lo], 0, smem);
+    else gemm_body<LA, LB, BM, BN, BK, WM, WN, WK, false>(d, (int)blockIdx.x - prefix[lo], 0, smem);
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const r3d_gemm_desc d, int nsplit) {
@@ -424,7 +483,8 @@ static const int kTileSz[4] = {0, 32, 64, 128};
 template <int LA, int LB, int BM, int BN, int BK, int WM, int WN, int WK>
 static int launch_cfg(const r3d_gemm_desc& d, int nsplit, hipStream_t s) {
     dim3 grid(r3d_cdiv(d.M, BM) * r3d_cdiv(d.N, BN), nsplit, 1);
-    hipLaunchKernelGGL((gemm_f32_kernel<LA, LB, BM, BN, BK, WM, WN, WK>), grid, dim3(64 * WM * WN * WK), 0, s, d);
+    if (d.vec) hipLaunchKernelGGL((gemm_f32_kernel<LA, LB, BM, BN, BK, WM, WN, WK, true>), grid, dim3(64 * WM * WN * WK), 0, s, d);
+    else hipLaunchKernelGGL((gemm_f32_kernel<LA, LB, BM, BN, BK, WM, WN, WK, false>), grid, dim3(64 * WM * WN * WK), 0, s, d);
     R3D_LAUNCH_CHECK();
     return R3D_OK;
 }
@@ -460,6 +520,10 @@ static int nsplits_of(const r3d_gemm_desc& d) {
 
 static bool gemm_can_vec(const r3d_gemm_desc& d) {
     bool vec = r3d_aligned16(d.A) && r3d_aligned16(d.B) && (d.lda % 4 == 0) && (d.ldb % 4 == 0);
+    // the branch-free 16-byte path needs whole float4s along each operand's contiguous dimension
+    const int a_contig = (d.layout == R3D_GEMM_TN) ? d.M : d.K;
+    const int b_contig = (d.layout == R3D_GEMM_NT) ? d.K : d.N;
+    vec = vec && (a_contig % 4 == 0) && (b_contig % 4 == 0) && a_contig >= 4 && b_contig >= 4;
     if (d.a_add) vec = vec && r3d_aligned16(d.a_add) && (d.a_add_ld % 4 == 0);
     if (d.b_add) vec = vec && r3d_aligned16(d.b_add) && (d.b_add_ld % 4 == 0);
     return vec;
