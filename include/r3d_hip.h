@@ -82,7 +82,8 @@ typedef struct r3d_gemm_desc {
                                  with the weight-gradient GEMM that already streams dY through LDS) */
     int32_t c_row_xor;       /* output (and pre_out/aux/res/drop operand) row index = m ^ c_row_xor: pair swap at store */
     int32_t splitk, k_per_split; float* partial;
-    int32_t tile;            /* 0 = auto; 1 = 32x32, 2 = 64x64, 3 = 128x128 workgroup tile (testing / tuning) */
+    int32_t tile;            /* 0 = auto; workgroup tile: 1 = 32x32 (4 k-split waves), 2 = 64x64, 3 = 128x128,
+                                4 = 64x64 with 2 k-split wave groups, 5 = 128x128 with 2 k-split wave groups */
     int32_t vec;             /* filled by the library: operands allow 16-byte loads */
 } r3d_gemm_desc;
 

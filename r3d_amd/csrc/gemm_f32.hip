@@ -127,80 +127,55 @@ __device__ __forceinline__ void gemm_epilogue_tile(const r3d_gemm_desc& d, const
 // ---------------------------------------------------------------------------------------------------------
 // staging: one register stage of a tile (two of them are alive in the pipeline)
 // ---------------------------------------------------------------------------------------------------------
+// VEC: every load is an UNCONDITIONAL 16-byte load from a clamped (always valid) address; the element is zeroed (and
+// the broadcast addend added) when the piece is written to LDS one step later.  A load under a lane-dependent branch
+// makes hipcc wait vmcnt(0) right behind it, which serialises the memory round trips of the tile (seen in the ISA).
+// Pieces (one float4 per thread each) can be loaded / stored one at a time so the main loop can slot them between
+// MFMA groups.
 // K-contiguous source: tile of R rows x BK k.  f indexes float4s: row = f/(BK/4), kq = f%(BK/4).
 template <int R, int BK, int NT, bool VEC>
 struct StageKC {
     static constexpr int Q4 = BK / 4;
     static constexpr int NLD = (R * Q4) / NT;
     static_assert(NLD >= 1 && (R * Q4) % NT == 0, "tile too small for the workgroup");
-    float4 v[NLD];
-    // VEC: every load is an UNCONDITIONAL 16-byte load from a clamped (always valid) address, zeroed by a select when
-    // the element is outside the tile.  A load under a lane-dependent branch makes hipcc wait vmcnt(0) right behind it,
-    // which serialises the memory round trips of the whole tile (seen in the ISA: one s_waitcnt vmcnt(0) per load).
-    __device__ __forceinline__ void load(const float* __restrict__ base, int ld, int row0, int rows_total, int k0,
-                                         int k_end, int k_total, int row_xor, const float* add, int add_mod, int add_ld) {
+    float4 v[NLD], y[NLD];
+    bool ok[NLD];
+    __device__ __forceinline__ void load_one(int p, const float* __restrict__ base, int ld, int row0, int rows_total,
+                                             int k0, int k_end, int k_total, int row_xor, const float* add, int add_mod,
+                                             int add_ld) {
+        const int f = threadIdx.x + p * NT;
+        const int row = row0 + f / Q4;
+        const int k = k0 + ((f % Q4) << 2);
         if (VEC) {
-            // all loads of the stage back to back (first the operand, then -- under ONE uniform branch -- the addend)
-#pragma unroll
-            for (int p = 0; p < NLD; ++p) {
-                const int f = threadIdx.x + p * NT;
-                const int row = row0 + f / Q4;
-                const int k = k0 + ((f % Q4) << 2);
-                const int srow = (row < rows_total ? row : 0) ^ row_xor;
-                const int sk = k < k_total - 4 ? k : k_total - 4;
-                v[p] = *reinterpret_cast<const float4*>(base + (size_t)srow * ld + sk);
+            const int vrow = row < rows_total ? row : 0;
+            const int sk = k < k_total - 4 ? k : k_total - 4;
+            v[p] = *reinterpret_cast<const float4*>(base + (size_t)(vrow ^ row_xor) * ld + sk);
+            if (add) y[p] = *reinterpret_cast<const float4*>(add + (size_t)(vrow % add_mod) * add_ld + sk);
+            else y[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+            ok[p] = row < rows_total && k < k_end;           // K % 4 == 0: a float4 is all in or all out
+        } else {
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < rows_total && k < k_end) {
+                const float* src = base + (size_t)(row ^ row_xor) * ld + k;
+                const float* ad = add ? add + (size_t)(row % add_mod) * add_ld + k : nullptr;
+                x.x = src[0] + (ad ? ad[0] : 0.f);
+                if (k + 1 < k_end) x.y = src[1] + (ad ? ad[1] : 0.f);
+                if (k + 2 < k_end) x.z = src[2] + (ad ? ad[2] : 0.f);
+                if (k + 3 < k_end) x.w = src[3] + (ad ? ad[3] : 0.f);
             }
-            if (add) {
-                float4 y[NLD];
-#pragma unroll
-                for (int p = 0; p < NLD; ++p) {
-                    const int f = threadIdx.x + p * NT;
-                    const int row = row0 + f / Q4;
-                    const int k = k0 + ((f % Q4) << 2);
-                    const int sk = k < k_total - 4 ? k : k_total - 4;
-                    y[p] = *reinterpret_cast<const float4*>(add + (size_t)((row < rows_total ? row : 0) % add_mod) * add_ld + sk);
-                }
-#pragma unroll
-                for (int p = 0; p < NLD; ++p) { v[p].x += y[p].x; v[p].y += y[p].y; v[p].z += y[p].z; v[p].w += y[p].w; }
-            }
-#pragma unroll
-            for (int p = 0; p < NLD; ++p) {
-                const int f = threadIdx.x + p * NT;
-                const int row = row0 + f / Q4;
-                const int k = k0 + ((f % Q4) << 2);
-                const bool ok = row < rows_total && k < k_end;           // K % 4 == 0: a float4 is all in or all out
-                if (!ok) v[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            return;
-        }
-#pragma unroll
-        for (int p = 0; p < NLD; ++p) {
-            const int f = threadIdx.x + p * NT;
-            const int row = row0 + f / Q4;
-            const int k = k0 + ((f % Q4) << 2);
-            {
-                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (row < rows_total && k < k_end) {
-                    const float* src = base + (size_t)(row ^ row_xor) * ld + k;
-                    const float* ad = add ? add + (size_t)(row % add_mod) * add_ld + k : nullptr;
-                    x.x = src[0] + (ad ? ad[0] : 0.f);
-                    if (k + 1 < k_end) x.y = src[1] + (ad ? ad[1] : 0.f);
-                    if (k + 2 < k_end) x.z = src[2] + (ad ? ad[2] : 0.f);
-                    if (k + 3 < k_end) x.w = src[3] + (ad ? ad[3] : 0.f);
-                }
-                v[p] = x;
-            }
+            v[p] = x;
+            y[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+            ok[p] = true;
         }
     }
     // LDS image [R][BK + 4] (row-major like the source: no transpose on the way in, one ds_write_b128 per float4)
-    __device__ __forceinline__ void store(float* __restrict__ s) const {
+    __device__ __forceinline__ void store_one(int p, float* __restrict__ s) const {
         constexpr int S = BK + 4;
-#pragma unroll
-        for (int p = 0; p < NLD; ++p) {
-            const int f = threadIdx.x + p * NT;
-            const int row = f / Q4, kq = (f % Q4) << 2;
-            *reinterpret_cast<float4*>(s + row * S + kq) = v[p];
-        }
+        const int f = threadIdx.x + p * NT;
+        const int row = f / Q4, kq = (f % Q4) << 2;
+        float4 x = make_float4(v[p].x + y[p].x, v[p].y + y[p].y, v[p].z + y[p].z, v[p].w + y[p].w);
+        if (!ok[p]) x = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(s + row * S + kq) = x;
     }
 };
 
@@ -209,100 +184,93 @@ template <int R, int BK, int NT, bool VEC>
 struct StageMC {
     static constexpr int NLD = (R * BK / 4) / NT;
     static_assert(NLD >= 1 && (R * BK / 4) % NT == 0, "tile too small for the workgroup");
-    float4 v[NLD];
-    __device__ __forceinline__ void load(const float* __restrict__ base, int ld, int col0, int cols_total, int k0,
-                                         int k_end, int k_total, const float* add, int add_mod, int add_ld) {
-        if (VEC) {                                                       // branch-free, see StageKC
-#pragma unroll
-            for (int p = 0; p < NLD; ++p) {
-                const int f = threadIdx.x + p * NT;
-                const int k = k0 + f / (R / 4);
-                const int c = col0 + ((f % (R / 4)) << 2);
-                const int sk = k < k_total ? k : k_total - 1;
-                const int sc = c < cols_total - 4 ? c : cols_total - 4;
-                v[p] = *reinterpret_cast<const float4*>(base + (size_t)sk * ld + sc);
+    float4 v[NLD], y[NLD];
+    bool ok[NLD];
+    __device__ __forceinline__ void load_one(int p, const float* __restrict__ base, int ld, int col0, int cols_total,
+                                             int k0, int k_end, int k_total, const float* add, int add_mod, int add_ld) {
+        const int f = threadIdx.x + p * NT;
+        const int k = k0 + f / (R / 4);
+        const int c = col0 + ((f % (R / 4)) << 2);
+        if (VEC) {
+            const int sk = k < k_total ? k : k_total - 1;
+            const int sc = c < cols_total - 4 ? c : cols_total - 4;
+            v[p] = *reinterpret_cast<const float4*>(base + (size_t)sk * ld + sc);
+            if (add) y[p] = *reinterpret_cast<const float4*>(add + (size_t)(sk % add_mod) * add_ld + sc);   // B'[k,:] += add[k%mod,:]
+            else y[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+            ok[p] = k < k_end && c < cols_total;             // cols % 4 == 0
+        } else {
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < k_end && c < cols_total) {
+                const float* src = base + (size_t)k * ld + c;
+                const float* ad = add ? add + (size_t)(k % add_mod) * add_ld + c : nullptr;
+                x.x = src[0] + (ad ? ad[0] : 0.f);
+                if (c + 1 < cols_total) x.y = src[1] + (ad ? ad[1] : 0.f);
+                if (c + 2 < cols_total) x.z = src[2] + (ad ? ad[2] : 0.f);
+                if (c + 3 < cols_total) x.w = src[3] + (ad ? ad[3] : 0.f);
             }
-            if (add) {                                                   // B'[k,:] = B[k,:] + add[k % mod,:]
-                float4 y[NLD];
-#pragma unroll
-                for (int p = 0; p < NLD; ++p) {
-                    const int f = threadIdx.x + p * NT;
-                    const int k = k0 + f / (R / 4);
-                    const int c = col0 + ((f % (R / 4)) << 2);
-                    const int sk = k < k_total ? k : k_total - 1;
-                    const int sc = c < cols_total - 4 ? c : cols_total - 4;
-                    y[p] = *reinterpret_cast<const float4*>(add + (size_t)(sk % add_mod) * add_ld + sc);
-                }
-#pragma unroll
-                for (int p = 0; p < NLD; ++p) { v[p].x += y[p].x; v[p].y += y[p].y; v[p].z += y[p].z; v[p].w += y[p].w; }
-            }
-#pragma unroll
-            for (int p = 0; p < NLD; ++p) {
-                const int f = threadIdx.x + p * NT;
-                const int k = k0 + f / (R / 4);
-                const int c = col0 + ((f % (R / 4)) << 2);
-                if (!(k < k_end && c < cols_total)) v[p] = make_float4(0.f, 0.f, 0.f, 0.f);   // cols % 4 == 0
-            }
-            return;
-        }
-#pragma unroll
-        for (int p = 0; p < NLD; ++p) {
-            const int f = threadIdx.x + p * NT;
-            const int k = k0 + f / (R / 4);
-            const int c = col0 + ((f % (R / 4)) << 2);
-            {
-                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (k < k_end && c < cols_total) {
-                    const float* src = base + (size_t)k * ld + c;
-                    const float* ad = add ? add + (size_t)(k % add_mod) * add_ld + c : nullptr;
-                    x.x = src[0] + (ad ? ad[0] : 0.f);
-                    if (c + 1 < cols_total) x.y = src[1] + (ad ? ad[1] : 0.f);
-                    if (c + 2 < cols_total) x.z = src[2] + (ad ? ad[2] : 0.f);
-                    if (c + 3 < cols_total) x.w = src[3] + (ad ? ad[3] : 0.f);
-                }
-                v[p] = x;
-            }
+            v[p] = x;
+            y[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+            ok[p] = true;
         }
     }
     // LDS image [BK][R + 4]
-    __device__ __forceinline__ void store(float* __restrict__ s) const {
+    __device__ __forceinline__ void store_one(int p, float* __restrict__ s) const {
         constexpr int S = R + 4;
-#pragma unroll
-        for (int p = 0; p < NLD; ++p) {
-            const int f = threadIdx.x + p * NT;
-            const int krow = f / (R / 4), cq = (f % (R / 4)) << 2;
-            *reinterpret_cast<float4*>(s + krow * S + cq) = v[p];
-        }
+        const int f = threadIdx.x + p * NT;
+        const int krow = f / (R / 4), cq = (f % (R / 4)) << 2;
+        float4 x = make_float4(v[p].x + y[p].x, v[p].y + y[p].y, v[p].z + y[p].z, v[p].w + y[p].w);
+        if (!ok[p]) x = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(s + krow * S + cq) = x;
     }
 };
 
+// Both operands of one k-step.  Piece index q runs over the A pieces (even slots) and B pieces (odd slots) so that a
+// partial [q0, q1) touches both operands evenly.
 template <int LA, int LB, int BM, int BN, int BK, int NT, bool VEC>
 struct Stage {
     StageKC<BM, BK, NT, VEC> a_kc;
     StageMC<BM, BK, NT, VEC> a_mc;
     StageKC<BN, BK, NT, VEC> b_kc;
     StageMC<BN, BK, NT, VEC> b_mc;
+    static constexpr int NA = (LA == 0) ? StageKC<BM, BK, NT, VEC>::NLD : StageMC<BM, BK, NT, VEC>::NLD;
+    static constexpr int NB = (LB == 0) ? StageKC<BN, BK, NT, VEC>::NLD : StageMC<BN, BK, NT, VEC>::NLD;
+    static constexpr int NP = NA + NB;
+    __device__ __forceinline__ void load_piece(int q, const r3d_gemm_desc& d, int m0, int n0, int k0, int k_end) {
+        if (q < NA) {
+            if (LA == 0) a_kc.load_one(q, d.A, d.lda, m0, d.M, k0, k_end, d.K, d.a_row_xor, d.a_add, d.a_add_mod, d.a_add_ld);
+            else a_mc.load_one(q, d.A, d.lda, m0, d.M, k0, k_end, d.K, nullptr, 1, 0);
+        } else {
+            if (LB == 0) b_kc.load_one(q - NA, d.B, d.ldb, n0, d.N, k0, k_end, d.K, 0, nullptr, 1, 0);
+            else b_mc.load_one(q - NA, d.B, d.ldb, n0, d.N, k0, k_end, d.K, d.b_add, d.b_add_mod, d.b_add_ld);
+        }
+    }
+    __device__ __forceinline__ void store_piece(int q, float* as, float* bs) const {
+        if (q < NA) { if (LA == 0) a_kc.store_one(q, as); else a_mc.store_one(q, as); }
+        else { if (LB == 0) b_kc.store_one(q - NA, bs); else b_mc.store_one(q - NA, bs); }
+    }
     __device__ __forceinline__ void load(const r3d_gemm_desc& d, int m0, int n0, int k0, int k_end) {
-        if (LA == 0) a_kc.load(d.A, d.lda, m0, d.M, k0, k_end, d.K, d.a_row_xor, d.a_add, d.a_add_mod, d.a_add_ld);
-        else a_mc.load(d.A, d.lda, m0, d.M, k0, k_end, d.K, nullptr, 1, 0);
-        if (LB == 0) b_kc.load(d.B, d.ldb, n0, d.N, k0, k_end, d.K, 0, nullptr, 1, 0);
-        else b_mc.load(d.B, d.ldb, n0, d.N, k0, k_end, d.K, d.b_add, d.b_add_mod, d.b_add_ld);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) load_piece(q, d, m0, n0, k0, k_end);
     }
     __device__ __forceinline__ void store(float* as, float* bs) const {
-        if (LA == 0) a_kc.store(as); else a_mc.store(as);
-        if (LB == 0) b_kc.store(bs); else b_mc.store(bs);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) store_piece(q, as, bs);
     }
 };
 
 // ---------------------------------------------------------------------------------------------------------
 // one output tile of one problem
 // ---------------------------------------------------------------------------------------------------------
-// WK > 1 (only with WM = WN = 1): the WK waves of the workgroup share ONE 32x32 output tile and split every k-step
-// between them (intra-workgroup split-K, reduced through LDS at the end).  The step's many tiny GEMMs have fewer tiles
+template <int LA, int LB, int BM, int BN, int BK>
+constexpr int gemm_lds_floats() {
+    return 2 * ((LA == 0 ? BM * (BK + 4) : BK * (BM + 4)) + (LB == 0 ? BN * (BK + 4) : BK * (BN + 4)));
+}
+
+// WK > 1: WK groups of WM x WN waves share the output tile and split every k-step between them (intra-workgroup
+// split-K, reduced through LDS at the end): two waves per SIMD cover each other's LDS / barrier / load-issue stalls.  The step's many tiny GEMMs have fewer tiles
 // than the chip has CUs; what they need is more loads in flight and a shorter MFMA chain per wave, not more tiles.
 template <int LA, int LB, int BM, int BN, int BK, int WM, int WN, int WK, bool VEC>
 __device__ __forceinline__ void gemm_body(const r3d_gemm_desc& d, int tile, int split, float* smem) {
-    static_assert(WK == 1 || (WM == 1 && WN == 1), "k-split waves share a single 32x32 tile");
     constexpr int NT = 64 * WM * WN * WK;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     // LDS images: K-contiguous operand -> [rows][BK+4] (fragment = one ds_read_b128 of 4 consecutive k, conflict-free:
@@ -327,12 +295,13 @@ __device__ __forceinline__ void gemm_body(const r3d_gemm_desc& d, int tile, int 
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int wm_off = (WK > 1) ? 0 : (wave / WN) * (BM / WM);
-    const int wn_off = (WK > 1) ? 0 : (wave % WN) * (BN / WN);
+    const int wave_mn = wave % (WM * WN), wk = wave / (WM * WN);     // WK groups of WM x WN waves split every k-step
+    const int wm_off = (wave_mn / WN) * (BM / WM);
+    const int wn_off = (wave_mn % WN) * (BN / WN);
     const int l31 = lane & 31, lhi = lane >> 5;
     constexpr int G_PER_WAVE = BK / 8 / WK;             // groups of 8 k (4 MFMAs) per wave and k-step
     static_assert(G_PER_WAVE >= 1, "BK too small for the k-split");
-    const int g0 = (WK > 1) ? wave * G_PER_WAVE : 0;
+    const int g0 = wk * G_PER_WAVE;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -348,80 +317,108 @@ __device__ __forceinline__ void gemm_body(const r3d_gemm_desc& d, int tile, int 
     // One group = 8 consecutive k.  MFMA t of a group (t = 0..3) contracts k = 8g + 4*(lane>>5) + t on BOTH operands:
     // the k order inside a step is permuted (any order is a valid dot product) so that a K-contiguous operand feeds
     // four MFMAs from one 16-byte LDS read.
-    auto compute = [&](const float* as, const float* bs) {
+    auto group = [&](const float* as, const float* bs, int gq) {
+        const int kb = (g0 + gq) * 8 + 4 * lhi;
+        float a[TM][4], b[TN][4];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            if (LA == 0) {
+                const float4 t4 = *reinterpret_cast<const float4*>(as + (wm_off + i * 32 + l31) * SA + kb);
+                a[i][0] = t4.x; a[i][1] = t4.y; a[i][2] = t4.z; a[i][3] = t4.w;
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    a[i][t] = as[(kb + t) * SA + wm_off + i * 32 + l31];
+                    asum[i] += a[i][t];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            if (LB == 0) {
+                const float4 t4 = *reinterpret_cast<const float4*>(bs + (wn_off + j * 32 + l31) * SB + kb);
+                b[j][0] = t4.x; b[j][1] = t4.y; b[j][2] = t4.z; b[j][3] = t4.w;
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) b[j][t] = bs[(kb + t) * SB + wn_off + j * 32 + l31];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
+    };
+
+    // One k-step: the MFMA groups of the current LDS buffer, with the global loads of tile kt+2 (into `ld_st`) and the
+    // LDS writes of tile kt+1 (from `st_st`, into the other buffer) slotted BETWEEN the groups: issued back to back in
+    // front of / behind the MFMA block they would add ~0.7 us of exposed issue + wait time to every ~1 us step.
+    using StageT = Stage<LA, LB, BM, BN, BK, NT, VEC>;
+    constexpr int NP = StageT::NP;
+    auto step = [&](const float* as, const float* bs, StageT& ld_st, bool do_load, int k_next, StageT& st_st, bool do_store,
+                    float* as_o, float* bs_o) {
 #pragma unroll
         for (int gq = 0; gq < G_PER_WAVE; ++gq) {
-            const int kb = (g0 + gq) * 8 + 4 * lhi;
-            float a[TM][4], b[TN][4];
+            group(as, bs, gq);
+            constexpr int PER = (NP + G_PER_WAVE - 1) / G_PER_WAVE;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                if (LA == 0) {
-                    const float4 t4 = *reinterpret_cast<const float4*>(as + (wm_off + i * 32 + l31) * SA + kb);
-                    a[i][0] = t4.x; a[i][1] = t4.y; a[i][2] = t4.z; a[i][3] = t4.w;
-                } else {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        a[i][t] = as[(kb + t) * SA + wm_off + i * 32 + l31];
-                        asum[i] += a[i][t];
-                    }
+            for (int u = 0; u < PER; ++u) {
+                const int q = gq * PER + u;
+                if (q < NP) {
+                    if (do_load) ld_st.load_piece(q, d, m0, n0, k_next, k_end);
+                    if (do_store) st_st.store_piece(q, as_o, bs_o);
                 }
             }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                if (LB == 0) {
-                    const float4 t4 = *reinterpret_cast<const float4*>(bs + (wn_off + j * 32 + l31) * SB + kb);
-                    b[j][0] = t4.x; b[j][1] = t4.y; b[j][2] = t4.z; b[j][3] = t4.w;
-                } else {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) b[j][t] = bs[(kb + t) * SB + wn_off + j * 32 + l31];
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
         }
     };
 
-    Stage<LA, LB, BM, BN, BK, NT, VEC> st0, st1;
+    StageT st0, st1;
     if (nk > 0) st0.load(d, m0, n0, k_begin, k_end);
     if (nk > 1) st1.load(d, m0, n0, k_begin + BK, k_end);
     if (nk > 0) st0.store(As0, Bs0);
     __syncthreads();
     for (int kt = 0; kt < nk;) {
         // even step: tile kt is in buffer 0, tile kt+1 in register stage 1; stage 0 is free for tile kt+2
-        if (kt + 2 < nk) st0.load(d, m0, n0, k_begin + (kt + 2) * BK, k_end);
-        compute(As0, Bs0);
-        if (kt + 1 < nk) st1.store(As1, Bs1);
+        step(As0, Bs0, st0, kt + 2 < nk, k_begin + (kt + 2) * BK, st1, kt + 1 < nk, As1, Bs1);
         __syncthreads();
         if (++kt >= nk) break;
         // odd step: roles swapped
-        if (kt + 2 < nk) st1.load(d, m0, n0, k_begin + (kt + 2) * BK, k_end);
-        compute(As1, Bs1);
-        if (kt + 1 < nk) st0.store(As0, Bs0);
+        step(As1, Bs1, st1, kt + 2 < nk, k_begin + (kt + 2) * BK, st0, kt + 1 < nk, As0, Bs0);
         __syncthreads();
         ++kt;
     }
 
     if (WK > 1) {
-        // reduce the WK partial accumulators (and bias-gradient sums) into wave 0 through LDS (staging buffers are free:
-        // the loop ended with a barrier)
-        float* red = smem;                                  // [WK][17][64]
-        if (wave > 0) {
+        // reduce the WK partial accumulators (and bias-gradient sums) into the wk == 0 waves through LDS (the staging
+        // buffers are free: the loop ended with a barrier)
+        constexpr int PER_WAVE = (TM * TN * 16 + TM) * 64;
+        static_assert((WK - 1) * WM * WN * PER_WAVE <= gemm_lds_floats<LA, LB, BM, BN, BK>(), "k-split reduction does not fit");
+        float* red = smem + ((wk - 1) * (WM * WN) + wave_mn) * PER_WAVE;
+        if (wk > 0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) red[(wave * 17 + r) * 64 + lane] = acc[0][0][r];
-            red[(wave * 17 + 16) * 64 + lane] = asum[0];
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[((i * TN + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+                red[(TM * TN * 16 + i) * 64 + lane] = asum[i];
+            }
         }
         __syncthreads();
-        if (wave > 0) return;
+        if (wk > 0) return;
 #pragma unroll
         for (int w = 1; w < WK; ++w) {
+            const float* rw = smem + ((w - 1) * (WM * WN) + wave_mn) * PER_WAVE;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[0][0][r] += red[(w * 17 + r) * 64 + lane];
-            asum[0] += red[(w * 17 + 16) * 64 + lane];
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] += rw[((i * TN + j) * 16 + r) * 64 + lane];
+                asum[i] += rw[(TM * TN * 16 + i) * 64 + lane];
+            }
         }
     }
     if (LA == 1 && d.bias_grad && n0 == 0 && wn_off == 0) {
@@ -439,10 +436,6 @@ __device__ __forceinline__ void gemm_body(const r3d_gemm_desc& d, int tile, int 
             gemm_epilogue_tile(d, acc[i][j], m0 + wm_off + i * 32 + 4 * lhi, n0 + wn_off + j * 32 + l31, split);
 }
 
-template <int LA, int LB, int BM, int BN, int BK>
-constexpr int gemm_lds_floats() {
-    return 2 * ((LA == 0 ? BM * (BK + 4) : BK * (BM + 4)) + (LB == 0 ? BN * (BK + 4) : BK * (BN + 4)));
-}
 
 template <int LA, int LB, int BM, int BN, int BK, int WM, int WN, int WK, bool VEC>
 __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_f32_kernel(const r3d_gemm_desc d) {
@@ -478,7 +471,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const r3d_gemm_desc 
 // ---------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------
-static const int kTileSz[4] = {0, 32, 64, 128};
+static const int kTileSz[6] = {0, 32, 64, 128, 64, 128};
 
 template <int LA, int LB, int BM, int BN, int BK, int WM, int WN, int WK>
 static int launch_cfg(const r3d_gemm_desc& d, int nsplit, hipStream_t s) {
@@ -495,6 +488,8 @@ static int launch_layout(const r3d_gemm_desc& d, int nsplit, hipStream_t s) {
         case 1: return launch_cfg<LA, LB, 32, 32, 64, 1, 1, 4>(d, nsplit, s);
         case 2: return launch_cfg<LA, LB, 64, 64, 64, 2, 2, 1>(d, nsplit, s);
         case 3: return launch_cfg<LA, LB, 128, 128, 32, 2, 2, 1>(d, nsplit, s);
+        case 4: return launch_cfg<LA, LB, 64, 64, 64, 2, 2, 2>(d, nsplit, s);
+        case 5: return launch_cfg<LA, LB, 128, 128, 32, 2, 2, 2>(d, nsplit, s);
         default: return R3D_EINVAL;
     }
 }
@@ -533,7 +528,7 @@ static int gemm_validate(const r3d_gemm_desc* d) {
     if (!d || !d->A || !d->B || !d->C) return R3D_EINVAL;
     if (d->M <= 0 || d->N <= 0 || d->K <= 0) return R3D_EINVAL;
     if (d->layout < 0 || d->layout > 2) return R3D_EINVAL;
-    if (d->tile < 1 || d->tile > 3) return R3D_EINVAL;
+    if (d->tile < 1 || d->tile > 5) return R3D_EINVAL;
     const int a_min = (d->layout == R3D_GEMM_TN) ? d->M : d->K;
     const int b_min = (d->layout == R3D_GEMM_NT) ? d->K : d->N;
     if (d->lda < a_min || d->ldb < b_min || d->ldc < d->N) return R3D_EINVAL;

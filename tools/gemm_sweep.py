@@ -35,10 +35,11 @@ def main():
         res = []
         d = ops.gemm(layout, A, B, Cm, ws=ws)
         res.append(("auto", d.tile, d.splitk, round(time_graph(lambda: ops.gemm(layout, A, B, Cm, ws=ws)), 2)))
-        for tile in (1, 2, 3):
+        for tile in (1, 2, 3, 4, 5):
             for sk in (1, 2, 4, 8, 16, 32, 49, 61, 64, 98, 122, 128, 196, 256):
                 if sk > 1 and K // sk < 128: continue
-                if sk == 1 and K > 8192 and (M * N) // (32 * 32 * (4 ** (tile - 1))) < 64: continue
+                ts = {1: 32, 2: 64, 3: 128, 4: 64, 5: 128}[tile]
+                if sk == 1 and K > 8192 and (M * N) // (ts * ts) < 64: continue
                 try:
                     t = time_graph(lambda: ops.gemm(layout, A, B, Cm, ws=ws, tile=tile, splitk=sk, defer_reduce=True))
                 except Exception as e:
