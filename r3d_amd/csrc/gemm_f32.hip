@@ -352,26 +352,16 @@ __device__ __forceinline__ void gemm_body(const r3d_gemm_desc& d, int tile, int 
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
     };
 
-    // One k-step: the MFMA groups of the current LDS buffer, with the global loads of tile kt+2 (into `ld_st`) and the
-    // LDS writes of tile kt+1 (from `st_st`, into the other buffer) slotted BETWEEN the groups: issued back to back in
-    // front of / behind the MFMA block they would add ~0.7 us of exposed issue + wait time to every ~1 us step.
+    // One k-step: issue the global loads of tile kt+2 (into `ld_st`), run the MFMA groups of the current LDS buffer,
+    // then write tile kt+1 (from `st_st`) into the other buffer.  (Slotting the pieces BETWEEN the MFMA groups was
+    // measured 1.7x slower: hipcc then puts a vmcnt wait in front of every group.)
     using StageT = Stage<LA, LB, BM, BN, BK, NT, VEC>;
-    constexpr int NP = StageT::NP;
     auto step = [&](const float* as, const float* bs, StageT& ld_st, bool do_load, int k_next, StageT& st_st, bool do_store,
                     float* as_o, float* bs_o) {
+        if (do_load) ld_st.load(d, m0, n0, k_next, k_end);
 #pragma unroll
-        for (int gq = 0; gq < G_PER_WAVE; ++gq) {
-            group(as, bs, gq);
-            constexpr int PER = (NP + G_PER_WAVE - 1) / G_PER_WAVE;
-#pragma unroll
-            for (int u = 0; u < PER; ++u) {
-                const int q = gq * PER + u;
-                if (q < NP) {
-                    if (do_load) ld_st.load_piece(q, d, m0, n0, k_next, k_end);
-                    if (do_store) st_st.store_piece(q, as_o, bs_o);
-                }
-            }
-        }
+        for (int gq = 0; gq < G_PER_WAVE; ++gq) group(as, bs, gq);
+        if (do_store) st_st.store(as_o, bs_o);
     };
 
     StageT st0, st1;
