@@ -14,6 +14,7 @@
 // The k order inside a 16-deep group is permuted identically on both operands so one 16-byte read feeds 4 MFMAs.
 #include "common.h"
 #include "../../include/r3d_hip.h"
+#include <stdlib.h>
 
 namespace r3d {
 
@@ -24,32 +25,85 @@ constexpr int DEC_THREADS = 1024;     // 16 waves: the layer is a chain of laten
 constexpr float kLnEpsD = 1e-5f;
 
 // ---- Y[16 x N] = X[16 x K] . W[N x K]^T : epi(row, col, value) for every element of the 16 x N result ------------
+// The phase is latency-bound (weights come from L2 per k-step), so the work is spread to keep every wave busy with many
+// independent loads in flight:
+//   * N/16 >= 2 * waves : each wave takes column tiles in PAIRS -- both tiles' weight loads are issued before the first
+//     MFMA and the two accumulator chains interleave;
+//   * N/16 * 2 <= waves  : two waves share a tile and split K; the upper half's partial sums go through `red` (LDS,
+//     [waves/2][4][64] floats) -- needs the workgroup barrier inside, so EVERY wave must call this function.
 template <class Epi>
 __device__ __forceinline__ void mm16_nt(const float* X, int ldx, int K, const float* __restrict__ W, int ldw, int N,
-                                        Epi epi) {
+                                        float* red, Epi epi) {
+    constexpr int NW = DEC_THREADS / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, kq = lane >> 4;
     const int ntiles = (N + 15) >> 4;
-    for (int tile = wave; tile < ntiles; tile += DEC_THREADS / 64) {
-        const int n = tile * 16 + i;                       // B operand: lane (kq, j = i) holds W[n0 + j][k]
-        const bool nok = n < N;
-        const float* wrow = W + (size_t)(nok ? n : 0) * ldw + 4 * kq;
-        const float* xrow = X + i * ldx + 4 * kq;
+    if (ntiles * 2 <= NW) {
+        // ---- k-split: wave = (tile, half)
+        const int tile = wave >> 1, half = wave & 1;
+        const bool active = tile < ntiles;
+        const int n = tile * 16 + i;
+        const bool nok = active && n < N;
+        const int kh = K >> 1;                                  // K is a multiple of 32 on this path (H, 4H)
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (active) {
+            const float* wrow = W + (size_t)(nok ? n : 0) * ldw + half * kh + 4 * kq;
+            const float* xrow = X + i * ldx + half * kh + 4 * kq;
+#pragma unroll 8
+            for (int k0 = 0; k0 < kh; k0 += 16) {
+                const float4 a = *reinterpret_cast<const float4*>(xrow + k0);
+                float4 b = *reinterpret_cast<const float4*>(wrow + k0);
+                if (!nok) b = make_float4(0.f, 0.f, 0.f, 0.f);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+            }
+            if (half == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[(tile * 4 + r) * 64 + lane] = acc[r];
+            }
+        }
+        __syncthreads();
+        if (active && half == 0 && nok) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) epi(kq * 4 + r, n, acc[r] + red[(tile * 4 + r) * 64 + lane]);
+        }
+        return;
+    }
+    for (int tile = wave; tile < ntiles; tile += 2 * NW) {
+        const int tile2 = tile + NW;
+        const bool has2 = tile2 < ntiles;
+        const int n1 = tile * 16 + i, n2 = tile2 * 16 + i;
+        const bool ok1 = n1 < N, ok2 = has2 && n2 < N;
+        const float* w1 = W + (size_t)(ok1 ? n1 : 0) * ldw + 4 * kq;
+        const float* w2 = W + (size_t)(ok2 ? n2 : 0) * ldw + 4 * kq;
+        const float* xrow = X + i * ldx + 4 * kq;
+        f32x4 acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 8
         for (int k0 = 0; k0 < K; k0 += 16) {
             const float4 a = *reinterpret_cast<const float4*>(xrow + k0);
-            float4 b = *reinterpret_cast<const float4*>(wrow + k0);
-            if (!nok) b = make_float4(0.f, 0.f, 0.f, 0.f);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+            float4 b1 = *reinterpret_cast<const float4*>(w1 + k0);
+            float4 b2 = *reinterpret_cast<const float4*>(w2 + k0);
+            if (!ok1) b1 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!ok2) b2 = make_float4(0.f, 0.f, 0.f, 0.f);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b1.x, acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b2.x, acc2, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b1.y, acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b2.y, acc2, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b1.z, acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b2.z, acc2, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b1.w, acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b2.w, acc2, 0, 0, 0);
         }
         // C/D map of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + r
-        if (nok) {
+        if (ok1) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) epi(kq * 4 + r, n, acc[r]);
+            for (int r = 0; r < 4; ++r) epi(kq * 4 + r, n1, acc1[r]);
+        }
+        if (ok2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) epi(kq * 4 + r, n2, acc2[r]);
         }
     }
 }
@@ -122,6 +176,7 @@ struct DecFwdArgs {
     const float *fin_g, *fin_b; float *tgtF, *mF, *rF;
     const float *head_w, *head_b; float* actdur; int n_head_out;
     int B, S, Q, H, heads;
+    int dbg_stop;      // diagnostic only (env R3D_DEC_STOP): return after phase N
 };
 
 __device__ __forceinline__ float keepf(const uint8_t* m, size_t idx, float scale) { return m ? scale * (float)m[idx] : 1.f; }
@@ -143,6 +198,8 @@ __global__ __launch_bounds__(DEC_THREADS) void decoder_layer_fwd_kernel(const De
     float* KV = WIDE + 16 * LDW;
     float* KIN = KV + S16 * LDK;
     float* PR = KIN + S16 * LD;
+    float* RED = PR + heads * Q * PL;                      // [waves/2][4][64] k-split partial sums
+    float* KMASK = RED + (DEC_THREADS / 128) * 4 * 64;     // [S16] 1 = padded key
     const float dsc = a.drop_scale;
     const size_t rowQ = (size_t)b * Q;                     // first query row of this clip in [B*Q, .] tensors
     const size_t rowS = (size_t)b * S;
@@ -163,14 +220,18 @@ __global__ __launch_bounds__(DEC_THREADS) void decoder_layer_fwd_kernel(const De
         const int r = e / H, c = e - r * H;
         KIN[r * LD + c] = (r < S) ? a.fused[(rowS + r) * H + c] + a.pos[r * H + c] : 0.f;
     }
+    for (int j = tid; j < S; j += DEC_THREADS)
+        KMASK[j] = (a.key_label && a.key_label[rowS + j] == (int64_t)a.pad_idx) ? 1.f : 0.f;
     __syncthreads();
+    if (a.dbg_stop == 1) return;
     // ---- self attention in_proj: WIDE[16][3H] = XA . Win^T + b
-    mm16_nt(XA, LD, H, a.p.sa_in_w, H, 3 * H, [&](int r, int c, float v) {
+    mm16_nt(XA, LD, H, a.p.sa_in_w, H, 3 * H, RED, [&](int r, int c, float v) {
         v += a.p.sa_in_b[c];
         WIDE[r * LDW + c] = v;
         if (r < Q) a.sa_qkv[(rowQ + r) * 3 * H + c] = v;
     });
     __syncthreads();
+    if (a.dbg_stop == 2) return;
     // ---- 8x8 attention per head: PR[h][i][j]
     const float scale = 1.0f / sqrtf((float)dh);
     for (int e = tid; e < heads * Q * Q; e += DEC_THREADS) {
@@ -203,8 +264,9 @@ __global__ __launch_bounds__(DEC_THREADS) void decoder_layer_fwd_kernel(const De
         a.sa_o[(rowQ + i) * H + c] = s;
     }
     __syncthreads();
+    if (a.dbg_stop == 3) return;
     // ---- out_proj + dropout1 + residual -> t1_pre (in XB)
-    mm16_nt(XA, LD, H, a.p.sa_out_w, H, H, [&](int r, int c, float v) {
+    mm16_nt(XA, LD, H, a.p.sa_out_w, H, H, RED, [&](int r, int c, float v) {
         if (r < Q) {
             v = (v + a.p.sa_out_b[c]) * keepf(a.drop_d1, (rowQ + r) * H + c, dsc) + XB[r * LD + c];
             XB[r * LD + c] = v;
@@ -212,6 +274,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decoder_layer_fwd_kernel(const De
         }
     });
     __syncthreads();
+    if (a.dbg_stop == 4) return;
     // ---- LN1 -> t1 in XB (residual for the next sub-layer), XA = t1 + query_pos
     ln_rows(XB, LD, Q, H, a.p.n1_g, a.p.n1_b, a.m1 + rowQ, a.r1 + rowQ, [&](int r, int c, float v) {
         XB[r * LD + c] = v;
@@ -219,26 +282,27 @@ __global__ __launch_bounds__(DEC_THREADS) void decoder_layer_fwd_kernel(const De
         a.t1[(rowQ + r) * H + c] = v;
     });
     __syncthreads();
+    if (a.dbg_stop == 5) return;
     // ---- cross attention: q = XA . Wq^T + bq -> WIDE[:, 0:H];  k|v rows = KIN . Wkv^T + bkv -> KV
-    mm16_nt(XA, LD, H, a.p.ca_in_w, H, H, [&](int r, int c, float v) {
+    mm16_nt(XA, LD, H, a.p.ca_in_w, H, H, RED, [&](int r, int c, float v) {
         v += a.p.ca_in_b[c];
         WIDE[r * LDW + c] = v;
         if (r < Q) a.caq[(rowQ + r) * H + c] = v;
     });
     for (int rt = 0; rt < S16; rt += 16) {
-        mm16_nt(KIN + rt * LD, LD, H, a.p.ca_in_w + (size_t)H * H, H, 2 * H, [&](int r, int c, float v) {
+        mm16_nt(KIN + rt * LD, LD, H, a.p.ca_in_w + (size_t)H * H, H, 2 * H, RED, [&](int r, int c, float v) {
             v += a.p.ca_in_b[H + c];
             KV[(rt + r) * LDK + c] = v;
             if (rt + r < S) a.cakv[(rowS + rt + r) * 2 * H + c] = v;
         });
     }
     __syncthreads();
+    if (a.dbg_stop == 6) return;
     for (int e = tid; e < heads * Q * S; e += DEC_THREADS) {
         const int h = e / (Q * S), i = (e / S) % Q, j = e % S;
         float s = 0.f;
         for (int d = 0; d < dh; ++d) s += WIDE[i * LDW + h * dh + d] * KV[j * LDK + h * dh + d];
-        const bool masked = a.key_label && a.key_label[rowS + j] == (int64_t)a.pad_idx;
-        PR[(h * Q + i) * PL + j] = masked ? -INFINITY : s * scale;
+        PR[(h * Q + i) * PL + j] = (KMASK[j] != 0.f) ? -INFINITY : s * scale;
     }
     __syncthreads();
     for (int e = tid; e < heads * Q; e += DEC_THREADS) {
@@ -263,7 +327,8 @@ __global__ __launch_bounds__(DEC_THREADS) void decoder_layer_fwd_kernel(const De
         a.ca_o[(rowQ + i) * H + c] = s;
     }
     __syncthreads();
-    mm16_nt(XA, LD, H, a.p.ca_out_w, H, H, [&](int r, int c, float v) {
+    if (a.dbg_stop == 7) return;
+    mm16_nt(XA, LD, H, a.p.ca_out_w, H, H, RED, [&](int r, int c, float v) {
         if (r < Q) {
             v = (v + a.p.ca_out_b[c]) * keepf(a.drop_d2, (rowQ + r) * H + c, dsc) + XB[r * LD + c];
             XB[r * LD + c] = v;
@@ -277,8 +342,9 @@ __global__ __launch_bounds__(DEC_THREADS) void decoder_layer_fwd_kernel(const De
         a.t2[(rowQ + r) * H + c] = v;
     });
     __syncthreads();
+    if (a.dbg_stop == 8) return;
     // ---- FFN: ff1 = drop(relu(t2 . W1^T + b1)) -> WIDE[16][4H];  t3_pre = t2 + drop3(ff1 . W2^T + b2)
-    mm16_nt(XA, LD, H, a.p.l1_w, H, 4 * H, [&](int r, int c, float v) {
+    mm16_nt(XA, LD, H, a.p.l1_w, H, 4 * H, RED, [&](int r, int c, float v) {
         v = fmaxf(v + a.p.l1_b[c], 0.f);
         if (r < Q) {
             v *= keepf(a.drop_ff, (rowQ + r) * 4 * H + c, dsc);
@@ -289,7 +355,8 @@ __global__ __launch_bounds__(DEC_THREADS) void decoder_layer_fwd_kernel(const De
         WIDE[r * LDW + c] = v;
     });
     __syncthreads();
-    mm16_nt(WIDE, LDW, 4 * H, a.p.l2_w, 4 * H, H, [&](int r, int c, float v) {
+    if (a.dbg_stop == 9) return;
+    mm16_nt(WIDE, LDW, 4 * H, a.p.l2_w, 4 * H, H, RED, [&](int r, int c, float v) {
         if (r < Q) {
             v = (v + a.p.l2_b[c]) * keepf(a.drop_d3, (rowQ + r) * H + c, dsc) + XB[r * LD + c];
             XB[r * LD + c] = v;
@@ -297,6 +364,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decoder_layer_fwd_kernel(const De
         }
     });
     __syncthreads();
+    if (a.dbg_stop == 10) return;
     ln_rows(XB, LD, Q, H, a.p.n3_g, a.p.n3_b, a.m3 + rowQ, a.r3 + rowQ, [&](int r, int c, float v) {
         XB[r * LD + c] = v;
         a.t3[(rowQ + r) * H + c] = v;
@@ -309,14 +377,15 @@ __global__ __launch_bounds__(DEC_THREADS) void decoder_layer_fwd_kernel(const De
         a.tgtF[(rowQ + r) * H + c] = v;
     });
     __syncthreads();
-    mm16_nt(XA, LD, H, a.head_w, H, a.n_head_out, [&](int r, int c, float v) {
+    mm16_nt(XA, LD, H, a.head_w, H, a.n_head_out, RED, [&](int r, int c, float v) {
         if (r < Q) a.actdur[(rowQ + r) * a.n_head_out + c] = v + a.head_b[c];
     });
 }
 
 static size_t dec_fwd_lds_bytes(int S, int Q, int H, int heads) {
     const int LD = H + 4, LDW = 4 * H + 4, LDK = 2 * H + 4, S16 = (S + 15) & ~15, PL = S > Q ? S : Q;
-    return sizeof(float) * ((size_t)2 * 16 * LD + 16 * LDW + (size_t)S16 * LDK + (size_t)S16 * LD + (size_t)heads * Q * PL);
+    return sizeof(float) * ((size_t)2 * 16 * LD + 16 * LDW + (size_t)S16 * LDK + (size_t)S16 * LD + (size_t)heads * Q * PL +
+                            (size_t)(DEC_THREADS / 128) * 4 * 64 + S16);
 }
 
 }  // namespace r3d
@@ -325,7 +394,7 @@ using namespace r3d;
 
 /* 1 when the fused per-clip decoder kernels support this shape (everything of one clip's layer fits one CU's LDS). */
 R3D_EXPORT int r3d_decoder_fused_supported(int S, int Q, int H, int heads) {
-    if (S <= 0 || Q <= 0 || Q > 16 || H <= 0 || heads <= 0 || (H % 16) != 0 || (H % heads) != 0) return 0;
+    if (S <= 0 || Q <= 0 || Q > 16 || H <= 0 || heads <= 0 || (H % 32) != 0 || (H % heads) != 0) return 0;
     return dec_fwd_lds_bytes(S, Q, H, heads) <= 150 * 1024 ? 1 : 0;
 }
 
@@ -356,6 +425,7 @@ R3D_EXPORT int r3d_decoder_layer_fwd(const void* const* ptrs, int nptrs, int B, 
     if (a.fin_g) R3D_REQUIRE(a.fin_b && a.tgtF && a.mF && a.rF && a.head_w && a.head_b && a.actdur && n_head_out > 0);
     a.pad_idx = pad_idx; a.drop_scale = drop_scale; a.n_head_out = n_head_out;
     a.B = B; a.S = S; a.Q = Q; a.H = H; a.heads = heads;
+    { const char* e = getenv("R3D_DEC_STOP"); a.dbg_stop = e ? atoi(e) : 0; }
     const size_t lds = dec_fwd_lds_bytes(S, Q, H, heads);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)decoder_layer_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
