@@ -120,6 +120,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eval-dropout-off", action="store_true", help="bench the eval()-state step (dropout off)")
     ap.add_argument("--no-side-stream", action="store_true", help="keep the query self-attention branch on the main stream")
+    ap.add_argument("--replicated-depth", action="store_true",
+                    help="N>1: keep depth_projection replicated and all-reduce its 25.7 MB gradient (plain data parallel) "
+                         "instead of sharding it over pixels")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the "
                                                       "multi-rank control flow on one GPU)")
     a = ap.parse_args()
@@ -145,23 +148,57 @@ def main():
     eng = model.engine()
     eng.use_side_stream = not a.no_side_stream
     from r3d_amd.parallel import DataParallelStep
-    dp = DataParallelStep(eng) if world > 1 else None
-    if dp is not None:
-        dp.broadcast_parameters()
     feats, depth, lab, dur, tgt = make_inputs(c, device, seed=1 + rank)
+    x_dep2d = depth.reshape(c["B"] * c["S"], -1)
     training = model.training
-    gscale = dp.grad_scale if dp is not None else 1.0
+    dp = tp = None
+    slot = [0]
 
     def step_eager():
         if dp is not None:
             dp.prepare_duration_denominator(dur, c["K"] + 1)
-        eng.forward(feats, depth, lab, "train", training)
+        eng.forward_begin(feats, depth, lab, "train", training)
+        if tp is not None:                  # the NEXT step's depth input travels under this step
+            slot[0] ^= 1
+            tp.prefetch(x_dep2d, slot[0])
+            tp.exchange_forward(eng._fw["w"])
+        eng.forward_finish()
         eng.losses(lab, tgt, dur)
         eng.backward()
         if dp is not None:
             dp.wait_grads()
         eng.adamw(c["lr"], c["wd"], grad_scale=gscale, tick_dropout=eng.last["drop"])
 
+    mode = "replicated"
+    if world > 1:
+        want_tp = not a.replicated_depth and c["P"] % (4 * world) == 0
+        pg_in = dist.new_group(backend=a.backend) if want_tp else None
+        dp = DataParallelStep(eng, pixel_shard=want_tp, input_group=pg_in)
+        dp.broadcast_parameters()
+        tp = dp.tp
+        gscale = dp.grad_scale
+        if tp is not None:                  # one trial step; every rank must agree that it worked
+            ok = torch.ones(1, device=device)
+            try:
+                step_eager()
+                torch.cuda.synchronize()
+            except Exception as e:          # noqa: BLE001
+                print(f"[rank {rank}] pixel-sharded step failed ({type(e).__name__}: {e}); falling back", flush=True)
+                ok.zero_()
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if float(ok.item()) < 1.0:
+                model = build_model(c, device)
+                if a.eval_dropout_off:
+                    model.eval()
+                eng = model.engine()
+                eng.use_side_stream = not a.no_side_stream
+                dp = DataParallelStep(eng)
+                dp.broadcast_parameters()
+                tp = None
+            else:
+                mode = "pixel-sharded depth_projection"
+    else:
+        gscale = 1.0
     for _ in range(3):
         step_eager()
     torch.cuda.synchronize()
@@ -174,6 +211,55 @@ def main():
                 with torch.cuda.graph(g):
                     step_eager()
                 run_step, launch = g.replay, "hipGraph (1 graph/step)"
+            elif tp is not None:
+                hook = eng.grad_hook
+                eng.grad_hook = None
+                ptr = x_dep2d.data_ptr()
+                gA, gC = {}, {}
+                gB, gD = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                tp.ready.clear()
+                for s in (0, 1):
+                    tp.prefetch(x_dep2d, s)
+                    sh = tp.ready[ptr]
+                    if sh["work"] is not None:
+                        sh["work"].wait()
+                        sh["work"] = None
+                    torch.cuda.synchronize()
+                    gA[s] = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gA[s]):
+                        eng.forward_begin(feats, depth, lab, "train", training)       # consumes the slot-s shard
+                    w_ = eng._fw["w"]
+                    if s == 0:
+                        with torch.cuda.graph(gB):
+                            eng.forward_finish()
+                            eng.losses(lab, tgt, dur)
+                            eng.backward_main()
+                    gC[s] = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gC[s]):
+                        tp.wgrad(w_, eng.ws)
+                with torch.cuda.graph(gD):
+                    eng.adamw(c["lr"], c["wd"], grad_scale=gscale, tick_dropout=training)
+                eng.grad_hook = hook
+                slot[0] = 0
+                tp.prefetch(x_dep2d, 0)
+
+                def run_step():
+                    cur = slot[0]
+                    sh = tp.ready.pop(ptr)
+                    if sh["work"] is not None:
+                        sh["work"].wait()                # stream-level join with the prefetched all-to-all
+                    slot[0] = cur ^ 1
+                    tp.prefetch(x_dep2d, slot[0])        # next step's input, on its own communicator
+                    dp.prepare_duration_denominator(dur, c["K"] + 1)
+                    gA[cur].replay()
+                    tp.exchange_forward(w_)
+                    gB.replay()
+                    tp.exchange_backward(w_)
+                    dp._on_stage("small_ready")          # all-reduce of the replicated parameters' gradients under gC
+                    gC[cur].replay()
+                    dp.wait_grads()
+                    gD.replay()
+                launch = "hipGraph (4 graphs/step around the RCCL exchanges)"
             else:
                 hook = eng.grad_hook
                 eng.grad_hook = None
@@ -201,6 +287,8 @@ def main():
             launch = f"eager (graph capture failed: {type(e).__name__})"
             run_step = step_eager
             torch.cuda.synchronize()
+            if tp is not None:
+                tp.ready.clear()
     for _ in range(a.warmup):
         run_step()
     torch.cuda.synchronize()
@@ -239,7 +327,8 @@ def main():
                    data="synthetic",
                    config=dict(workload="DARai RGB+Depth futr_safuser_tokenfusion, batch=8 per GPU, 16-frame clips, "
                                         "hidden=128, n_class=17, depth 224x224 (BASELINE.json configs[1])",
-                               global_batch=world * c["B"], clip_frames=c["S"], hidden=c["H"], parallelism=f"dp{world}",
+                               global_batch=world * c["B"], clip_frames=c["S"], hidden=c["H"],
+                               parallelism=f"dp{world}" + (f" ({mode})" if world > 1 else ""),
                                launch=launch, dropout="on" if training else "off"),
                    roofline=roof,
                    kernels={k: dict(us=v["seconds"] * 1e6, GBps=v["bytes"] / v["seconds"] / 1e9,

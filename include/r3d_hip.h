@@ -213,6 +213,9 @@ int64_t r3d_losses_ws_floats(int B, int S, int Q);     /* scratch for r3d_losses
  * grad_scale first (1/world after a sum all-reduce).  lr and the 1-based step are read from device memory. */
 int r3d_adamw_flat(float* p, const float* g, float* m, float* v, int64_t n, const float* lr, const int64_t* step,
                    float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream);
+/* The same update on a [rows x cols] block (leading dimension ld) of p/g/m/v: a pixel shard of depth_projection.weight. */
+int r3d_adamw_2d(float* p, const float* g, float* m, float* v, int rows, int cols, int ld, const float* lr,
+                 const int64_t* step, float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream);
 /* mask[i] = 1 with probability 1-p (Philox4x32-10 keyed by seed, counter (i/4, *offset)). */
 int r3d_dropout_mask(uint8_t* mask, int64_t n, float p, uint64_t seed, const int64_t* offset, void* stream);
 

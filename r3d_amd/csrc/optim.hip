@@ -39,6 +39,41 @@ __global__ __launch_bounds__(256) void adamw_kernel(float4* __restrict__ p, cons
     }
 }
 
+// The same update on a [rows x cols] block of a row-major matrix with leading dimension ld: a COLUMN shard of
+// depth_projection.weight [H, 50176] when the projection is tensor-parallel over pixels (r3d_amd/parallel.py).
+__global__ __launch_bounds__(256) void adamw_2d_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                       float* __restrict__ m, float* __restrict__ v, int rows, int cols4,
+                                                       int ld4, const float* lr_ptr, const int64_t* step_ptr, float b1,
+                                                       float b2, float eps, float wd, float gscale) {
+    const float lr = *lr_ptr;
+    const double step = (double)*step_ptr;
+    const float bc1 = (float)(1.0 - pow((double)b1, step));
+    const float bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, step));
+    const float decay = 1.0f - lr * wd;
+    const float step_size = lr / bc1;
+    const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
+    const size_t total = (size_t)rows * cols4;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const size_t i = (e / cols4) * ld4 + (e % cols4);
+        float4 pp = reinterpret_cast<float4*>(p)[i], gg = reinterpret_cast<const float4*>(g)[i];
+        float4 mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+#define R3D_ADAM2(c)                                               \
+        {                                                          \
+            const float gr = gg.c * gscale;                        \
+            pp.c *= decay;                                         \
+            mm.c = mm.c + (gr - mm.c) * omb1;                      \
+            vv.c = vv.c * b2 + gr * gr * omb2;                     \
+            const float den = sqrtf(vv.c) / bc2_sqrt + eps;        \
+            pp.c -= step_size * (mm.c / den);                      \
+        }
+        R3D_ADAM2(x) R3D_ADAM2(y) R3D_ADAM2(z) R3D_ADAM2(w)
+#undef R3D_ADAM2
+        reinterpret_cast<float4*>(p)[i] = pp;
+        reinterpret_cast<float4*>(m)[i] = mm;
+        reinterpret_cast<float4*>(v)[i] = vv;
+    }
+}
+
 __device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) { return __umulhi(a, b); }
 
 __device__ __forceinline__ uint4 philox4x32_10(uint4 ctr, uint2 key) {
@@ -82,6 +117,21 @@ R3D_EXPORT int r3d_adamw_flat(float* p, const float* g, float* m, float* v, int6
     const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
     hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float4*)p, (const float4*)g,
                        (float4*)m, (float4*)v, n4, lr, step, beta1, beta2, eps, weight_decay, grad_scale);
+    R3D_LAUNCH_CHECK();
+    return R3D_OK;
+}
+
+/* AdamW on a [rows x cols] block (leading dimension ld) of p/g/m/v -- all four share the layout. */
+R3D_EXPORT int r3d_adamw_2d(float* p, const float* g, float* m, float* v, int rows, int cols, int ld, const float* lr,
+                            const int64_t* step, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                            void* stream) {
+    R3D_REQUIRE(p && g && m && v && lr && step && rows > 0 && cols > 0 && ld >= cols);
+    R3D_REQUIRE((cols % 4) == 0 && (ld % 4) == 0);
+    if (!(r3d_aligned16(p) && r3d_aligned16(g) && r3d_aligned16(m) && r3d_aligned16(v))) return R3D_EALIGN;
+    const size_t total = (size_t)rows * (cols / 4);
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(adamw_2d_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, rows, cols / 4, ld / 4,
+                       lr, step, beta1, beta2, eps, weight_decay, grad_scale);
     R3D_LAUNCH_CHECK();
     return R3D_OK;
 }

@@ -186,6 +186,8 @@ class FusionEngine:
         self.dur_den = None               # device scalar set by the data-parallel wrapper
         self.score_allreduce = None       # callable(sums fp64 [2,H]) -> global row count, set by the DP wrapper
         self.grad_hook = None             # callable(stage) set by the DP wrapper: "small_ready" / "big_ready"
+        self.tp = None                    # parallel.PixelShardedDepth: depth_projection tensor-parallel over pixels
+        self._fw = None
         self.last = None
         a = self.arena
         K, H = self.K, self.H
@@ -220,9 +222,17 @@ class FusionEngine:
     def forward(self, feats, depth, labels, mode="train", training=False, need_grad=True):
         """feats [B,S,D] f32, depth [B,S,...] f32 (flattened to [N,P]), labels [B,S] int64 (train mode only).
         Returns dict of views into the workspace: seg [B,S,K], action [B,Q,K], duration [B,Q] (strided views)."""
-        a, H, Q, K, heads, dh = self.arena, self.H, self.Q, self.K, self.heads, self.dh
+        self.forward_begin(feats, depth, labels, mode, training, need_grad)
+        if self._fw["tp"] is not None:
+            self._fw["tp"].exchange_forward(self._fw["w"])
+        return self.forward_finish()
+
+    def forward_begin(self, feats, depth, labels, mode="train", training=False, need_grad=True):
+        """The two input projections (:179,194-195).  With a pixel-sharded depth projection this rank multiplies ITS
+        pixel columns of every rank's clips and the partial sums are exchanged before forward_finish()."""
+        a, H = self.arena, self.H
         B, S = feats.shape[0], feats.shape[1]
-        N, BQ = B * S, B * Q
+        N = B * S
         assert feats.is_cuda and depth.is_cuda and feats.dtype == torch.float32 and depth.dtype == torch.float32
         x_rgb = feats.reshape(N, -1)
         x_dep = depth.reshape(N, -1)
@@ -230,10 +240,28 @@ class FusionEngine:
         assert x_rgb.is_contiguous() and x_dep.is_contiguous()
         w = self._shape(B, S, need_grad)
         drop = training and need_grad
-        dsc = 1.0 / (1.0 - DROP_P)
-        dm = (lambda k: w.drop[k]) if drop else (lambda k: None)
         if drop:
             ops.dropout_mask(w.drop_pool, DROP_P, self.drop_seed, self.drop_offset)
+        tp = self.tp if (self.tp is not None and need_grad) else None
+        ops.gemm(GEMM_NT, x_rgb, a.p("input_embed.weight"), w.rgb, bias=a.p("input_embed.bias"), act=1, ws=self.ws)
+        d = None
+        if tp is None:
+            d = ops.gemm(GEMM_NT, x_dep, a.p("depth_projection.weight"), w.dep_pre, bias=a.p("depth_projection.bias"),
+                         ws=self.ws, defer_reduce=True)                          # (:194-195)
+        else:
+            tp.partial_forward(w, x_dep, self.ws)
+        self._fw = dict(w=w, x_rgb=x_rgb, x_dep=x_dep, labels=labels, mode=mode, drop=drop, d=d, tp=tp, B=B, S=S)
+
+    def forward_finish(self):
+        """Everything after the input projections; see forward()."""
+        fw = self._fw
+        w, x_rgb, x_dep, labels, mode, drop, d, tp = (fw[k] for k in ("w", "x_rgb", "x_dep", "labels", "mode", "drop", "d",
+                                                                       "tp"))
+        B, S = fw["B"], fw["S"]
+        a, H, Q, K, heads, dh = self.arena, self.H, self.Q, self.K, self.heads, self.dh
+        N, BQ = B * S, B * Q
+        dsc = 1.0 / (1.0 - DROP_P)
+        dm = (lambda k: w.drop[k]) if drop else (lambda k: None)
         key_labels = None
         if mode == "train":                     # get_pad_mask (:168,243-244) is evaluated inside the attention kernel
             assert labels.dtype == torch.int64 and labels.is_cuda and labels.is_contiguous()
@@ -269,10 +297,11 @@ class FusionEngine:
         if not fused_dec:
             with torch.cuda.stream(s2):
                 sa_block(0, w.tgt0, ws2)
-        ops.gemm(GEMM_NT, x_rgb, a.p("input_embed.weight"), w.rgb, bias=a.p("input_embed.bias"), act=1, ws=self.ws)
-        d = ops.gemm(GEMM_NT, x_dep, a.p("depth_projection.weight"), w.dep_pre, bias=a.p("depth_projection.bias"),
-                     ws=self.ws, defer_reduce=True)                              # (:194-195)
-        if d.splitk > 1:
+        if tp is not None:                      # the exchanged sum of the ranks' partial products, bias still to add
+            ops.layernorm_fwd(tp.summed(w), a.p("depth_layernorm.weight"), a.p("depth_layernorm.bias"), w.dep, w.mean_d,
+                              w.rstd_d, relu=True, nsplit=1, bias=a.p("depth_projection.bias"), pre_out=w.dep_pre,
+                              rows=N, H=H)
+        elif d.splitk > 1:
             ops.layernorm_fwd(self.ws.buf, a.p("depth_layernorm.weight"), a.p("depth_layernorm.bias"), w.dep, w.mean_d,
                               w.rstd_d, relu=True, nsplit=d.splitk, bias=a.p("depth_projection.bias"),
                               pre_out=w.dep_pre, rows=N, H=H)                    # (:196-197)
@@ -311,7 +340,7 @@ class FusionEngine:
             self._decoder_fused(w, key_labels, drop, dsc)
         else:
             self._decoder_unfused(w, key_labels, dm, dsc, multi, main, s2, sa_block)
-        self.last = dict(w=w, x_rgb=x_rgb, x_dep=x_dep, mask=mask, idx=idx, drop=drop, mode=mode)
+        self.last = dict(w=w, x_rgb=x_rgb, x_dep=x_dep, mask=mask, idx=idx, drop=drop, mode=mode, tp=tp)
         return dict(seg=w.seg.view(B, S, K), action=w.actdur[:, :K].view(B, Q, K), duration=w.actdur[:, K].view(B, Q))
 
     def _decoder_unfused(self, w, key_labels, dm, dsc, multi, main, s2, sa_block):
@@ -400,6 +429,8 @@ class FusionEngine:
     def backward(self, d_seg=None, d_actdur=None):
         """Adjoint of forward(); gradients land in the grad arena (written, not accumulated)."""
         self.backward_main(d_seg, d_actdur)
+        if self.last["tp"] is not None:         # before the small bucket: the weight gradient waits for this one
+            self.last["tp"].exchange_backward(self.last["w"])
         if self.grad_hook is not None:
             self.grad_hook("small_ready")
         self.backward_depth_wgrad()
@@ -410,6 +441,9 @@ class FusionEngine:
         """depth_projection.weight gradient [H, 50176] = d_dep_pre^T . depth -- the last and largest kernel of the
         backward (81 % of the gradient bytes at H=128); everything else is complete before it starts."""
         st = self.last
+        if st["tp"] is not None:                # this rank's pixel columns, summed over every rank's clips
+            st["tp"].wgrad(st["w"], self.ws)
+            return
         ops.gemm(GEMM_TN, st["w"].d_dep_pre, st["x_dep"], self.arena.g("depth_projection.weight"), ws=self.ws)
 
     def _build_groups(self, w):
@@ -571,8 +605,13 @@ class FusionEngine:
             self.lr_t.fill_(float(lr))
             self._lr_host = float(lr)
         ops.tick(self.step_t, self.drop_offset if tick_dropout else None)
-        ops.adamw_flat(a.params[:a.n_live], a.grads, a.exp_avg, a.exp_avg_sq, self.lr_t, self.step_t, beta1=betas[0],
+        n = a.n_live if self.tp is None else a.bucket_small[1]
+        ops.adamw_flat(a.params[:n], a.grads[:n], a.exp_avg[:n], a.exp_avg_sq[:n], self.lr_t, self.step_t, beta1=betas[0],
                        beta2=betas[1], eps=eps, weight_decay=weight_decay, grad_scale=grad_scale)
+        if self.tp is not None:                 # depth_projection.weight: only this rank's pixel columns are live here
+            t = self.tp
+            ops.adamw_2d(t.w, t.g, t.m, t.v, self.lr_t, self.step_t, beta1=betas[0], beta2=betas[1], eps=eps,
+                         weight_decay=weight_decay, grad_scale=grad_scale)
 
     def train_step(self, feats, depth, past_label, target_dur, target, lr, weight_decay, training=True):
         """forward + losses + backward + AdamW, all enqueued, no host sync.  Returns (loss[4], counts[4]) on device."""

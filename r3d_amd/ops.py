@@ -382,6 +382,16 @@ def adamw_flat(p, g, m, v, lr_t, step_t, *, beta1=0.9, beta2=0.999, eps=1e-8, we
                              _stream()), "r3d_adamw_flat")
 
 
+def adamw_2d(p, g, m, v, lr_t, step_t, *, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, grad_scale=1.0):
+    """p, g, m, v: [rows, cols] views with the same (possibly larger) row stride."""
+    lib = _lib.load()
+    rows, cols = p.shape
+    ld = _ld(p)
+    assert _ld(g) == ld and _ld(m) == ld and _ld(v) == ld and g.shape == p.shape
+    check(lib.r3d_adamw_2d(_p(p), _p(g), _p(m), _p(v), rows, cols, ld, _p(lr_t), _p(step_t), beta1, beta2, eps, weight_decay,
+                           grad_scale, _stream()), "r3d_adamw_2d")
+
+
 def dropout_mask(mask, p, seed, offset_t=None):
     lib = _lib.load()
     assert mask.dtype == torch.uint8 and mask.is_contiguous()

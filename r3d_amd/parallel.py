@@ -13,9 +13,20 @@ cross-batch couplings of SURVEY.md 8(e):
 
 The class only needs an object with the engine's hook attributes and tensors, so its logic is exercised on CPU with
 the gloo backend in tests/test_parallel_cpu.py.
+
+PixelShardedDepth (opt-in) removes the big bucket altogether: depth_projection.weight [H, 50176] -- 86 % of the
+trainable parameters at H=128 -- becomes tensor-parallel over PIXELS.  Rank r owns columns [r*P/W, (r+1)*P/W) of the
+weight, of its gradient and of both AdamW moments; what crosses xGMI instead of the 25.7 MB gradient is
+  * the depth INPUT, all-to-all (each rank receives its pixel block of every rank's clips): half the bytes of the
+    gradient all-reduce and, unlike it, known before the step starts -> prefetched under the previous step;
+  * two [sum_r N_r, H] activations (512 KB at 8 GPUs): the partial products forward, d(depth_pre) backward.
+The mathematics is unchanged (the sum over pixels is split across ranks instead of across split-K workgroups).
 """
 import torch
 import torch.distributed as dist
+
+from . import ops
+from ._lib import GEMM_NT, GEMM_TN
 
 
 def shard_range(n_items, rank, world):
@@ -25,8 +36,130 @@ def shard_range(n_items, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+class PixelShardedDepth:
+    """depth_projection (futr_safuser_tokenfusion.py:143,194-195) tensor-parallel over its 50176 input pixels."""
+
+    def __init__(self, engine, process_group=None, equal_batches=True, input_group=None):
+        """input_group: a second communicator for the input all-to-all, so that a prefetch does not queue ahead of the
+        step's own (latency-critical) exchanges on the gradient communicator's stream."""
+        self.eng, self.pg = engine, process_group
+        self.pg_in = input_group if input_group is not None else process_group
+        self.world, self.rank = dist.get_world_size(process_group), dist.get_rank(process_group)
+        P, H = engine.P, engine.H
+        if P % (4 * self.world):
+            raise ValueError(f"{P} depth pixels do not split into {self.world} 16-byte aligned column blocks")
+        self.Pr = P // self.world
+        self.p0 = self.rank * self.Pr
+        a = engine.arena
+        o, n, _ = a.offsets["depth_projection.weight"]
+        cols = slice(self.p0, self.p0 + self.Pr)
+        self.w = a.params[o:o + n].view(H, P)[:, cols]
+        self.g = a.grads[o:o + n].view(H, P)[:, cols]
+        self.m = a.exp_avg[o:o + n].view(H, P)[:, cols]
+        self.v = a.exp_avg_sq[o:o + n].view(H, P)[:, cols]
+        self.equal = equal_batches
+        self.native_a2a = dist.get_backend(process_group) == "nccl"
+        self.gemm = ops.gemm              # (tests substitute a CPU stand-in to rehearse the exchange logic)
+        self.bufs = {}
+        self.ready = {}                   # data_ptr of a depth batch -> its exchanged shard (prefetched)
+        engine.tp = self
+
+    def _buf(self, key, shape):
+        if key not in self.bufs:
+            self.bufs[key] = torch.empty(*shape, dtype=torch.float32, device=self.eng.device)
+        return self.bufs[key]
+
+    def _rows(self, N):
+        if self.equal:
+            return [N] * self.world
+        t = torch.zeros(self.world, dtype=torch.int64, device=self.eng.device)
+        t[self.rank] = N
+        dist.all_reduce(t, group=self.pg)
+        return [int(x) for x in t.cpu()]
+
+    # -- inputs ------------------------------------------------------------------------------------------------
+    def shard_inputs(self, x_dep, slot=0, async_op=False):
+        """[N, P] depth rows of THIS rank's clips -> [sum_r N_r, P/W]: this rank's pixel block of EVERY rank's clips
+        (rows ordered by rank).  async_op: the exchange runs on the communicator's stream; inputs() joins it."""
+        W, Pr = self.world, self.Pr
+        N = x_dep.shape[0]
+        rows = self._rows(N)
+        tot = sum(rows)
+        recv = self._buf(("recv", tot, slot), (tot, Pr))
+        work = None
+        if self.native_a2a:
+            send = self._buf(("send", N, slot), (W, N, Pr))
+            send.copy_(x_dep.view(N, W, Pr).transpose(0, 1))
+            if all(r == N for r in rows):
+                work = dist.all_to_all_single(recv, send.view(W * N, Pr), group=self.pg_in, async_op=async_op)
+            else:
+                work = dist.all_to_all_single(recv, send.view(W * N, Pr), output_split_sizes=rows,
+                                              input_split_sizes=[N] * W, group=self.pg_in, async_op=async_op)
+        else:                             # backends without all-to-all (gloo rehearsal): W broadcasts
+            off = 0
+            for j in range(W):
+                full = x_dep if j == self.rank else self._buf(("bc", rows[j]), (rows[j], self.eng.P))
+                dist.broadcast(full, src=dist.get_global_rank(self.pg_in, j) if self.pg_in is not None else j,
+                               group=self.pg_in)
+                recv[off:off + rows[j]].copy_(full[:, self.p0:self.p0 + Pr])
+                off += rows[j]
+        sh = dict(x=recv, rows=rows, off=sum(rows[:self.rank]), n=N, work=work if async_op else None)
+        return sh
+
+    def prefetch(self, x_dep, slot=0):
+        """Start the exchange for a batch a later step will use (its depth tensor must stay unchanged until then)."""
+        self.ready[x_dep.data_ptr()] = self.shard_inputs(x_dep, slot, async_op=self.native_a2a)
+
+    def inputs(self, x_dep):
+        sh = self.ready.pop(x_dep.data_ptr(), None)
+        if sh is None:
+            sh = self.shard_inputs(x_dep)
+        if sh["work"] is not None:
+            sh["work"].wait()             # stream-level join, the host does not block
+            sh["work"] = None
+        assert sh["n"] == x_dep.shape[0]
+        return sh
+
+    # -- forward -----------------------------------------------------------------------------------------------
+    def partial_forward(self, w, x_dep, ws):
+        sh = self.inputs(x_dep)
+        tot = sh["x"].shape[0]
+        w.tp_in = sh
+        w.tp_part = self._buf(("part", tot), (tot, self.eng.H))
+        self.gemm(GEMM_NT, sh["x"], self.w, w.tp_part, ws=ws)
+
+    def exchange_forward(self, w):
+        dist.all_reduce(w.tp_part, group=self.pg)
+
+    def summed(self, w):
+        o = w.tp_in["off"]
+        return w.tp_part[o:o + w.tp_in["n"]]
+
+    # -- backward ----------------------------------------------------------------------------------------------
+    def exchange_backward(self, w):
+        sh = w.tp_in
+        tot = sh["x"].shape[0]
+        g = self._buf(("dpre", tot), (tot, self.eng.H))
+        g.zero_()
+        g[sh["off"]:sh["off"] + sh["n"]].copy_(w.d_dep_pre)
+        dist.all_reduce(g, group=self.pg)                    # a gather: every other rank contributed zeros here
+        w.tp_dpre_all = g
+
+    def wgrad(self, w, ws):
+        self.gemm(GEMM_TN, w.tp_dpre_all, w.tp_in["x"], self.g, ws=ws)
+
+    # -- replicated view (validation, checkpoints) -----------------------------------------------------------------
+    def sync_full_weight(self):
+        """All ranks end with the complete depth_projection.weight (each owned only its pixel columns)."""
+        W = self.eng.arena.p("depth_projection.weight")
+        tmp = torch.zeros_like(W)
+        tmp[:, self.p0:self.p0 + self.Pr] = self.w
+        dist.all_reduce(tmp, group=self.pg)
+        W.copy_(tmp)
+
+
 class DataParallelStep:
-    def __init__(self, engine, process_group=None):
+    def __init__(self, engine, process_group=None, pixel_shard=False, equal_batches=True, input_group=None):
         self.eng = engine
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -40,11 +173,16 @@ class DataParallelStep:
         engine.score_allreduce = self._scores
         if self.world > 1:
             engine.dur_den = self._den
+        self.tp = None
+        if pixel_shard and self.world > 1:
+            self.tp = PixelShardedDepth(engine, process_group, equal_batches, input_group)
 
     # -- 1. gradients ------------------------------------------------------------------------------------------
     def _on_stage(self, stage):
         if self.world == 1:
             return
+        if stage == "big_ready" and self.tp is not None:
+            return                        # that gradient is already complete on the rank that owns the columns
         buf = self.small if stage == "small_ready" else self.big
         if buf.numel():
             self.works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))

@@ -91,7 +91,11 @@ def train(args, model, train_loader, optimizer, scheduler, criterion, model_save
     model.to(device)
     model.train()
     eng = core.engine()
-    dp = DataParallelStep(eng) if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else None
+    dp = None
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        # --pixel_shard: depth_projection tensor-parallel over pixels (parallel.PixelShardedDepth); per-rank batch sizes may
+        # differ at the end of an epoch, so the row counts are exchanged every step
+        dp = DataParallelStep(eng, pixel_shard=getattr(args, "pixel_shard", False), equal_batches=False)
     if dp is not None:
         dp.broadcast_parameters()
     is_main = dp is None or dp.rank == 0
@@ -147,6 +151,8 @@ def train(args, model, train_loader, optimizer, scheduler, criterion, model_save
             if args.task == "long":
                 print("dur loss: %.5f" % (float(lsum[2]) / denom if denom else 0.0))
         scheduler.step()
+        if dp is not None and dp.tp is not None:
+            dp.tp.sync_full_weight()                                 # validation and checkpoints see the complete weight
         val_loss, val_acc, weight_acc = validate(model, val_loader, criterion, pad_idx, device)
         if getattr(args, "restore_train_mode", False):
             model.train()

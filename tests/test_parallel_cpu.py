@@ -122,3 +122,91 @@ def test_shard_range_partitions_everything():
             assert cuts[0][0] == 0 and cuts[-1][1] == n
             assert all(cuts[i][1] == cuts[i + 1][0] for i in range(w - 1))
             assert max(h - l for l, h in cuts) - min(h - l for l, h in cuts) <= 1
+
+
+# ---- pixel-sharded depth projection: the exchange logic with ragged per-rank batches (CPU stand-in for the GEMM) ----
+class _TpArena:
+    def __init__(self, H, P, seed):
+        g = torch.Generator().manual_seed(seed)
+        self.offsets = {"depth_projection.weight": (8, H * P, (H, P))}
+        self.params = torch.randn(8 + H * P, generator=g)
+        self.grads = torch.zeros(8 + H * P)
+        self.exp_avg = torch.zeros(8 + H * P)
+        self.exp_avg_sq = torch.zeros(8 + H * P)
+
+    def p(self, n):
+        o, k, shp = self.offsets[n]
+        return self.params[o:o + k].view(shp)
+
+
+class _TpEngine:
+    def __init__(self, H, P):
+        self.H, self.P, self.device, self.tp = H, P, torch.device("cpu"), None
+        self.arena = _TpArena(H, P, 7)
+
+
+def _cpu_gemm(layout, A, B, C, ws=None):
+    from r3d_amd._lib import GEMM_NT
+    C.copy_(A @ B.t() if layout == GEMM_NT else A.t() @ B)
+
+
+class _W:
+    pass
+
+
+def _tp_worker(rank, world, port, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.set_num_threads(2)
+        from r3d_amd.parallel import PixelShardedDepth
+        H, P = 8, 48
+        rows = [5, 3]                                           # ragged: the last batch of an epoch
+        g = torch.Generator().manual_seed(3)
+        X = [torch.randn(r, P, generator=g) for r in rows]       # every rank can rebuild every rank's inputs
+        D = [torch.randn(r, H, generator=g) for r in rows]
+        eng = _TpEngine(H, P)
+        tp = PixelShardedDepth(eng, equal_batches=False)
+        tp.gemm = _cpu_gemm
+        Wfull = eng.arena.p("depth_projection.weight").clone()
+        w = _W()
+        for use_prefetch in (False, True):
+            if use_prefetch:
+                tp.prefetch(X[rank], slot=1)
+            tp.partial_forward(w, X[rank], None)
+            tp.exchange_forward(w)
+            got = tp.summed(w)
+            assert torch.allclose(got, X[rank] @ Wfull.t(), atol=1e-5), "forward: sum of the ranks' pixel blocks"
+            w.d_dep_pre = D[rank]
+            tp.exchange_backward(w)
+            tp.wgrad(w, None)
+            want = sum(d.t() @ x for d, x in zip(D, X))          # what the all-reduce of the replicated run would hold
+            assert torch.allclose(tp.g, want[:, tp.p0:tp.p0 + tp.Pr], atol=1e-5), "weight gradient of the owned columns"
+        # each rank updates only its columns; sync_full_weight() restores one complete, identical weight everywhere
+        tp.w.add_(float(rank + 1))
+        tp.sync_full_weight()
+        full = eng.arena.p("depth_projection.weight")
+        for r in range(world):
+            blk = slice(r * tp.Pr, (r + 1) * tp.Pr)
+            assert torch.allclose(full[:, blk], Wfull[:, blk] + float(r + 1))
+        q.put((rank, "ok", ""))
+    except Exception as e:          # noqa: BLE001
+        import traceback
+        q.put((rank, "fail", traceback.format_exc() + repr(e)))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_pixel_sharded_depth_exchange_two_ranks_ragged():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, status, info in res:
+        assert status == "ok", f"rank {rank}: {info}"

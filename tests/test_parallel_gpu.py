@@ -1,0 +1,130 @@
+"""Two ranks sharing one MI355X (gloo rendezvous, world_size 2): the pixel-sharded depth projection
+(r3d_amd.parallel.PixelShardedDepth) must give the same training step as the replicated data-parallel step -- same
+losses, same gradients (the sharded rank holds the SUM over ranks in its pixel columns, exactly what the all-reduce
+leaves in the replicated run), same parameters after AdamW."""
+import argparse
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+from tests.helpers import load_fixture, fixture_params, fixture_batch  # noqa: E402
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _model(fx):
+    from r3d_amd.model.futr_safuser_tokenfusion import FUTR
+    m = fx["meta"]
+    args = argparse.Namespace(input_dim=2048, seg=True, anticipate=True, max_pos_len=2000, input_type="i3d_transcript")
+    model = FUTR(m["n_class"], m["H"], m["pad_idx"], torch.device("cuda"), args, n_query=m["n_query"], n_head=m["n_head"],
+                 num_encoder_layers=2, num_decoder_layers=m["n_dec"])
+    model.load_state_dict(fixture_params(fx), strict=False)
+    return model.to("cuda").eval()
+
+
+def _run(fx, rank, pixel_shard, steps, prefetch):
+    from r3d_amd.parallel import DataParallelStep
+    m = fx["meta"]
+    model = _model(fx)
+    eng = model.engine()
+    dp = DataParallelStep(eng, pixel_shard=pixel_shard)
+    dp.broadcast_parameters()
+    batches = [[t.cuda() for t in fixture_batch(fx, seed=100 + 10 * s + rank)] for s in range(steps)]
+    rec = []
+    if prefetch and dp.tp is not None:
+        dp.tp.prefetch(batches[0][1].reshape(m["B"] * m["S"], -1), slot=0)
+    for s, (feats, depth, lab, dur, tgt) in enumerate(batches):
+        dp.prepare_duration_denominator(dur, m["pad_idx"])
+        eng.forward_begin(feats, depth, lab, "train", False)
+        if prefetch and dp.tp is not None and s + 1 < steps:          # next batch's exchange under this step
+            dp.tp.prefetch(batches[s + 1][1].reshape(m["B"] * m["S"], -1), slot=(s + 1) % 2)
+        if dp.tp is not None:
+            dp.tp.exchange_forward(eng._fw["w"])
+        eng.forward_finish()
+        loss, _ = eng.losses(lab, tgt, dur)
+        eng.backward()
+        dp.wait_grads()
+        torch.cuda.synchronize()
+        g = eng.arena.grads.clone()
+        dep = eng.last["w"].dep.clone()
+        eng.adamw(m["lr"], m["wd"], grad_scale=dp.grad_scale)
+        rec.append(dict(loss=loss.clone(), grads=g, dep=dep))
+    if dp.tp is not None:
+        dp.tp.sync_full_weight()
+    torch.cuda.synchronize()
+    return eng, dp, rec
+
+
+def _worker(rank, world, port, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        fx = load_fixture("step_tiny")
+        lr = fx["meta"]["lr"]
+        engA, dpA, recA = _run(fx, rank, False, 2, False)
+        msgs = []
+        for prefetch in (False, True):
+            engB, dpB, recB = _run(fx, rank, True, 2, prefetch)
+            a, b = engA.arena, engB.arena
+            o, n, _ = a.offsets["depth_projection.weight"]
+            H, P = engA.H, engA.P
+            cols = slice(dpB.tp.p0, dpB.tp.p0 + dpB.tp.Pr)
+            for s in range(2):
+                ra, rb = recA[s], recB[s]
+                tol = 1e-5 if s == 0 else 2e-2          # step 2 starts from parameters that differ by AdamW's step-1
+                                                         # sign sensitivity where |g| ~ 0 (see test_engine_gpu)
+                assert torch.allclose(ra["loss"], rb["loss"], rtol=tol, atol=1e-6), (s, ra["loss"], rb["loss"])
+                sc = float(ra["dep"].abs().max())
+                assert float((ra["dep"] - rb["dep"]).abs().max()) <= tol * sc
+                if s == 0:
+                    ga, gb = ra["grads"], rb["grads"]
+                    small = slice(0, a.bucket_small[1])
+                    sc = float(ga[small].abs().max())
+                    assert float((ga[small] - gb[small]).abs().max()) <= 1e-5 * sc
+                    gwa, gwb = ga[o:o + n].view(H, P)[:, cols], gb[o:o + n].view(H, P)[:, cols]
+                    sc = float(gwa.abs().max())
+                    assert float((gwa - gwb).abs().max()) <= 1e-5 * sc, "sharded depth weight gradient"
+            pa, pb = a.params[:a.n_live], b.params[:b.n_live]
+            d = (pa - pb).abs()
+            assert float(d.max()) <= 2 * 2.1 * lr, float(d.max())
+            frac = float((d <= 1e-5 * (1 + pa.abs())).double().mean())
+            assert frac > 0.97, frac
+            # every rank ends with the same complete weight
+            t = pb.clone()
+            dist.broadcast(t, src=0)
+            assert torch.equal(t, pb)
+            msgs.append((prefetch, frac))
+        q.put((rank, "ok", msgs))
+    except Exception as e:          # noqa: BLE001
+        import traceback
+        q.put((rank, "fail", traceback.format_exc() + repr(e)))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_pixel_sharded_depth_matches_replicated_two_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, status, info in res:
+        assert status == "ok", f"rank {rank}: {info}"
