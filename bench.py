@@ -249,10 +249,11 @@ def main():
                     if sh["work"] is not None:
                         sh["work"].wait()                # stream-level join with the prefetched all-to-all
                     slot[0] = cur ^ 1
+                    dp.prepare_duration_denominator(dur, c["K"] + 1, async_group=pg_in)   # joins before the losses
                     tp.prefetch(x_dep2d, slot[0])        # next step's input, on its own communicator
-                    dp.prepare_duration_denominator(dur, c["K"] + 1)
                     gA[cur].replay()
                     tp.exchange_forward(w_)
+                    dp.wait_duration_denominator()
                     gB.replay()
                     tp.exchange_backward(w_)
                     dp._on_stage("small_ready")          # all-reduce of the replicated parameters' gradients under gC

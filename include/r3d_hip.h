@@ -223,6 +223,12 @@ int r3d_dropout_mask(uint8_t* mask, int64_t n, float p, uint64_t seed, const int
 int64_t r3d_erank_lds_bytes(int R, int C);
 int r3d_erank_jacobi(const float* x, int ld, int64_t batch_stride, int batch, int R, int C, int gram, float* sigma,
                      float* af_t, float* stats, int max_sweeps, void* stream);
+/* Any size: two-level (block) one-sided Jacobi with the columns in HBM; one matrix X[R, C].  r3d_erank_blocked_sizes
+ * fills out[0] = floats of af_t ([Cpad][R], the rotated columns (X V)^T, zero rows past C), out[1] = ints of ctrl
+ * (scratch).  sigma [C] unsorted, stats [4] = {erank, entropy, sum sigma, sweeps}.  Enqueues its launches, no sync. */
+int r3d_erank_blocked_sizes(int R, int C, int max_sweeps, int64_t* out);
+int r3d_erank_blocked(const float* x, int ld, int R, int C, float* sigma, float* af_t, int* ctrl, float* stats,
+                      int max_sweeps, void* stream);
 int r3d_erank_bwd_coef(const float* sigma, const float* stats, const float* gout, float* coef, int C, void* stream);
 int r3d_scale_rows(float* x, int ld, int rows, int cols, const float* coef, void* stream);
 

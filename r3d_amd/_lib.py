@@ -87,6 +87,8 @@ _SIGNATURES = {
     "r3d_dropout_mask": ([_P, _L, _F, C.c_uint64, _P, _P], C.c_int),
     "r3d_erank_lds_bytes": ([_I, _I], C.c_int64),
     "r3d_erank_jacobi": ([_P, _I, _L, _I, _I, _I, _I, _P, _P, _P, _I, _P], C.c_int),
+    "r3d_erank_blocked_sizes": ([_I, _I, _I, _P], C.c_int),
+    "r3d_erank_blocked": ([_P, _I, _I, _I, _P, _P, _P, _P, _I, _P], C.c_int),
     "r3d_erank_bwd_coef": ([_P, _P, _P, _P, _I, _P], C.c_int),
     "r3d_scale_rows": ([_P, _I, _I, _I, _P, _P], C.c_int),
 }

@@ -414,6 +414,23 @@ def erank_jacobi(x, sigma, stats, *, af_t=None, gram=False, max_sweeps=30):
                                max_sweeps, _stream()), "r3d_erank_jacobi")
 
 
+def erank_blocked(x, max_sweeps=30):
+    """x: [R, C] (row stride >= C).  Returns (sigma [C], stats [4], af_t [Cpad, R]) -- any size, columns in HBM."""
+    import ctypes
+    lib = _lib.load()
+    R, Cc = x.shape
+    assert x.stride(1) == 1
+    sz = (ctypes.c_int64 * 2)()
+    check(lib.r3d_erank_blocked_sizes(R, Cc, max_sweeps, ctypes.cast(sz, ctypes.c_void_p)), "r3d_erank_blocked_sizes")
+    af_t = torch.empty(sz[0] // R, R, dtype=torch.float32, device=x.device)
+    ctrl = torch.empty(sz[1], dtype=torch.int32, device=x.device)
+    sigma = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    stats = torch.empty(4, dtype=torch.float32, device=x.device)
+    check(lib.r3d_erank_blocked(_p(x), x.stride(0), R, Cc, _p(sigma), _p(af_t), _p(ctrl), _p(stats), max_sweeps, _stream()),
+          "r3d_erank_blocked")
+    return sigma, stats, af_t
+
+
 def erank_bwd_coef(sigma, stats, gout, coef):
     lib = _lib.load()
     check(lib.r3d_erank_bwd_coef(_p(sigma), _p(stats), _p(gout), _p(coef), sigma.numel(), _stream()), "r3d_erank_bwd_coef")

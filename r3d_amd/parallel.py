@@ -197,13 +197,22 @@ class DataParallelStep:
         return 1.0 / self.world
 
     # -- 2. duration denominator ---------------------------------------------------------------------------------
-    def prepare_duration_denominator(self, target_dur, pad_idx):
-        """Call before the step's loss kernel: den = (global count of non-pad duration targets) / world."""
+    def prepare_duration_denominator(self, target_dur, pad_idx, async_group=None):
+        """Call before the step's loss kernel: den = (global count of non-pad duration targets) / world.
+        async_group: run the all-reduce asynchronously on that communicator (under the input projections); the caller
+        joins it with wait_duration_denominator() before the loss kernel is enqueued."""
         if self.world == 1:
             return
-        self._den.copy_((target_dur != pad_idx).sum().to(torch.float32).reshape(1))
-        dist.all_reduce(self._den, op=dist.ReduceOp.SUM, group=self.pg)
-        self._den.div_(self.world)
+        torch.mul((target_dur != pad_idx).sum().to(torch.float32).reshape(1), 1.0 / self.world, out=self._den)
+        if async_group is None:
+            dist.all_reduce(self._den, op=dist.ReduceOp.SUM, group=self.pg)
+        else:
+            self._den_work = dist.all_reduce(self._den, op=dist.ReduceOp.SUM, group=async_group, async_op=True)
+
+    def wait_duration_denominator(self):
+        w, self._den_work = getattr(self, "_den_work", None), None
+        if w is not None:
+            w.wait()
 
     # -- 3. eval-mode selection scores ------------------------------------------------------------------------
     def _scores(self, sums, n_local):

@@ -472,3 +472,43 @@ def test_erank_jacobi_vs_svdvals(ops, R, Cc):
     G = aft[0].cpu().double() @ aft[0].cpu().double().t()
     off = G - torch.diag(torch.diag(G))
     assert float(off.abs().max()) < 1e-3 * float(sv[0]) ** 2
+
+
+@pytest.mark.parametrize("R,Cc", [(512, 512), (128, 512), (2048, 256), (300, 200), (64, 40)])
+def test_erank_blocked_vs_svdvals(ops, R, Cc):
+    """The two-level Jacobi (columns in HBM) for matrices that exceed one CU's LDS -- and small ones for coverage."""
+    from oracle import futr_oracle as O
+    from r3d_amd.erank import effective_rank
+    # a prescribed, well separated spectrum: in fp32 the singular VECTORS of sigma_k (and with them the gradient) carry
+    # a relative error ~ eps * sigma_max / gap, so the gradient check needs a matrix whose small singular values are
+    # not crowded (a raw square random matrix has sigma_min ~ 1e-3 sigma_max)
+    k = min(R, Cc)
+    q1 = torch.linalg.qr(rnd(R, k, seed=R + Cc).double())[0]
+    q2 = torch.linalg.qr(rnd(Cc, k, seed=R + Cc + 1).double())[0]
+    x = (q1 @ torch.diag(torch.linspace(0.2, 2.0, k).double()) @ q2.t()).float()
+    xd = dev(x)
+    if R >= Cc:
+        sig, st, aft = ops.erank_blocked(xd)
+        torch.cuda.synchronize()
+        sv = torch.linalg.svdvals(x.double())
+        assert_close(torch.sort(sig.cpu(), descending=True)[0], sv, 1e-4, 1e-4 * float(sv[0]), "sigma")
+        assert float(st[3]) < 30, "did not converge"
+        A = aft[:Cc].cpu().double()
+        G = A @ A.t()
+        off = G - torch.diag(torch.diag(G))
+        assert float(off.abs().max()) < 1e-3 * float(sv[0]) ** 2
+        assert float(aft[Cc:].abs().max()) == 0.0 if aft.shape[0] > Cc else True
+    # differentiable wrapper (handles R < C by working on the transpose); gradient against autograd through svdvals
+    xg = xd.clone().requires_grad_(True)
+    er = effective_rank(xg, route="blocked")
+    er.backward()
+    torch.cuda.synchronize()
+    xr = x.double().clone().requires_grad_(True)
+    s = torch.linalg.svdvals(xr)
+    p = s / s.sum()
+    ref = torch.exp(-(p * torch.log(p)).sum())
+    ref.backward()
+    assert abs(float(er.detach()) - float(ref.detach())) < 5e-3 * max(1.0, float(ref.detach()) / 50)
+    assert abs(float(er.detach()) - O.effective_rank(x)) < 0.5
+    sc = float(xr.grad.abs().max())
+    assert float((xg.grad.cpu().double() - xr.grad).abs().max()) < 2e-3 * sc
