@@ -21,6 +21,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 CFG = dict(B=8, S=16, H=128, K=17, D=2048, P=224 * 224, Q=8, heads=8, n_dec=1, n_enc=2, lr=1e-3, wd=5e-3)
+# BASELINE.json's other configurations at their per-GPU shapes: parity-test cases (tests/test_engine_gpu.py), selectable
+# here with --config for profiling only -- the headline line is always cfg2
+OTHER = dict(cfg3=dict(S=32), cfg4=dict(S=64, H=512), cfg5=dict(S=16, H=1024))
+NAMES = dict(cfg2="DARai RGB+Depth futr_safuser_tokenfusion, batch=8 per GPU, 16-frame clips, hidden=128, n_class=17, "
+                  "depth 224x224 (BASELINE.json configs[1])")
 
 
 def make_inputs(c, device, seed):
@@ -123,6 +128,9 @@ def main():
     ap.add_argument("--replicated-depth", action="store_true",
                     help="N>1: keep depth_projection replicated and all-reduce its 25.7 MB gradient (plain data parallel) "
                          "instead of sharding it over pixels")
+    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"],
+                    help="cfg2 = the headline workload; the others (per-GPU shapes of BASELINE.json configs[2..4]) are "
+                         "for profiling")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the "
                                                       "multi-rank control flow on one GPU)")
     a = ap.parse_args()
@@ -141,7 +149,7 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(a.backend)
-    c = CFG
+    c = dict(CFG, **OTHER.get(a.config, {}))
     model = build_model(c, device)
     if a.eval_dropout_off:
         model.eval()
@@ -326,8 +334,8 @@ def main():
                    value=world * c["B"] * a.steps / dt, unit="clips/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
                    ms_per_step=dt / a.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32",
                    data="synthetic",
-                   config=dict(workload="DARai RGB+Depth futr_safuser_tokenfusion, batch=8 per GPU, 16-frame clips, "
-                                        "hidden=128, n_class=17, depth 224x224 (BASELINE.json configs[1])",
+                   config=dict(workload=NAMES.get(a.config, f"{a.config} per-GPU shape B={c['B']} S={c['S']} H={c['H']} "
+                                                                  "(profiling only, not the headline workload)"),
                                global_batch=world * c["B"], clip_frames=c["S"], hidden=c["H"],
                                parallelism=f"dp{world}" + (f" ({mode})" if world > 1 else ""),
                                launch=launch, dropout="on" if training else "off"),
@@ -335,7 +343,7 @@ def main():
                    kernels={k: dict(us=v["seconds"] * 1e6, GBps=v["bytes"] / v["seconds"] / 1e9,
                                     TFLOPs=v["flops"] / v["seconds"] / 1e12) for k, v in kr.items()},
                    final_losses=loss_now)
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and a.config == "cfg2":
             out["cpu_baseline"] = cpu_baseline(c)
         print(json.dumps(out), flush=True)
     if world > 1:

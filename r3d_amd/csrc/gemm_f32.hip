@@ -551,37 +551,35 @@ R3D_EXPORT int64_t r3d_gemm_partial_floats(int32_t M, int32_t N, int32_t splitk)
 // tiles_m times), more splits add slab traffic.
 R3D_EXPORT int r3d_gemm_plan(r3d_gemm_desc* d) {
     if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0) return R3D_EINVAL;
-    static const int tile_waves[4] = {0, 4, 4, 4};
-    static const int tile_bk[4] = {0, 64, 64, 32};
-    static const double mfma_us_per_step[4] = {0, 0.25, 0.9, 1.8};    // MFMA time of one k-step of one wave
-    const double flops = 2.0 * d->M * d->N * (double)d->K;
+    // Constants fitted (tools/gemm_fit.py, log-space least squares, rms error 7 %, mean regret of the pick 1.6 %) to
+    // 1893 hipGraph-timed launches of tools/gemm_sweep.py on MI355X: 81 shapes x 5 tiles x split counts.
+    // Per unit of 64 k-elements a workgroup needs max(lat, load * thr) us, load = workgroups resident per CU.
+    static const double lat[6] = {0, 0.525, 1.394, 4.768, 1.309, 4.224};
+    static const double thr[6] = {0, 0.429, 1.387, 4.815, 1.291, 4.418};
+    static const double epi[6] = {0, 3.563, 3.284, 5.613, 2.852, 5.837};     // prologue + epilogue of one round
+    static const int occ[6] = {0, 8, 4, 1, 2, 1};
+    static const int cand[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 49, 61, 64, 96, 98, 122, 128, 192, 196, 256, 392, 512};
     double best = 1e300;
     int bt = 1, bs = 1, bk = d->K;
-    for (int t = 1; t <= 3; ++t) {
-        const long tm = r3d_cdiv(d->M, kTileSz[t]), tn = r3d_cdiv(d->N, kTileSz[t]);
-        const long tiles = tm * tn;
-        for (int sk = 1; sk <= 512; sk *= 2) {
-            int kps = r3d_cdiv(r3d_cdiv(d->K, sk), 64) * 64;
+    for (int t = 1; t <= 5; ++t) {
+        const long tiles = (long)r3d_cdiv(d->M, kTileSz[t]) * r3d_cdiv(d->N, kTileSz[t]);
+        double lt = 1.0;
+        if (d->layout == R3D_GEMM_TN) lt = (t == 3 || t == 5) ? 1.053 : 0.996;
+        else if (d->layout == R3D_GEMM_NN) lt = 1.074;
+        int last_ns = 0;
+        for (int sk : cand) {
+            const int kps = (sk == 1) ? d->K : r3d_cdiv(r3d_cdiv(d->K, sk), 64) * 64;
             if (sk > 1 && kps < 128) break;
             const int ns = r3d_cdiv(d->K, kps);
-            if (sk > 1 && ns < 2) continue;
-            const long waves = tiles * ns * tile_waves[t];
-            const double rounds = (double)((waves + 1023) / 1024);
-            const double occ = (double)waves / (1024.0 * rounds);                 // SIMD fill
-            const int steps = r3d_cdiv(kps, tile_bk[t]);
-            // a step is MFMA-bound only when a SIMD has other waves to run while one waits on HBM (~2 us)
-            const double lat = occ < 0.5 ? 0.7 : 0.5;        // measured with the depth-2 prefetch
-            const double step_us = mfma_us_per_step[t] > lat ? mfma_us_per_step[t] : lat;
-            // operand re-fetch through L2 at ~10 TB/s aggregate, HBM once at ~5 TB/s
-            const double l2_us = 4.0 * ((double)d->M * d->K * tn + (double)d->N * d->K * tm) / 10.0e6;
-            const double hbm_us = 4.0 * ((double)d->M * d->K + (double)d->N * d->K) / 5.0e6;
-            const double slab_us = (ns > 1) ? 7.0 + 2.0 * 4.0 * ns * (double)d->M * d->N / 4.0e6 : 0.0;   // extra launch
-            const double mfma_us = flops / 140.0e6 / (occ < 1.0 ? occ : 1.0);
-            double t_us = rounds * steps * step_us + 3.0;
-            if (t_us < l2_us) t_us = l2_us;
-            if (t_us < hbm_us) t_us = hbm_us;
-            if (t_us < mfma_us) t_us = mfma_us;
-            t_us += slab_us;
+            if (ns == last_ns || (sk > 1 && ns < 2)) continue;
+            last_ns = ns;
+            const long wgs = tiles * ns;
+            const long ncu = (wgs + 255) / 256;
+            const double load = ncu <= 4 ? (double)ncu : (double)wgs / 256.0;
+            const double unit = lat[t] > load * thr[t] * lt ? lat[t] : load * thr[t] * lt;
+            const double rounds = (double)((ncu + occ[t] - 1) / occ[t]);
+            double t_us = 1.118 + r3d_cdiv(kps, 64) * unit + rounds * epi[t];
+            if (ns > 1) t_us += 5.0 + 2.0 * 4.0 * ns * (double)d->M * d->N / 4.0e6;     // slabs out and back + the reducer
             if (t_us < best) { best = t_us; bt = t; bs = ns; bk = kps; }
         }
     }

@@ -475,7 +475,7 @@ class FusionEngine:
         add(w.d_u, w.h2, a.g(pre + "mlp.mlp.0.weight"), a.g(pre + "mlp.mlp.0.bias"))
         add(w.d_x1, w.vsw, a.g(pre + "attn.proj.weight"), a.g(pre + "attn.proj.bias"))
         add(w.d_v, w.h1, a.g(pre + "attn.qkv.weight")[2 * H:], None)          # rows [0,2H) (Q,K) stay exactly zero
-        w.wgrad_group = ops.GemmGroup(GEMM_TN, P, tile=1)
+        w.wgrad_group = ops.GemmGroup(GEMM_TN, P, tile=1 if H < 256 else 2)
         J = [(w.lnp["final"], BQ, H, a.g("transformer.decoder.norm.weight"), a.g("transformer.decoder.norm.bias")),
              (w.lnp["nf"], 2 * N, H, a.g("fuser.norm.weight"), a.g("fuser.norm.bias")),
              (w.lnp["n2"], 2 * N, H, a.g(pre + "norm2.weight"), a.g(pre + "norm2.bias")),

@@ -25,7 +25,20 @@ def main():
     shapes = {"depth_fwd_cfg2": (0, 128, 128, 50176), "depth_wgrad_cfg2": (2, 128, 50176, 128),
               "rgb_fwd_cfg2": (0, 128, 128, 2048), "fuser_fc1_cfg2": (0, 256, 512, 128), "fuser_fc2_cfg2": (0, 256, 128, 512),
               "dec_64x128x128": (0, 64, 128, 128), "depth_fwd_cfg4": (0, 512, 512, 50176), "depth_wgrad_cfg4": (2, 512, 50176, 512)}
+    for H in (128, 512, 1024):
+        for N in (128, 512, 1024):
+            shapes[f"dfwd_N{N}_H{H}"] = (0, N, H, 50176)
+            shapes[f"dwg_N{N}_H{H}"] = (2, H, 50176, N)
+            shapes[f"rgbf_N{N}_H{H}"] = (0, N, H, 2048)
+            shapes[f"rgbwg_N{N}_H{H}"] = (2, H, 2048, N)
+            shapes[f"fc1_N{N}_H{H}"] = (0, 2 * N, 4 * H, H)
+            shapes[f"fc2_N{N}_H{H}"] = (0, 2 * N, H, 4 * H)
+            shapes[f"dfc2_N{N}_H{H}"] = (1, 2 * N, 4 * H, H)
+            shapes[f"dfc1_N{N}_H{H}"] = (1, 2 * N, H, 4 * H)
+            shapes[f"wgfc1_N{N}_H{H}"] = (2, 4 * H, H, 2 * N)
     names = sys.argv[1:] or list(shapes)
+    if names == ["grid"]:
+        names = [k for k in shapes if "_N" in k]
     out = {}
     for name in names:
         layout, M, N, K = shapes[name]
