@@ -46,6 +46,7 @@ __device__ __forceinline__ void mm16_nt(const float* X, int ldx, int K, const fl
         const bool nok = active && n < N;
         const int kh = K >> 1;                                  // K is a multiple of 32 on this path (H, 4H)
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        __syncthreads();                  // the lower halves of a PREVIOUS k-split call may still be reading `red`
         if (active) {
             const float* wrow = W + (size_t)(nok ? n : 0) * ldw + half * kh + 4 * kq;
             const float* xrow = X + i * ldx + half * kh + 4 * kq;

@@ -428,9 +428,26 @@ __device__ __forceinline__ void gemm_body(const r3d_gemm_desc& d, int tile, int 
 
 
 template <int LA, int LB, int BM, int BN, int BK, int WM, int WN, int WK, bool VEC>
-__global__ __launch_bounds__(64 * WM * WN * WK) void gemm_f32_kernel(const r3d_gemm_desc d) {
+__global__ __launch_bounds__(64 * WM * WN * WK) void gemm_f32_kernel(const r3d_gemm_desc d, const int mode, const int G,
+                                                                     const int NG) {
     __shared__ __attribute__((aligned(16))) float smem[gemm_lds_floats<LA, LB, BM, BN, BK>()];
-    gemm_body<LA, LB, BM, BN, BK, WM, WN, WK, VEC>(d, blockIdx.x, blockIdx.y, smem);
+    // XCD-aware placement.  Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one L2), so workgroups
+    // that stream the SAME operand panel must have equal linear id mod 8 or every one of them pulls its own copy over
+    // the fabric (measured on the depth projection: FETCH_SIZE = 2.0x the algorithmic bytes with the 2-D grid).
+    // A group = G workgroups sharing a panel; group g goes to XCD g % 8, its members sit at stride 8.
+    //   mode 1: group = one K-split, members = its output tiles
+    //   mode 2: group = one column of tiles (shares the B panel), mode 3: one row of tiles (shares the A panel)
+    int tile = blockIdx.x, split = blockIdx.y;
+    if (mode != 0) {
+        const int p = blockIdx.x, idx = p >> 3;
+        const int g = (idx / G) * 8 + (p & 7), mem = idx % G;
+        if (g >= NG) return;
+        const int tiles_n = (d.N + BN - 1) / BN;
+        if (mode == 1) { tile = mem; split = g; }
+        else if (mode == 2) { tile = mem * tiles_n + g; split = 0; }
+        else { tile = g * tiles_n + mem; split = 0; }
+    }
+    gemm_body<LA, LB, BM, BN, BK, WM, WN, WK, VEC>(d, tile, split, smem);
 }
 
 // Many independent problems (same layout and tile config, splitk == 1) in one launch.  prefix[p] = first workgroup
@@ -465,9 +482,15 @@ static const int kTileSz[6] = {0, 32, 64, 128, 64, 128};
 
 template <int LA, int LB, int BM, int BN, int BK, int WM, int WN, int WK>
 static int launch_cfg(const r3d_gemm_desc& d, int nsplit, hipStream_t s) {
-    dim3 grid(r3d_cdiv(d.M, BM) * r3d_cdiv(d.N, BN), nsplit, 1);
-    if (d.vec) hipLaunchKernelGGL((gemm_f32_kernel<LA, LB, BM, BN, BK, WM, WN, WK, true>), grid, dim3(64 * WM * WN * WK), 0, s, d);
-    else hipLaunchKernelGGL((gemm_f32_kernel<LA, LB, BM, BN, BK, WM, WN, WK, false>), grid, dim3(64 * WM * WN * WK), 0, s, d);
+    const int tm = r3d_cdiv(d.M, BM), tn = r3d_cdiv(d.N, BN);
+    dim3 grid(tm * tn, nsplit, 1);
+    int mode = 0, G = 1, NG = 1;
+    if (nsplit > 1 && tm * tn > 1 && tm * tn <= 32) { mode = 1; G = tm * tn; NG = nsplit; }
+    else if (nsplit == 1 && tm >= 2 && tm <= 16 && tn >= 16) { mode = 2; G = tm; NG = tn; }
+    else if (nsplit == 1 && tn >= 2 && tn <= 16 && tm >= 16) { mode = 3; G = tn; NG = tm; }
+    if (mode) grid = dim3(8 * G * r3d_cdiv(NG, 8), 1, 1);
+    if (d.vec) hipLaunchKernelGGL((gemm_f32_kernel<LA, LB, BM, BN, BK, WM, WN, WK, true>), grid, dim3(64 * WM * WN * WK), 0, s, d, mode, G, NG);
+    else hipLaunchKernelGGL((gemm_f32_kernel<LA, LB, BM, BN, BK, WM, WN, WK, false>), grid, dim3(64 * WM * WN * WK), 0, s, d, mode, G, NG);
     R3D_LAUNCH_CHECK();
     return R3D_OK;
 }

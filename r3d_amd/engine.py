@@ -250,7 +250,11 @@ class FusionEngine:
                          ws=self.ws, defer_reduce=True)                          # (:194-195)
         else:
             tp.partial_forward(w, x_dep, self.ws)
-        self._fw = dict(w=w, x_rgb=x_rgb, x_dep=x_dep, labels=labels, mode=mode, drop=drop, d=d, tp=tp, B=B, S=S)
+        # the split-K slabs of the depth GEMM are consumed by the LayerNorm launch in forward_finish(): keep THIS buffer
+        # (a later, larger request would re-allocate the workspace) -- nothing may use self.ws before that launch
+        slabs = self.ws.buf if (d is not None and d.splitk > 1) else None
+        self._fw = dict(w=w, x_rgb=x_rgb, x_dep=x_dep, labels=labels, mode=mode, drop=drop, d=d, tp=tp, B=B, S=S,
+                        slabs=slabs)
 
     def forward_finish(self):
         """Everything after the input projections; see forward()."""
@@ -288,6 +292,18 @@ class FusionEngine:
             wi, bi = a.p(pl + "multihead_attn.in_proj_weight"), a.p(pl + "multihead_attn.in_proj_bias")
             ops.gemm(GEMM_NT, c["t1"], wi[:H], c["caq"], a_add=qpos, a_add_mod=Q, bias=bi[:H], ws=wsx)
 
+        # ---- depth LayerNorm + ReLU first: it drains the deferred split-K slabs (:196-197)
+        if tp is not None:                      # the exchanged sum of the ranks' partial products, bias still to add
+            ops.layernorm_fwd(tp.summed(w), a.p("depth_layernorm.weight"), a.p("depth_layernorm.bias"), w.dep, w.mean_d,
+                              w.rstd_d, relu=True, nsplit=1, bias=a.p("depth_projection.bias"), pre_out=w.dep_pre,
+                              rows=N, H=H)
+        elif d.splitk > 1:
+            ops.layernorm_fwd(fw["slabs"], a.p("depth_layernorm.weight"), a.p("depth_layernorm.bias"), w.dep, w.mean_d,
+                              w.rstd_d, relu=True, nsplit=d.splitk, bias=a.p("depth_projection.bias"),
+                              pre_out=w.dep_pre, rows=N, H=H)                    # (:196-197)
+        else:
+            ops.layernorm_fwd(w.dep_pre, a.p("depth_layernorm.weight"), a.p("depth_layernorm.bias"), w.dep, w.mean_d,
+                              w.rstd_d, relu=True)
         fused_dec = self.use_fused_decoder and ops.decoder_fused_supported(S, Q, H, heads)
         if fused_dec:
             multi = False                     # the whole layer is one launch: nothing left to branch
@@ -297,17 +313,6 @@ class FusionEngine:
         if not fused_dec:
             with torch.cuda.stream(s2):
                 sa_block(0, w.tgt0, ws2)
-        if tp is not None:                      # the exchanged sum of the ranks' partial products, bias still to add
-            ops.layernorm_fwd(tp.summed(w), a.p("depth_layernorm.weight"), a.p("depth_layernorm.bias"), w.dep, w.mean_d,
-                              w.rstd_d, relu=True, nsplit=1, bias=a.p("depth_projection.bias"), pre_out=w.dep_pre,
-                              rows=N, H=H)
-        elif d.splitk > 1:
-            ops.layernorm_fwd(self.ws.buf, a.p("depth_layernorm.weight"), a.p("depth_layernorm.bias"), w.dep, w.mean_d,
-                              w.rstd_d, relu=True, nsplit=d.splitk, bias=a.p("depth_projection.bias"),
-                              pre_out=w.dep_pre, rows=N, H=H)                    # (:196-197)
-        else:
-            ops.layernorm_fwd(w.dep_pre, a.p("depth_layernorm.weight"), a.p("depth_layernorm.bias"), w.dep, w.mean_d,
-                              w.rstd_d, relu=True)
         # ---- token selection + exchange (:33-66)
         if mode == "train":
             idx, mask = self._train_masks(B, S)
