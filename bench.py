@@ -84,6 +84,23 @@ def kernel_rooflines(eng, c):
     return out
 
 
+def pmc_traffic(kernel_label):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE
+    in separate runs, gfx950 correction applied: tools/pmc_summary.py -> profiles/r01_pmc_hbm.json).  A profiler cannot
+    run inside the timed process, so this is the figure of the committed profile of the same command, or None."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")
+    key = {"adamw_flat": "adamw_kernel", "depth_projection_wgrad (gemm_f32 TN)": "gemm_f32_kernel<1, 1, 64, 64, 64, 2, 2, 1, true>",
+           "depth_projection_fwd (gemm_f32 NT split-K)": "gemm_f32_kernel<0, 0, 64, 64, 64, 2, 2, 2, true>"}.get(kernel_label)
+    try:
+        tab = json.load(open(path))
+    except OSError:
+        return None
+    for k, v in tab.items():
+        if key and key in k:
+            return v["hbm_bytes"]
+    return None
+
+
 def cpu_baseline(c, budget_s=15.0):
     """The oracle (CPU restatement, 'port') timed on this box's host cores on a bounded sample of the same workload."""
     from oracle import futr_oracle as O, synth
@@ -327,7 +344,8 @@ def main():
         else:
             roof = dict(bound="hbm", achieved=dom["bytes"] / dom["seconds"] / 1e9, peak=8000.0, unit="GB/s")
         roof["frac"] = roof["achieved"] / roof["peak"]
-        roof["traffic"] = None
+        roof["traffic"] = pmc_traffic(name) if a.config == "cfg2" else None     # measured HBM bytes per launch (PMC)
+        roof["algorithmic_bytes"] = dom["bytes"]
         roof["kernel"] = name
         roof["us_per_launch"] = dom["seconds"] * 1e6
         out = dict(metric="training clips/sec (RGB+Depth fusion, DARai) at 1/2/4/8 GPUs; effective-rank match",

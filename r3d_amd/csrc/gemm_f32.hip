@@ -47,15 +47,94 @@ __device__ __forceinline__ void gemm_epilogue(const r3d_gemm_desc& d, int m, int
 
 // Staged epilogue of one 32x32 accumulator tile held by a wave.  C/D map of the 32x32 MFMA: col = lane & 31 (fixed
 // per lane), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); mb already contains the lane's 4*(lane>>5) offset.
+// Operands of the epilogue for NR output elements of one column n (rows given by the caller).  load() issues EVERY
+// operand load unconditionally from clamped (always valid) rows before any is used: one memory round trip instead of one
+// per operand -- and the small-tile kernel calls it BEFORE its k-loop, so the (cold: written by the previous kernel,
+// possibly through another XCD's L2) residual / mask / aux reads travel under the main loop.
+template <int NR>
+struct EpiOps {
+    float kk[NR], xa[NR], x1[NR], x2[NR], xc[NR];
+    float bias;
+    __device__ __forceinline__ void load(const r3d_gemm_desc& d, const size_t* ml, int n) {
+        bias = d.bias ? d.bias[n] : 0.f;
+        if (d.drop_mask) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) kk[r] = (float)d.drop_mask[ml[r] * d.lddrop + n];
+        }
+        if (d.mul) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) xa[r] = d.aux[ml[r] * d.ldaux + n];
+        }
+        if (d.res1) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) x1[r] = d.res1[ml[r] * d.ldr1 + n];
+        }
+        if (d.res2) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) x2[r] = d.res2[ml[r] * d.ldr2 + n];
+        }
+        if (d.accumulate) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) xc[r] = d.C[ml[r] * d.ldc + n];
+        }
+    }
+    // arithmetic in the reference's order, then the store; m[r] = destination row, ok[r] = row inside the matrix
+    __device__ __forceinline__ void apply(const r3d_gemm_desc& d, const float* acc, const int* m, const bool* ok, int n) {
+        float v[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) v[r] = d.alpha * acc[r] + bias;
+        if (d.pre_out) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+                if (ok[r]) d.pre_out[(size_t)m[r] * d.ldpre + n] = v[r];
+        }
+        if (d.act == 1) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) v[r] = fmaxf(v[r], 0.0f);
+        } else if (d.act == 2) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) v[r] = gelu_f(v[r]);
+        }
+        if (d.drop_mask) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) v[r] *= d.drop_scale * kk[r];
+        }
+        if (d.mul == 1) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) v[r] = (xa[r] > 0.0f) ? v[r] : 0.0f;
+        } else if (d.mul) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) v[r] *= gelu_grad_f(xa[r]);
+        }
+        if (d.res1) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) v[r] += x1[r];
+        }
+        if (d.res2) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) v[r] += x2[r];
+        }
+        if (d.accumulate) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) v[r] += xc[r];
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+            if (ok[r]) d.C[(size_t)m[r] * d.ldc + n] = v[r];
+    }
+};
+
 __device__ __forceinline__ void gemm_epilogue_tile(const r3d_gemm_desc& d, const f32x16& acc, int mb, int n, int split) {
     if (n >= d.N) return;
     int m[16];
+    size_t ml[16];       // row used for operand LOADS: clamped into the matrix so that every load is unconditional
     bool ok[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int mr = mb + (r & 3) + 8 * (r >> 2);
         ok[r] = mr < d.M;
         m[r] = mr ^ d.c_row_xor;
+        ml[r] = (size_t)((ok[r] ? mr : d.M - 1) ^ d.c_row_xor);
     }
     if (d.splitk > 1) {
 #pragma unroll
@@ -63,65 +142,12 @@ __device__ __forceinline__ void gemm_epilogue_tile(const r3d_gemm_desc& d, const
             if (ok[r]) d.partial[((size_t)split * d.M + (m[r] ^ d.c_row_xor)) * d.N + n] = acc[r];
         return;
     }
-    float v[16];
-    const float bias = d.bias ? d.bias[n] : 0.f;
+    EpiOps<16> e;
+    e.load(d, ml, n);
+    float a[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = d.alpha * acc[r] + bias;
-    if (d.pre_out) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            if (ok[r]) d.pre_out[(size_t)m[r] * d.ldpre + n] = v[r];
-    }
-    if (d.act == 1) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.0f);
-    } else if (d.act == 2) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = gelu_f(v[r]);
-    }
-    if (d.drop_mask) {
-        float k[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) k[r] = ok[r] ? (float)d.drop_mask[(size_t)m[r] * d.lddrop + n] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] *= d.drop_scale * k[r];
-    }
-    if (d.mul) {
-        float x[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) x[r] = ok[r] ? d.aux[(size_t)m[r] * d.ldaux + n] : 0.f;
-        if (d.mul == 1) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = (x[r] > 0.0f) ? v[r] : 0.0f;
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] *= gelu_grad_f(x[r]);
-        }
-    }
-    if (d.res1) {
-        float x[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) x[r] = ok[r] ? d.res1[(size_t)m[r] * d.ldr1 + n] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] += x[r];
-    }
-    if (d.res2) {
-        float x[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) x[r] = ok[r] ? d.res2[(size_t)m[r] * d.ldr2 + n] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] += x[r];
-    }
-    if (d.accumulate) {
-        float x[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) x[r] = ok[r] ? d.C[(size_t)m[r] * d.ldc + n] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] += x[r];
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-        if (ok[r]) d.C[(size_t)m[r] * d.ldc + n] = v[r];
+    for (int r = 0; r < 16; ++r) a[r] = acc[r];
+    e.apply(d, a, m, ok, n);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -364,6 +390,26 @@ __device__ __forceinline__ void gemm_body(const r3d_gemm_desc& d, int tile, int 
         if (do_store) st_st.store(as_o, bs_o);
     };
 
+    // Small-tile kernel (one 32x32 tile, the 4 waves split k): after the k-loop every wave finishes 4 of the 16 row
+    // groups, so the epilogue (loads, erf of the GELU, stores) is spread over the 4 waves and its operand reads are
+    // issued HERE, before the k-loop.
+    constexpr bool QUAD = (WK == 4 && WM == 1 && WN == 1 && TM == 1 && TN == 1);
+    EpiOps<4> qe;
+    int qm[4];
+    bool qok[4];
+    const int qn = n0 + l31;
+    if (QUAD) {
+        size_t qml[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int mr = m0 + 4 * lhi + q + 8 * wk;            // row of accumulator register r = 4 * wk + q
+            qok[q] = mr < d.M;
+            qm[q] = mr ^ d.c_row_xor;
+            qml[q] = (size_t)((qok[q] ? mr : d.M - 1) ^ d.c_row_xor);
+        }
+        if (d.splitk <= 1) qe.load(d, qml, qn < d.N ? qn : d.N - 1);
+    }
+
     StageT st0, st1;
     if (nk > 0) st0.load(d, m0, n0, k_begin, k_end);
     if (nk > 1) st1.load(d, m0, n0, k_begin + BK, k_end);
@@ -380,6 +426,38 @@ __device__ __forceinline__ void gemm_body(const r3d_gemm_desc& d, int tile, int 
         ++kt;
     }
 
+    if (QUAD) {
+        constexpr int PER_WAVE = 17 * 64;
+        static_assert(4 * PER_WAVE <= gemm_lds_floats<LA, LB, BM, BN, BK>(), "k-split reduction does not fit");
+        float* mine = smem + wk * PER_WAVE;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mine[r * 64 + lane] = acc[0][0][r];
+        mine[16 * 64 + lane] = asum[0];
+        __syncthreads();
+        float v4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = 4 * wk + q;
+            v4[q] = (smem[r * 64 + lane] + smem[PER_WAVE + r * 64 + lane]) +
+                    (smem[2 * PER_WAVE + r * 64 + lane] + smem[3 * PER_WAVE + r * 64 + lane]);
+        }
+        if (LA == 1 && d.bias_grad && n0 == 0 && wk == 0) {
+            float t = (smem[16 * 64 + lane] + smem[PER_WAVE + 16 * 64 + lane]) +
+                      (smem[2 * PER_WAVE + 16 * 64 + lane] + smem[3 * PER_WAVE + 16 * 64 + lane]);
+            t += __shfl_xor(t, 32, 64);
+            const int m = m0 + l31;
+            if (lhi == 0 && m < d.M) d.bias_grad[m] = t;
+        }
+        if (qn >= d.N) return;
+        if (d.splitk > 1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (qok[q]) d.partial[((size_t)split * d.M + (qm[q] ^ d.c_row_xor)) * d.N + qn] = v4[q];
+            return;
+        }
+        qe.apply(d, v4, qm, qok, qn);
+        return;
+    }
     if (WK > 1) {
         // reduce the WK partial accumulators (and bias-gradient sums) into the wk == 0 waves through LDS (the staging
         // buffers are free: the loop ended with a barrier)
