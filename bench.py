@@ -188,11 +188,11 @@ def main():
             tp.prefetch(x_dep2d, slot[0])
             tp.exchange_forward(eng._fw["w"])
         eng.forward_finish()
-        eng.losses(lab, tgt, dur)
+        eng.losses(lab, tgt, dur, tick=True)
         eng.backward()
         if dp is not None:
             dp.wait_grads()
-        eng.adamw(c["lr"], c["wd"], grad_scale=gscale, tick_dropout=eng.last["drop"])
+        eng.adamw(c["lr"], c["wd"], grad_scale=gscale, ticked=True)
 
     mode = "replicated"
     if world > 1:
@@ -257,13 +257,13 @@ def main():
                     if s == 0:
                         with torch.cuda.graph(gB):
                             eng.forward_finish()
-                            eng.losses(lab, tgt, dur)
+                            eng.losses(lab, tgt, dur, tick=True)
                             eng.backward_main()
                     gC[s] = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(gC[s]):
                         tp.wgrad(w_, eng.ws)
                 with torch.cuda.graph(gD):
-                    eng.adamw(c["lr"], c["wd"], grad_scale=gscale, tick_dropout=training)
+                    eng.adamw(c["lr"], c["wd"], grad_scale=gscale, ticked=True)
                 eng.grad_hook = hook
                 slot[0] = 0
                 tp.prefetch(x_dep2d, 0)
@@ -292,12 +292,12 @@ def main():
                 g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g1):
                     eng.forward(feats, depth, lab, "train", training)
-                    eng.losses(lab, tgt, dur)
+                    eng.losses(lab, tgt, dur, tick=True)
                     eng.backward_main()
                 with torch.cuda.graph(g2):
                     eng.backward_depth_wgrad()
                 with torch.cuda.graph(g3):
-                    eng.adamw(c["lr"], c["wd"], grad_scale=gscale, tick_dropout=training)
+                    eng.adamw(c["lr"], c["wd"], grad_scale=gscale, ticked=True)
                 eng.grad_hook = hook
 
                 def run_step():

@@ -133,6 +133,8 @@ int r3d_layernorm_bwd(const float* dy, int lddy, int pair_in, const float* dy2, 
  * (so the host can take it off the critical path). */
 int r3d_layernorm_bwd_finalize(const float* ws, int rows, int H, float* dgamma, float* dbeta, void* stream);
 /* The same for many LayerNorm sites in one launch; jobs live in device memory. */
+/* rows > 0: ws holds the partials r3d_layernorm_bwd left for that many rows; rows < 0: exactly -rows (dgamma, dbeta)
+ * pairs [-rows][2][H] written by another producer (r3d_embed_fuse_bwd). */
 typedef struct r3d_ln_finalize_job { const float* ws; float* dgamma; float* dbeta; int32_t rows, H; } r3d_ln_finalize_job;
 int r3d_layernorm_bwd_finalize_batched(const r3d_ln_finalize_job* dev_jobs, int njobs, int max_H, void* stream);
 /* out[c] (+)= sum_r x[r,c]: bias gradients.  ws: r3d_colsum_ws_floats(rows, cols) floats. */
@@ -200,13 +202,35 @@ int r3d_decoder_fused_supported(int S, int Q, int H, int heads);
 int r3d_decoder_layer_fwd(const void* const* ptrs, int nptrs, int B, int S, int Q, int H, int heads, int pad_idx,
                           float drop_scale, int n_head_out, void* stream);
 
+/* ---- the seam between the input projections and the fuser block, one launch per direction (train mode) -----------
+ * forward : split-K slab sums of input_embed (+bias, ReLU :183) and depth_projection (+bias, LayerNorm, ReLU :195-197),
+ *           token exchange + embd_drop (:56-62,83), fuser.blocks.0.norm1 (transformerblock.py:122).
+ *           rgb_src: ns_r > 0 -> slabs [ns_r][N][H]; ns_r == 0 -> the finished embedding (rgb_out may alias it).
+ *           dep_src: slabs [ns_d][N][H], ns_d >= 1 (a finished pre-LayerNorm matrix is one slab).
+ * backward: norm1 backward (+ residual gradients add1, add2), exchange backward, ReLU of the RGB embedding, depth
+ *           LayerNorm + ReLU backward; ws_n1 / ws_dep [N][2][H] receive one (dgamma, dbeta) partial per frame
+ *           (r3d_layernorm_bwd_finalize_batched job with rows = -N).  All matrices contiguous, ld = H <= 1024. */
+int r3d_embed_fuse_fwd(const float* rgb_src, int ns_r, const float* bias_r, const float* dep_src, int ns_d,
+                       const float* bias_d, const float* lnd_gamma, const float* lnd_beta, const float* mask_rgb,
+                       const float* mask_dep, const uint8_t* drop_mask, float drop_scale, const float* ln1_gamma,
+                       const float* ln1_beta, float* rgb_out, float* dep_pre_out, float* mean_d, float* rstd_d,
+                       float* dep_out, float* x0, float* h1, float* m1, float* r1, int N, int H, void* stream);
+int r3d_embed_fuse_bwd(const float* d_h1, const float* x0, const float* m1, const float* r1, const float* ln1_gamma,
+                       const float* add1, const float* add2, const uint8_t* drop_mask, float drop_scale,
+                       const float* mask_rgb, const float* mask_dep, const float* rgb, const float* dep_pre,
+                       const float* mean_d, const float* rstd_d, const float* lnd_gamma, const float* lnd_beta,
+                       float* d_rgb_pre, float* d_dep_pre, float* ws_n1, float* ws_dep, int N, int H, void* stream);
+
 /* ---- losses: utils.py:325-328,358-378,410-490 as composed at train/train_proposed_depth.py:171-213 ------------- */
 int r3d_losses_fwd_bwd(const float* seg_logits, int ld_seg, const float* act_logits, int ld_act, const float* dur,
                        int ld_dur, const int64_t* past_label, const int64_t* target, const float* target_dur, int B, int S,
                        int Q, int K, int pad_idx, int exclude_idx, int val_mode, const float* dur_den, float grad_scale,
                        float* d_seg, int ld_dseg, float* d_act, int ld_dact, float* d_dur, int ld_ddur, float* loss_out,
-                       int64_t* counts, float* ws, void* stream);
-int64_t r3d_losses_ws_floats(int B, int S, int Q);     /* scratch for r3d_losses_fwd_bwd (16-byte aligned) */
+                       int64_t* counts, float* ws, int64_t* tick_a, int64_t* tick_b, void* stream);
+/* ws: r3d_losses_ws_floats floats, 16-byte aligned and ZERO before the first call (it ends with the arrival counter of
+ * the single-launch reduction, which every call leaves at zero).  tick_a / tick_b: optional device int64 counters
+ * incremented once per call (the engine's step counter and dropout offset). */
+int64_t r3d_losses_ws_floats(int B, int S, int Q);
 
 /* ---- optimiser / dropout masks: main_darai.py:135, train/train_proposed_depth.py:215 -------------------------- */
 /* torch.optim.AdamW semantics over flat arenas of n floats (n % 4 == 0, 16-byte aligned); g is multiplied by

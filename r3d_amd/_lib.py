@@ -79,8 +79,12 @@ _SIGNATURES = {
                          C.c_int),
     "r3d_decoder_fused_supported": ([_I, _I, _I, _I], C.c_int),
     "r3d_decoder_layer_fwd": ([_P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P], C.c_int),
+    "r3d_embed_fuse_fwd": ([_P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I,
+                            _P], C.c_int),
+    "r3d_embed_fuse_bwd": ([_P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+                           C.c_int),
     "r3d_losses_fwd_bwd": ([_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _F, _P, _I, _P, _I,
-                            _P, _I, _P, _P, _P, _P], C.c_int),
+                            _P, _I, _P, _P, _P, _P, _P, _P], C.c_int),
     "r3d_losses_ws_floats": ([_I, _I, _I], C.c_int64),
     "r3d_adamw_flat": ([_P, _P, _P, _P, _L, _P, _P, _F, _F, _F, _F, _F, _P], C.c_int),
     "r3d_adamw_2d": ([_P, _P, _P, _P, _I, _I, _I, _P, _P, _F, _F, _F, _F, _F, _P], C.c_int),

@@ -1,0 +1,309 @@
+// The seam between the two input projections and the SA-Fuser block as ONE launch per direction (train mode, where the
+// token selection is data independent -- SURVEY F5a):
+//   forward : split-K slab sums of both projections (+bias; ReLU on RGB futr_safuser_tokenfusion.py:183; LayerNorm +
+//             ReLU on depth :196-197) -> token exchange + embd_drop (:56-62,83) -> fuser.blocks.0.norm1
+//             (transformerblock.py:122).   Replaces 4 dependent launches (reduce, LN, exchange, LN) by one.
+//   backward: norm1 backward (+ the two residual gradients) -> exchange backward (index_put / clone, ReLU of :183)
+//             -> depth LayerNorm + ReLU backward.   Replaces 3 dependent launches by one.
+// One workgroup (4 waves) per frame row n.  Everything is latency: all loads are unconditional (clamped columns) and
+// issued up front.  Reductions are wave shuffles / fixed-order LDS sums -> bitwise reproducible.
+#include "common.h"
+#include "../../include/r3d_hip.h"
+
+namespace r3d {
+
+constexpr float kLnEpsE = 1e-5f;
+
+struct EmbedFwdArgs {
+    const float* rgb_src; int ns_r; const float* bias_r;      // ns_r > 0: [ns_r][N][H] slabs, bias + ReLU applied here
+    const float* dep_src; int ns_d; const float* bias_d;      // ns_d > 0: [ns_d][N][H] slabs (+bias); LN + ReLU here
+    const float* lnd_g; const float* lnd_b; const float* m_rgb; const float* m_dep;
+    const uint8_t* drop; float drop_scale; const float* ln1_g; const float* ln1_b;
+    float* rgb_out; float* dep_pre_out; float* mean_d; float* rstd_d; float* dep_out;
+    float* x0; float* h1; float* m1; float* r1;
+    int N, H;
+};
+
+template <int EPL>
+__global__ __launch_bounds__(256) void embed_fuse_fwd_kernel(const EmbedFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float red[];       // [4 waves][2][H]
+    const int n = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, H = a.H;
+    const size_t stride = (size_t)a.N * H, rowo = (size_t)n * H;
+    int cc[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) { const int c = lane + 64 * e; cc[e] = c < H ? c : H - 1; }
+    // ---- operands of the row tail, prefetched by the two waves that run it (wave t finishes token t of the frame)
+    const int t = wave & 1;
+    float g1[EPL], b1[EPL], gd[EPL], bd[EPL], br[EPL], bdp[EPL], msk[EPL], keep[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        g1[e] = a.ln1_g[cc[e]]; b1[e] = a.ln1_b[cc[e]];
+        gd[e] = a.lnd_g[cc[e]]; bd[e] = a.lnd_b[cc[e]];
+        br[e] = (a.ns_r > 0 && a.bias_r) ? a.bias_r[cc[e]] : 0.f;
+        bdp[e] = a.bias_d ? a.bias_d[cc[e]] : 0.f;
+        msk[e] = (t == 0 ? a.m_rgb : a.m_dep)[cc[e]];
+        keep[e] = a.drop ? a.drop_scale * (float)a.drop[((size_t)2 * n + t) * H + cc[e]] : 1.f;
+    }
+    // ---- slab sums: wave w takes slabs w, w+4, ... of both projections, 4 independent partial sums per column
+    float ar[EPL], ad[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        float s4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (a.ns_r > 0) {
+            const float* p = a.rgb_src + rowo + cc[e];
+            int s = wave;
+            for (; s + 12 < a.ns_r; s += 16) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) s4[q] += p[(size_t)(s + 4 * q) * stride];
+            }
+            for (; s < a.ns_r; s += 4) s4[0] += p[(size_t)s * stride];
+        } else if (wave == 0) {
+            s4[0] = a.rgb_src[rowo + cc[e]];
+        }
+        ar[e] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+        float d4[4] = {0.f, 0.f, 0.f, 0.f};
+        {
+            const float* p = a.dep_src + rowo + cc[e];
+            int s = wave;
+            for (; s + 12 < a.ns_d; s += 16) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) d4[q] += p[(size_t)(s + 4 * q) * stride];
+            }
+            for (; s < a.ns_d; s += 4) d4[0] += p[(size_t)s * stride];
+        }
+        ad[e] = (d4[0] + d4[1]) + (d4[2] + d4[3]);
+    }
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const int c = lane + 64 * e;
+        if (c < H) { red[(wave * 2 + 0) * H + c] = ar[e]; red[(wave * 2 + 1) * H + c] = ad[e]; }
+    }
+    __syncthreads();
+    if (wave >= 2) return;
+    // ---- both tail waves rebuild the two embedding rows (identical arithmetic -> identical values)
+    float r[EPL], dpre[EPL];
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const int c = lane + 64 * e;
+        float vr = 0.f, vd = 0.f;
+        if (c < H) {
+            vr = (red[0 * H + c] + red[2 * H + c]) + (red[4 * H + c] + red[6 * H + c]);
+            vd = (red[1 * H + c] + red[3 * H + c]) + (red[5 * H + c] + red[7 * H + c]) + bdp[e];
+            if (a.ns_r > 0) vr = fmaxf(vr + br[e], 0.f);
+        }
+        r[e] = vr; dpre[e] = vd;
+        s += vd;
+    }
+    const float mean = wave_sum(s) / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const int c = lane + 64 * e;
+        const float dl = c < H ? dpre[e] - mean : 0.f;
+        q += dl * dl;
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)H + kLnEpsE);
+    float d[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) d[e] = fmaxf((dpre[e] - mean) * rstd * gd[e] + bd[e], 0.f);
+    if (wave == 0) {
+        if (lane == 0) { a.mean_d[n] = mean; a.rstd_d[n] = rstd; }
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const int c = lane + 64 * e;
+            if (c < H) {
+                if (a.rgb_out != a.rgb_src) a.rgb_out[rowo + c] = r[e];
+                a.dep_pre_out[rowo + c] = dpre[e];
+                a.dep_out[rowo + c] = d[e];
+            }
+        }
+    }
+    // ---- token t of the frame: exchange, embd_drop, norm1
+    const size_t row = (size_t)2 * n + t;
+    float x[EPL];
+    float s1 = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const int c = lane + 64 * e;
+        const float own = t == 0 ? r[e] : d[e], other = t == 0 ? d[e] : r[e];
+        float v = (msk[e] != 0.f ? other : own) * keep[e];
+        if (c >= H) v = 0.f;
+        x[e] = v;
+        s1 += v;
+        if (c < H) a.x0[row * H + c] = v;
+    }
+    const float mean1 = wave_sum(s1) / (float)H;
+    float q1 = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const int c = lane + 64 * e;
+        const float dl = c < H ? x[e] - mean1 : 0.f;
+        q1 += dl * dl;
+    }
+    const float rstd1 = 1.0f / sqrtf(wave_sum(q1) / (float)H + kLnEpsE);
+    if (lane == 0) { a.m1[row] = mean1; a.r1[row] = rstd1; }
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const int c = lane + 64 * e;
+        if (c < H) a.h1[row * H + c] = (x[e] - mean1) * rstd1 * g1[e] + b1[e];
+    }
+}
+
+struct EmbedBwdArgs {
+    const float* d_h1; const float* x0; const float* m1; const float* r1; const float* ln1_g;
+    const float* add1; const float* add2; const uint8_t* drop; float drop_scale;
+    const float* m_rgb; const float* m_dep; const float* rgb; const float* dep_pre; const float* mean_d;
+    const float* rstd_d; const float* lnd_g; const float* lnd_b;
+    float* d_rgb_pre; float* d_dep_pre; float* ws_n1; float* ws_dep;     // ws_*: [N][2][H] partial (dgamma, dbeta)
+    int N, H;
+};
+
+template <int EPL>
+__global__ __launch_bounds__(128) void embed_fuse_bwd_kernel(const EmbedBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];        // G[2][H] | P[2][2][H]
+    const int n = blockIdx.x, lane = threadIdx.x & 63, t = threadIdx.x >> 6, H = a.H;
+    float* G = lds;
+    float* P = lds + 2 * H;
+    const size_t row = (size_t)2 * n + t, rowo = (size_t)n * H;
+    int cc[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) { const int c = lane + 64 * e; cc[e] = c < H ? c : H - 1; }
+    // ---- every load of the workgroup up front
+    const float mean1 = a.m1[row], rstd1 = a.r1[row];
+    float dh[EPL], xv[EPL], g1[EPL], a1[EPL], a2[EPL], keep[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        dh[e] = a.d_h1[row * H + cc[e]];
+        xv[e] = a.x0[row * H + cc[e]];
+        g1[e] = a.ln1_g[cc[e]];
+        a1[e] = a.add1 ? a.add1[row * H + cc[e]] : 0.f;
+        a2[e] = a.add2 ? a.add2[row * H + cc[e]] : 0.f;
+        keep[e] = a.drop ? a.drop_scale * (float)a.drop[row * H + cc[e]] : 1.f;
+    }
+    float mr[EPL], md[EPL], rg[EPL], dp[EPL], gd[EPL], bd[EPL];
+    float mean_d = 0.f, rstd_d = 0.f;
+    if (t == 0) {
+        mean_d = a.mean_d[n]; rstd_d = a.rstd_d[n];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            mr[e] = a.m_rgb[cc[e]]; md[e] = a.m_dep[cc[e]];
+            rg[e] = a.rgb[rowo + cc[e]]; dp[e] = a.dep_pre[rowo + cc[e]];
+            gd[e] = a.lnd_g[cc[e]]; bd[e] = a.lnd_b[cc[e]];
+        }
+    }
+    // ---- norm1 backward of token t (+ the two residual gradients), then back through embd_drop
+    float xh[EPL], gg[EPL];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const int c = lane + 64 * e;
+        float xhat = 0.f, g = 0.f;
+        if (c < H) {
+            xhat = (xv[e] - mean1) * rstd1;
+            g = dh[e] * g1[e];
+            P[(t * 2 + 0) * H + c] = dh[e] * xhat;
+            P[(t * 2 + 1) * H + c] = dh[e];
+        }
+        xh[e] = xhat; gg[e] = g;
+        s1 += g; s2 += g * xhat;
+    }
+    s1 = wave_sum(s1) / (float)H;
+    s2 = wave_sum(s2) / (float)H;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const int c = lane + 64 * e;
+        if (c < H) G[t * H + c] = (rstd1 * (gg[e] - s1 - xh[e] * s2) + a1[e] + a2[e]) * keep[e];
+    }
+    __syncthreads();
+    if (t == 1) {                       // norm1 parameter-gradient partial of this frame (its two token rows)
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const int c = lane + 64 * e;
+            if (c < H) {
+                a.ws_n1[((size_t)n * 2 + 0) * H + c] = P[0 * H + c] + P[2 * H + c];
+                a.ws_n1[((size_t)n * 2 + 1) * H + c] = P[1 * H + c] + P[3 * H + c];
+            }
+        }
+        return;
+    }
+    // ---- exchange backward (index_put / clone), ReLU of the RGB embedding, depth LayerNorm + ReLU backward
+    float xd[EPL], gq[EPL];
+    float u1 = 0.f, u2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const int c = lane + 64 * e;
+        float xhat = 0.f, g = 0.f;
+        if (c < H) {
+            const float g0 = G[c], g1v = G[H + c];
+            const float drgb = ((mr[e] != 0.f ? 0.f : g0) + (md[e] != 0.f ? g1v : 0.f)) * (rg[e] > 0.f ? 1.f : 0.f);
+            a.d_rgb_pre[rowo + c] = drgb;
+            float dd = (mr[e] != 0.f ? g0 : 0.f) + (md[e] != 0.f ? 0.f : g1v);
+            xhat = (dp[e] - mean_d) * rstd_d;
+            if (!(xhat * gd[e] + bd[e] > 0.f)) dd = 0.f;
+            a.ws_dep[((size_t)n * 2 + 0) * H + c] = dd * xhat;
+            a.ws_dep[((size_t)n * 2 + 1) * H + c] = dd;
+            g = dd * gd[e];
+        }
+        xd[e] = xhat; gq[e] = g;
+        u1 += g; u2 += g * xhat;
+    }
+    u1 = wave_sum(u1) / (float)H;
+    u2 = wave_sum(u2) / (float)H;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const int c = lane + 64 * e;
+        if (c < H) a.d_dep_pre[rowo + c] = rstd_d * (gq[e] - u1 - xd[e] * u2);
+    }
+}
+
+}  // namespace r3d
+
+using namespace r3d;
+
+/* Backward seam (see the file header): d_h1 [2N,H] = gradient w.r.t. norm1's output; add1 / add2 (optional) are added
+ * to norm1's input gradient (the residual paths).  Outputs: d_rgb_pre [N,H] (gradient before input_embed's ReLU),
+ * d_dep_pre [N,H] (gradient before depth_layernorm), and the LayerNorm parameter-gradient partials ws_n1 / ws_dep, each
+ * [N][2][H] floats: one (dgamma, dbeta) pair per frame, summed by r3d_layernorm_bwd_finalize_batched with rows = -N. */
+R3D_EXPORT int r3d_embed_fuse_bwd(const float* d_h1, const float* x0, const float* m1, const float* r1, const float* ln1_gamma,
+                                  const float* add1, const float* add2, const uint8_t* drop_mask, float drop_scale,
+                                  const float* mask_rgb, const float* mask_dep, const float* rgb, const float* dep_pre,
+                                  const float* mean_d, const float* rstd_d, const float* lnd_gamma, const float* lnd_beta,
+                                  float* d_rgb_pre, float* d_dep_pre, float* ws_n1, float* ws_dep, int N, int H,
+                                  void* stream) {
+    R3D_REQUIRE(d_h1 && x0 && m1 && r1 && ln1_gamma && mask_rgb && mask_dep && rgb && dep_pre && mean_d && rstd_d);
+    R3D_REQUIRE(lnd_gamma && lnd_beta && d_rgb_pre && d_dep_pre && ws_n1 && ws_dep && N > 0 && H > 0 && H <= 1024);
+    EmbedBwdArgs a{d_h1, x0, m1, r1, ln1_gamma, add1, add2, drop_mask, drop_scale, mask_rgb, mask_dep, rgb, dep_pre,
+                   mean_d, rstd_d, lnd_gamma, lnd_beta, d_rgb_pre, d_dep_pre, ws_n1, ws_dep, N, H};
+    const size_t shmem = (size_t)6 * H * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+    if (H <= 128) hipLaunchKernelGGL(embed_fuse_bwd_kernel<2>, dim3(N), dim3(128), shmem, s, a);
+    else if (H <= 512) hipLaunchKernelGGL(embed_fuse_bwd_kernel<8>, dim3(N), dim3(128), shmem, s, a);
+    else hipLaunchKernelGGL(embed_fuse_bwd_kernel<16>, dim3(N), dim3(128), shmem, s, a);
+    R3D_LAUNCH_CHECK();
+    return R3D_OK;
+}
+
+/* Forward seam (see the file header).  rgb_src: ns_r > 0 -> split-K slabs [ns_r][N][H] of input_embed (bias_r and ReLU
+ * are applied here), ns_r == 0 -> the finished [N,H] embedding (rgb_out may alias it).  dep_src: [ns_d][N][H] slabs
+ * (ns_d >= 1; a finished pre-LayerNorm matrix is one slab), bias_d optional.  Outputs: rgb_out, dep_pre_out (pre-LN),
+ * mean_d / rstd_d [N], dep_out (post ReLU), x0 [2N,H] (exchanged + dropped tokens), h1 = norm1(x0), m1 / r1 [2N].
+ * All matrices contiguous with leading dimension H; H <= 1024. */
+R3D_EXPORT int r3d_embed_fuse_fwd(const float* rgb_src, int ns_r, const float* bias_r, const float* dep_src, int ns_d,
+                                  const float* bias_d, const float* lnd_gamma, const float* lnd_beta, const float* mask_rgb,
+                                  const float* mask_dep, const uint8_t* drop_mask, float drop_scale, const float* ln1_gamma,
+                                  const float* ln1_beta, float* rgb_out, float* dep_pre_out, float* mean_d, float* rstd_d,
+                                  float* dep_out, float* x0, float* h1, float* m1, float* r1, int N, int H, void* stream) {
+    R3D_REQUIRE(rgb_src && dep_src && lnd_gamma && lnd_beta && mask_rgb && mask_dep && ln1_gamma && ln1_beta);
+    R3D_REQUIRE(rgb_out && dep_pre_out && mean_d && rstd_d && dep_out && x0 && h1 && m1 && r1);
+    R3D_REQUIRE(N > 0 && H > 0 && H <= 1024 && ns_r >= 0 && ns_d >= 1);
+    EmbedFwdArgs a{rgb_src, ns_r, bias_r, dep_src, ns_d, bias_d, lnd_gamma, lnd_beta, mask_rgb, mask_dep, drop_mask,
+                   drop_scale, ln1_gamma, ln1_beta, rgb_out, dep_pre_out, mean_d, rstd_d, dep_out, x0, h1, m1, r1, N, H};
+    const size_t shmem = (size_t)8 * H * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+    if (H <= 128) hipLaunchKernelGGL(embed_fuse_fwd_kernel<2>, dim3(N), dim3(256), shmem, s, a);
+    else if (H <= 512) hipLaunchKernelGGL(embed_fuse_fwd_kernel<8>, dim3(N), dim3(256), shmem, s, a);
+    else hipLaunchKernelGGL(embed_fuse_fwd_kernel<16>, dim3(N), dim3(256), shmem, s, a);
+    R3D_LAUNCH_CHECK();
+    return R3D_OK;
+}

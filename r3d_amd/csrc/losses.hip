@@ -19,6 +19,7 @@ struct LossArgs {
     const float* dur_den; float grad_scale;
     float* d_seg; int ld_dseg; float* d_act; int ld_dact; float* d_dur; int ld_ddur;
     float* loss_out; int64_t* counts;
+    int64_t* tick_a; int64_t* tick_b;      // optional: ++*tick_a, ++*tick_b once per call (step counter, dropout offset)
 };
 
 // CE of one row held across a wave.  Returns loss contribution; writes gradient (softmax - onehot) * gscale if dl.
@@ -57,11 +58,8 @@ __device__ __forceinline__ float ce_row(const float* logit, int K, int64_t label
 // Unit u of the row grid: [0,N) segmentation rows, [N,N+BQ) anticipation rows, [N+BQ, N+BQ+B) duration clips.
 // One wave per unit (the work is latency-bound, so units must not queue inside a wave); each writes
 // part[u] = {loss contribution, correct, valid, 0}; losses_finalize_kernel adds them in a fixed order.
-__global__ __launch_bounds__(256) void losses_rows_kernel(const LossArgs a, float* part) {
-    const int lane = threadIdx.x & 63;
-    const int u = blockIdx.x * 4 + (threadIdx.x >> 6);
+__device__ __forceinline__ void losses_unit(const LossArgs& a, float* part, int u, int lane) {
     const int N = a.B * a.S, BQ = a.B * a.Q;
-    if (u >= N + BQ + a.B) return;
     float out_l = 0.f, out_c = 0.f, out_v = 0.f;
     if (u < N) {
         if (a.seg) {
@@ -136,7 +134,7 @@ __global__ __launch_bounds__(256) void losses_rows_kernel(const LossArgs a, floa
     }
 }
 
-__global__ __launch_bounds__(256) void losses_finalize_kernel(const LossArgs a, const float* part) {
+__device__ __forceinline__ void losses_finalize(const LossArgs& a, const float* part) {
     __shared__ double red[4][3][3];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int N = a.B * a.S, BQ = a.B * a.Q;
@@ -168,7 +166,27 @@ __global__ __launch_bounds__(256) void losses_finalize_kernel(const LossArgs a, 
         a.loss_out[0] = ls; a.loss_out[1] = la; a.loss_out[2] = ld; a.loss_out[3] = ls + la + ld;
         a.counts[0] = (int64_t)(t[0][1] + 0.5); a.counts[1] = (int64_t)(t[0][2] + 0.5);
         a.counts[2] = (int64_t)(t[1][1] + 0.5); a.counts[3] = (int64_t)(t[1][2] + 0.5);
+        if (a.tick_a) *a.tick_a += 1;
+        if (a.tick_b) *a.tick_b += 1;
     }
+}
+
+// One launch: every workgroup finishes its 4 units, the LAST one to arrive (device-scope counter behind an agent
+// release fence; acquire fence before it reads the others' partials) adds them up in a fixed order -- bitwise
+// reproducible, and no second dependent launch (~5 us on this part) for a result the backward does not even consume.
+__global__ __launch_bounds__(256) void losses_kernel(const LossArgs a, float* part, unsigned* arrivals) {
+    __shared__ int is_last;
+    const int lane = threadIdx.x & 63;
+    const int u = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (u < a.B * a.S + a.B * a.Q + a.B) losses_unit(a, part, u, lane);
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) is_last = (atomicAdd(arrivals, 1u) == gridDim.x - 1) ? 1 : 0;
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    losses_finalize(a, part);
+    if (threadIdx.x == 0) *arrivals = 0u;             // ready for the next launch
 }
 
 }  // namespace r3d
@@ -181,15 +199,17 @@ using namespace r3d;
  * (global mask sum / world size) so that the average of rank gradients equals the gradient of the reference's
  * global-batch loss.  val_mode=1 reproduces validate()'s unmasked duration target
  * (train_proposed_depth.py:98-99) and ignores seg when seg == NULL. */
-/* ws: r3d_losses_ws_floats(B, S, Q) floats of scratch, 16-byte aligned. */
-R3D_EXPORT int64_t r3d_losses_ws_floats(int B, int S, int Q) { return 4ll * ((int64_t)B * S + (int64_t)B * Q + B); }
+/* ws: r3d_losses_ws_floats(B, S, Q) floats of scratch, 16-byte aligned, ZERO before the first call (its last 16 bytes
+ * hold the arrival counter, which every launch leaves at zero again).  tick_a / tick_b (optional device int64): both
+ * are incremented once per call -- the caller's step counter and dropout offset ride along instead of costing a launch. */
+R3D_EXPORT int64_t r3d_losses_ws_floats(int B, int S, int Q) { return 4ll * ((int64_t)B * S + (int64_t)B * Q + B) + 4; }
 
 R3D_EXPORT int r3d_losses_fwd_bwd(const float* seg_logits, int ld_seg, const float* act_logits, int ld_act,
                                   const float* dur, int ld_dur, const int64_t* past_label, const int64_t* target,
                                   const float* target_dur, int B, int S, int Q, int K, int pad_idx, int exclude_idx,
                                   int val_mode, const float* dur_den, float grad_scale, float* d_seg, int ld_dseg,
                                   float* d_act, int ld_dact, float* d_dur, int ld_ddur, float* loss_out,
-                                  int64_t* counts, float* ws, void* stream) {
+                                  int64_t* counts, float* ws, int64_t* tick_a, int64_t* tick_b, void* stream) {
     R3D_REQUIRE(act_logits && dur && past_label && target && target_dur && loss_out && counts && ws);
     if (!r3d_aligned16(ws)) return R3D_EALIGN;
     R3D_REQUIRE(B > 0 && S > 0 && Q > 0 && K > 0);
@@ -199,11 +219,10 @@ R3D_EXPORT int r3d_losses_fwd_bwd(const float* seg_logits, int ld_seg, const flo
     R3D_REQUIRE(!d_dur || ld_ddur >= 1);
     LossArgs a{seg_logits, ld_seg, act_logits, ld_act, dur, ld_dur, past_label, target, target_dur, B, S, Q, K, pad_idx,
                exclude_idx, val_mode, dur_den, grad_scale, d_seg, ld_dseg, d_act, ld_dact, d_dur, ld_ddur, loss_out,
-               counts};
+               counts, tick_a, tick_b};
     const int units = B * S + B * Q + B;
-    hipLaunchKernelGGL(losses_rows_kernel, dim3(r3d_cdiv(units, 4)), dim3(256), 0, (hipStream_t)stream, a, ws);
-    R3D_LAUNCH_CHECK();
-    hipLaunchKernelGGL(losses_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a, (const float*)ws);
+    hipLaunchKernelGGL(losses_kernel, dim3(r3d_cdiv(units, 4)), dim3(256), 0, (hipStream_t)stream, a, ws,
+                       reinterpret_cast<unsigned*>(ws + 4 * (size_t)units));
     R3D_LAUNCH_CHECK();
     return R3D_OK;
 }

@@ -15,37 +15,44 @@ struct LnFwdArgs {
     float* pair_out; int rows; int H; int relu;
 };
 
+// Every load below is UNCONDITIONAL from a clamped column (a load under a lane-dependent branch makes hipcc wait
+// vmcnt(0) right behind it) and all loads of a workgroup's rows are issued before the first reduction: the kernels are
+// pure latency (their inputs were just written by the previous kernel), so what counts is ONE memory round trip.
 template <int EPL>
-__device__ __forceinline__ void ln_fwd_row(const LnFwdArgs& a, int row, int lane, float (&yv)[EPL]) {
-    float v[EPL];
-    float s = 0.f;
+__device__ __forceinline__ void ln_fwd_load(const LnFwdArgs& a, int row, int lane, float (&v)[EPL]) {
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
         const int c = lane + 64 * e;
-        float t = 0.f;
-        if (c < a.H) {
-            if (a.nsplit > 0) {
-                // split-K slabs: 8 independent partial sums keep 8 loads in flight (a serial chain pays one
-                // memory round trip per slab)
-                const float* px = a.x + (size_t)row * a.H + c;
-                const size_t stride = (size_t)a.rows * a.H;
-                float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                int p = 0;
-                for (; p + 8 <= a.nsplit; p += 8) {
+        const int cc = c < a.H ? c : a.H - 1;
+        float t;
+        if (a.nsplit > 0) {
+            // split-K slabs: 8 independent partial sums keep 8 loads in flight (a serial chain pays one
+            // memory round trip per slab)
+            const float* px = a.x + (size_t)row * a.H + cc;
+            const size_t stride = (size_t)a.rows * a.H;
+            float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            int p = 0;
+            for (; p + 8 <= a.nsplit; p += 8) {
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) s8[q] += px[(size_t)(p + q) * stride];
-                }
-                for (; p < a.nsplit; ++p) s8[0] += px[(size_t)p * stride];
-                t = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
-                if (a.bias) t += a.bias[c];
-                if (a.pre_out) a.pre_out[(size_t)row * a.H + c] = t;
-            } else {
-                t = a.x[(size_t)row * a.ldx + c];
+                for (int q = 0; q < 8; ++q) s8[q] += px[(size_t)(p + q) * stride];
             }
+            for (; p < a.nsplit; ++p) s8[0] += px[(size_t)p * stride];
+            t = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+            if (a.bias) t += a.bias[cc];
+            if (a.pre_out && c < a.H) a.pre_out[(size_t)row * a.H + c] = t;
+        } else {
+            t = a.x[(size_t)row * a.ldx + cc];
         }
-        v[e] = t;
-        s += t;
+        v[e] = c < a.H ? t : 0.f;
     }
+}
+
+template <int EPL>
+__device__ __forceinline__ void ln_fwd_finish(const LnFwdArgs& a, int row, int lane, const float (&v)[EPL],
+                                              const float (&gam)[EPL], const float (&bet)[EPL], float (&yv)[EPL]) {
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) s += v[e];
     const float mean = wave_sum(s) / (float)a.H;
     float q = 0.f;
 #pragma unroll
@@ -61,7 +68,7 @@ __device__ __forceinline__ void ln_fwd_row(const LnFwdArgs& a, int row, int lane
         const int c = lane + 64 * e;
         float o = 0.f;
         if (c < a.H) {
-            o = (v[e] - mean) * rstd * a.gamma[c] + a.beta[c];
+            o = (v[e] - mean) * rstd * gam[e] + bet[e];
             if (a.relu) o = fmaxf(o, 0.f);
             a.y[(size_t)row * a.ldy + c] = o;
         }
@@ -73,12 +80,22 @@ template <int EPL>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int unit = blockIdx.x * 4 + wave;
-    float y0[EPL];
+    float gam[EPL], bet[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const int c = lane + 64 * e;
+        const int cc = c < a.H ? c : a.H - 1;
+        gam[e] = a.gamma[cc];
+        bet[e] = a.beta[cc];
+    }
+    float y0[EPL], v0[EPL];
     if (a.pair_out) {
         if (2 * unit >= a.rows) return;
-        float y1[EPL];
-        ln_fwd_row<EPL>(a, 2 * unit, lane, y0);
-        ln_fwd_row<EPL>(a, 2 * unit + 1, lane, y1);
+        float y1[EPL], v1[EPL];
+        ln_fwd_load<EPL>(a, 2 * unit, lane, v0);
+        ln_fwd_load<EPL>(a, 2 * unit + 1, lane, v1);
+        ln_fwd_finish<EPL>(a, 2 * unit, lane, v0, gam, bet, y0);
+        ln_fwd_finish<EPL>(a, 2 * unit + 1, lane, v1, gam, bet, y1);
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
             const int c = lane + 64 * e;
@@ -86,7 +103,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs a) {
         }
     } else {
         if (unit >= a.rows) return;
-        ln_fwd_row<EPL>(a, unit, lane, y0);
+        ln_fwd_load<EPL>(a, unit, lane, v0);
+        ln_fwd_finish<EPL>(a, unit, lane, v0, gam, bet, y0);
     }
 }
 
@@ -109,8 +127,29 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
     float dg[EPL], db[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; ++e) { dg[e] = 0.f; db[e] = 0.f; }
+    float gam[EPL], bet[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const int c = lane + 64 * e;
+        const int cc = c < a.H ? c : a.H - 1;
+        gam[e] = a.gamma[cc];
+        bet[e] = a.relu ? a.beta[cc] : 0.f;
+    }
     for (int row = r_begin + wave; row < r_end; row += 4) {
+        // phase 1: every load of the row, unconditional from clamped columns (see ln_fwd_load)
         const float mean = a.mean[row], rstd = a.rstd[row];
+        float xv[EPL], dv[EPL], d2[EPL], a1[EPL], a2[EPL], km[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const int c = lane + 64 * e;
+            const int cc = c < a.H ? c : a.H - 1;
+            xv[e] = a.x[(size_t)row * a.ldx + cc];
+            dv[e] = a.pair_in ? 0.5f * a.dy[(size_t)(row >> 1) * a.lddy + cc] : a.dy[(size_t)row * a.lddy + cc];
+            d2[e] = a.dy2 ? a.dy2[(size_t)row * a.lddy2 + cc] : 0.f;
+            a1[e] = a.add1 ? a.add1[(size_t)row * a.ldadd1 + cc] : 0.f;
+            a2[e] = a.add2 ? a.add2[(size_t)row * a.ldadd2 + cc] : 0.f;
+            km[e] = (a.dx2 && a.drop_mask) ? a.drop_scale * (float)a.drop_mask[(size_t)row * a.lddrop + cc] : 1.f;
+        }
         float xh[EPL], g[EPL];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -118,14 +157,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
             const int c = lane + 64 * e;
             float xhat = 0.f, gg = 0.f;
             if (c < a.H) {
-                xhat = (a.x[(size_t)row * a.ldx + c] - mean) * rstd;
-                float d = a.pair_in ? 0.5f * a.dy[(size_t)(row >> 1) * a.lddy + c] : a.dy[(size_t)row * a.lddy + c];
-                if (a.dy2) d += a.dy2[(size_t)row * a.lddy2 + c];
-                const float gam = a.gamma[c];
-                if (a.relu && !(xhat * gam + a.beta[c] > 0.f)) d = 0.f;
+                xhat = (xv[e] - mean) * rstd;
+                float d = dv[e] + d2[e];
+                if (a.relu && !(xhat * gam[e] + bet[e] > 0.f)) d = 0.f;
                 dg[e] += d * xhat;
                 db[e] += d;
-                gg = d * gam;
+                gg = d * gam[e];
             }
             xh[e] = xhat;
             g[e] = gg;
@@ -138,15 +175,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
         for (int e = 0; e < EPL; ++e) {
             const int c = lane + 64 * e;
             if (c < a.H) {
-                float o = rstd * (g[e] - s1 - xh[e] * s2);
-                if (a.add1) o += a.add1[(size_t)row * a.ldadd1 + c];
-                if (a.add2) o += a.add2[(size_t)row * a.ldadd2 + c];
+                const float o = rstd * (g[e] - s1 - xh[e] * s2) + a1[e] + a2[e];
                 a.dx[(size_t)row * a.lddx + c] = o;
-                if (a.dx2) {
-                    float o2 = o;
-                    if (a.drop_mask) o2 *= a.drop_scale * (float)a.drop_mask[(size_t)row * a.lddrop + c];
-                    a.dx2[(size_t)row * a.lddx2 + c] = o2;
-                }
+                if (a.dx2) a.dx2[(size_t)row * a.lddx2 + c] = o * km[e];
             }
         }
     }
@@ -199,8 +230,9 @@ __global__ __launch_bounds__(256) void ln_param_finalize_batched_kernel(const r3
     const r3d_ln_finalize_job j = jobs[blockIdx.y];
     int rpb = ((j.rows + 255) / 256 + 3) / 4 * 4;
     if (rpb < 4) rpb = 4;
-    const int blocks = (j.rows + rpb - 1) / rpb;
-    if (blocks <= 1) return;                               // the backward kernel already wrote the final values
+    // rows < 0: the producer wrote exactly -rows partial pairs (r3d_embed_fuse_bwd: one per frame)
+    const int blocks = j.rows < 0 ? -j.rows : (j.rows + rpb - 1) / rpb;
+    if (blocks <= 1 && j.rows > 0) return;                 // the backward kernel already wrote the final values
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + lane;
     float s = 0.f;

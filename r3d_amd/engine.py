@@ -125,7 +125,7 @@ class _Shape:
         self.seg = f(N, K)
         self.loss = f(4)
         self.tables = {}
-        self.loss_ws = f(4 * (N + BQ + B))
+        self.loss_ws = torch.zeros(ops.losses_ws_floats(B, S, eng.Q), dtype=torch.float32, device=dev)
         self.counts = torch.zeros(4, dtype=torch.int64, device=dev)
         if train:
             self.d_actdur, self.d_seg = torch.zeros(BQ, K + 1, dtype=torch.float32, device=dev), f(N, K)
@@ -138,6 +138,8 @@ class _Shape:
             self.d_fused, self.d_fused2 = f(N, H), f(N, H)
             lnw = lambda rows: f(max(ops.layernorm_bwd_ws_floats(rows, H), 4))       # noqa: E731
             self.lnp = dict(final=lnw(BQ), nf=lnw(2 * N), n2=lnw(2 * N), n1=lnw(2 * N), dep=lnw(N))
+            # the fused embedding seam (embed.hip) leaves one (dgamma, dbeta) partial per frame for these two sites
+            self.lnp_seam = dict(n1=f(2 * N * H), dep=f(2 * N * H))
             for l in range(L):
                 self.lnp.update({f"d3_{l}": lnw(BQ), f"d2_{l}": lnw(BQ), f"d1_{l}": lnw(BQ)})
             self.d_x3, self.d_u, self.d_h1, self.d_h2, self.d_x1, self.d_v, self.d_x0 = (
@@ -176,6 +178,7 @@ class FusionEngine:
         self.ws_side2 = ops.GemmWorkspace(self.device)
         self.use_side_stream = True
         self.use_fused_decoder = True           # one workgroup per clip and layer (decoder.hip) when the shape fits LDS
+        self.use_fused_embed = True             # train mode: projections' slab sums + LN + exchange + norm1 in one launch
         self.shapes = {}
         self.train_mask = None            # cached train-mode selection (data independent)
         self.drop_seed = 0x5EED
@@ -243,7 +246,10 @@ class FusionEngine:
         if drop:
             ops.dropout_mask(w.drop_pool, DROP_P, self.drop_seed, self.drop_offset)
         tp = self.tp if (self.tp is not None and need_grad) else None
-        ops.gemm(GEMM_NT, x_rgb, a.p("input_embed.weight"), w.rgb, bias=a.p("input_embed.bias"), act=1, ws=self.ws)
+        seam = self.use_fused_embed and mode == "train" and H <= 1024
+        dr = ops.gemm(GEMM_NT, x_rgb, a.p("input_embed.weight"), w.rgb, bias=a.p("input_embed.bias"), act=1,
+                      ws=self.ws_side if seam else self.ws, defer_reduce=seam)
+        slabs_r = self.ws_side.buf if (seam and dr.splitk > 1) else None
         d = None
         if tp is None:
             d = ops.gemm(GEMM_NT, x_dep, a.p("depth_projection.weight"), w.dep_pre, bias=a.p("depth_projection.bias"),
@@ -254,7 +260,7 @@ class FusionEngine:
         # (a later, larger request would re-allocate the workspace) -- nothing may use self.ws before that launch
         slabs = self.ws.buf if (d is not None and d.splitk > 1) else None
         self._fw = dict(w=w, x_rgb=x_rgb, x_dep=x_dep, labels=labels, mode=mode, drop=drop, d=d, tp=tp, B=B, S=S,
-                        slabs=slabs)
+                        slabs=slabs, seam=seam, dr=dr, slabs_r=slabs_r)
 
     def forward_finish(self):
         """Everything after the input projections; see forward()."""
@@ -292,8 +298,25 @@ class FusionEngine:
             wi, bi = a.p(pl + "multihead_attn.in_proj_weight"), a.p(pl + "multihead_attn.in_proj_bias")
             ops.gemm(GEMM_NT, c["t1"], wi[:H], c["caq"], a_add=qpos, a_add_mod=Q, bias=bi[:H], ws=wsx)
 
+        seam = fw["seam"]
+        pre = "fuser.blocks.0."
+        if seam:
+            # ---- one launch: slab sums of both projections, bias/ReLU, depth LayerNorm + ReLU (:183,195-197), token
+            # exchange + embd_drop (:56-62,83) and the fuser block's norm1 (transformerblock.py:122)
+            idx, mask = self._train_masks(B, S)
+            dr = fw["dr"]
+            if tp is not None:
+                dep_src, ns_d, bias_d = tp.summed(w), 1, a.p("depth_projection.bias")
+            elif d.splitk > 1:
+                dep_src, ns_d, bias_d = fw["slabs"], d.splitk, a.p("depth_projection.bias")
+            else:
+                dep_src, ns_d, bias_d = w.dep_pre, 1, None
+            ops.embed_fuse_fwd(fw["slabs_r"] if dr.splitk > 1 else w.rgb, dr.splitk if dr.splitk > 1 else 0,
+                               a.p("input_embed.bias"), dep_src, ns_d, bias_d, a.p("depth_layernorm.weight"),
+                               a.p("depth_layernorm.bias"), mask[0], mask[1], dm("x0"), dsc, a.p(pre + "norm1.weight"),
+                               a.p(pre + "norm1.bias"), w.rgb, w.dep_pre, w.mean_d, w.rstd_d, w.dep, w.x0, w.h1, w.m1, w.r1)
         # ---- depth LayerNorm + ReLU first: it drains the deferred split-K slabs (:196-197)
-        if tp is not None:                      # the exchanged sum of the ranks' partial products, bias still to add
+        elif tp is not None:                      # the exchanged sum of the ranks' partial products, bias still to add
             ops.layernorm_fwd(tp.summed(w), a.p("depth_layernorm.weight"), a.p("depth_layernorm.bias"), w.dep, w.mean_d,
                               w.rstd_d, relu=True, nsplit=1, bias=a.p("depth_projection.bias"), pre_out=w.dep_pre,
                               rows=N, H=H)
@@ -314,7 +337,9 @@ class FusionEngine:
             with torch.cuda.stream(s2):
                 sa_block(0, w.tgt0, ws2)
         # ---- token selection + exchange (:33-66)
-        if mode == "train":
+        if seam:
+            pass
+        elif mode == "train":
             idx, mask = self._train_masks(B, S)
         else:
             ops.colabssum(w.rgb, w.sums[0])
@@ -324,10 +349,10 @@ class FusionEngine:
                 count = self.score_allreduce(w.sums, N)
             ops.token_select(H // 4, w.idx, w.mask, score_sum=w.sums, count=count)
             idx, mask = w.idx, w.mask
-        ops.token_exchange_fwd(w.rgb, w.dep, mask[0], mask[1], w.x0, drop_mask=dm("x0"), drop_scale=dsc)
         # ---- SA-Fuser block in closed form (transformerblock.py:118-135) + x_res + norm + mean (:86-94)
-        pre = "fuser.blocks.0."
-        ops.layernorm_fwd(w.x0, a.p(pre + "norm1.weight"), a.p(pre + "norm1.bias"), w.h1, w.m1, w.r1)
+        if not seam:
+            ops.token_exchange_fwd(w.rgb, w.dep, mask[0], mask[1], w.x0, drop_mask=dm("x0"), drop_scale=dsc)
+            ops.layernorm_fwd(w.x0, a.p(pre + "norm1.weight"), a.p(pre + "norm1.bias"), w.h1, w.m1, w.r1)
         wv = a.p(pre + "attn.qkv.weight")[2 * H:]
         ops.gemm(GEMM_NT, w.h1, wv, w.vsw, c_row_xor=1, ws=self.ws)            # V of the OTHER modality token
         ops.gemm(GEMM_NT, w.vsw, a.p(pre + "attn.proj.weight"), w.x1, bias=a.p(pre + "attn.proj.bias"), res1=w.x0,
@@ -345,7 +370,7 @@ class FusionEngine:
             self._decoder_fused(w, key_labels, drop, dsc)
         else:
             self._decoder_unfused(w, key_labels, dm, dsc, multi, main, s2, sa_block)
-        self.last = dict(w=w, x_rgb=x_rgb, x_dep=x_dep, mask=mask, idx=idx, drop=drop, mode=mode, tp=tp)
+        self.last = dict(w=w, x_rgb=x_rgb, x_dep=x_dep, mask=mask, idx=idx, drop=drop, mode=mode, tp=tp, seam=seam)
         return dict(seg=w.seg.view(B, S, K), action=w.actdur[:, :K].view(B, Q, K), duration=w.actdur[:, K].view(B, Q))
 
     def _decoder_unfused(self, w, key_labels, dm, dsc, multi, main, s2, sa_block):
@@ -419,15 +444,20 @@ class FusionEngine:
         return None if m is None else m.view(rows, cols)
 
     # ------------------------------------------------------------------------------------------------------
-    def losses(self, past_label, target, target_dur, with_grad=True, val_mode=False):
-        """The 3 losses + counters of train_proposed_depth.py:171-213 in one launch; fills d_seg / d_actdur."""
+    def losses(self, past_label, target, target_dur, with_grad=True, val_mode=False, tick=False):
+        """The 3 losses + counters of train_proposed_depth.py:171-213 in one launch; fills d_seg / d_actdur.
+        tick=True: the launch also advances the optimiser's step counter (and the dropout offset when dropout ran), so
+        the following adamw(..., ticked=True) needs no launch of its own for that."""
         w = self.last["w"]
         K = self.K
+        ta = self.step_t if tick else None
+        tb = self.drop_offset if (tick and self.last["drop"]) else None
         ops.losses_fwd_bwd(None if val_mode else w.seg, w.actdur[:, :K], w.actdur[:, K:], K + 1, past_label, target,
                            target_dur, w.B, w.S, self.Q, K, self.pad_idx, EXCLUDE_CLASS_IDX, w.loss, w.counts,
                            val_mode=val_mode, dur_den=self.dur_den,
                            d_seg=w.d_seg if with_grad else None, d_act=w.d_actdur[:, :K] if with_grad else None,
-                           d_dur=w.d_actdur[:, K:] if with_grad else None, ld_ddur=K + 1, ws=w.loss_ws)
+                           d_dur=w.d_actdur[:, K:] if with_grad else None, ld_ddur=K + 1, ws=w.loss_ws, tick_a=ta,
+                           tick_b=tb)
         return w.loss, w.counts
 
     # ------------------------------------------------------------------------------------------------------
@@ -491,6 +521,9 @@ class FusionEngine:
             for k in (1, 2, 3):
                 J.append((w.lnp[f"d{k}_{l}"], BQ, H, a.g(pl + f"norm{k}.weight"), a.g(pl + f"norm{k}.bias")))
         w.ln_group = ops.LnFinalizeGroup(J)
+        Js = [(w.lnp_seam["n1"], -N, H) + j[3:] if j[0] is w.lnp["n1"] else
+              ((w.lnp_seam["dep"], -N, H) + j[3:] if j[0] is w.lnp["dep"] else j) for j in J]
+        w.ln_group_seam = ops.LnFinalizeGroup(Js)
         R = [(w.d_fused, None, S, a.g("pos_embedding")[0, :S]),
              (w.d_dep_pre, None, 1, a.g("depth_projection.bias").view(1, H)),
              (w.glayers[self.L - 1]["caqin"], w.glayers[self.L - 1]["sain"], Q, a.g("query_embed.weight"))]
@@ -583,17 +616,24 @@ class FusionEngine:
         ln_bwd("n2", w.d_h2, w.x1, w.m2, w.r2, pre + "norm2.weight", pre + "norm2.bias", w.d_x1, add1=w.d_x3)
         ops.gemm(GEMM_NN, w.d_x1, a.p(pre + "attn.proj.weight"), w.d_v, c_row_xor=1, ws=ws)     # un-swap
         ops.gemm(GEMM_NN, w.d_v, a.p(pre + "attn.qkv.weight")[2 * H:], w.d_h1, ws=ws)
-        ln_bwd("n1", w.d_h1, w.x0, w.m1, w.r1, pre + "norm1.weight", pre + "norm1.bias", w.d_x0, add1=w.d_x1, add2=w.d_x3)
         mask = st["mask"]
-        ops.token_exchange_bwd(w.d_x0, w.rgb, mask[0], mask[1], w.d_rgb_pre, w.d_dep, drop_mask=dmf("x0"), drop_scale=dsc)
-        # ---- embeddings
-        ln_bwd("dep", w.d_dep, w.dep_pre, w.mean_d, w.rstd_d, "depth_layernorm.weight", "depth_layernorm.bias",
-               w.d_dep_pre, relu=True)
+        if st["seam"]:                      # norm1 backward + exchange backward + depth LayerNorm backward: one launch
+            ops.embed_fuse_bwd(w.d_h1, w.x0, w.m1, w.r1, a.p(pre + "norm1.weight"), w.d_x1, w.d_x3, dmf("x0"), dsc, mask[0],
+                               mask[1], w.rgb, w.dep_pre, w.mean_d, w.rstd_d, a.p("depth_layernorm.weight"),
+                               a.p("depth_layernorm.bias"), w.d_rgb_pre, w.d_dep_pre, w.lnp_seam["n1"], w.lnp_seam["dep"])
+        else:
+            ln_bwd("n1", w.d_h1, w.x0, w.m1, w.r1, pre + "norm1.weight", pre + "norm1.bias", w.d_x0, add1=w.d_x1,
+                   add2=w.d_x3)
+            ops.token_exchange_bwd(w.d_x0, w.rgb, mask[0], mask[1], w.d_rgb_pre, w.d_dep, drop_mask=dmf("x0"),
+                                   drop_scale=dsc)
+            # ---- embeddings
+            ln_bwd("dep", w.d_dep, w.dep_pre, w.mean_d, w.rstd_d, "depth_layernorm.weight", "depth_layernorm.bias",
+                   w.d_dep_pre, relu=True)
         if not joined:
             main.wait_stream(s2)
         # ---- everything that only feeds parameter gradients: 2 launches + the broadcast-parameter sums
         w.wgrad_group.launch()
-        w.ln_group.launch()
+        (w.ln_group_seam if st["seam"] else w.ln_group).launch()
         ops.gemm(GEMM_TN, w.d_rgb_pre, st["x_rgb"], a.g("input_embed.weight"), bias_grad=a.g("input_embed.bias"), ws=ws)
         w.rowsum_group.launch()            # pos_embedding (:190), depth_projection.bias, query_embed (top layer)
         g_qe = a.g("query_embed.weight")
@@ -603,13 +643,15 @@ class FusionEngine:
             ops.rowmod_sum(gl["sain"], Q, g_qe, accumulate=True)
 
     # ------------------------------------------------------------------------------------------------------
-    def adamw(self, lr, weight_decay, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0, tick_dropout=False):
-        """One fused launch over the live prefix of the arena (main_darai.py:135; train_proposed_depth.py:215)."""
+    def adamw(self, lr, weight_decay, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0, tick_dropout=False, ticked=False):
+        """One fused launch over the live prefix of the arena (main_darai.py:135; train_proposed_depth.py:215).
+        ticked: losses(tick=True) already advanced the counters in this step."""
         a = self.arena
         if self._lr_host != float(lr):          # lr lives in device memory so a captured graph sees scheduler updates
             self.lr_t.fill_(float(lr))
             self._lr_host = float(lr)
-        ops.tick(self.step_t, self.drop_offset if tick_dropout else None)
+        if not ticked:
+            ops.tick(self.step_t, self.drop_offset if tick_dropout else None)
         n = a.n_live if self.tp is None else a.bucket_small[1]
         ops.adamw_flat(a.params[:n], a.grads[:n], a.exp_avg[:n], a.exp_avg_sq[:n], self.lr_t, self.step_t, beta1=betas[0],
                        beta2=betas[1], eps=eps, weight_decay=weight_decay, grad_scale=grad_scale)
@@ -621,7 +663,7 @@ class FusionEngine:
     def train_step(self, feats, depth, past_label, target_dur, target, lr, weight_decay, training=True):
         """forward + losses + backward + AdamW, all enqueued, no host sync.  Returns (loss[4], counts[4]) on device."""
         self.forward(feats, depth, past_label, "train", training)
-        loss, counts = self.losses(past_label, target, target_dur)
+        loss, counts = self.losses(past_label, target, target_dur, tick=True)
         self.backward()
-        self.adamw(lr, weight_decay, tick_dropout=self.last["drop"])
+        self.adamw(lr, weight_decay, ticked=True)
         return loss, counts

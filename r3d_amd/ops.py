@@ -353,24 +353,50 @@ def decoder_layer_fwd(table, B, S, Q, H, heads, pad_idx, drop_scale, n_head_out)
           "r3d_decoder_layer_fwd")
 
 
+def embed_fuse_fwd(rgb_src, ns_r, bias_r, dep_src, ns_d, bias_d, lnd_g, lnd_b, m_rgb, m_dep, drop, drop_scale, ln1_g, ln1_b,
+                   rgb_out, dep_pre_out, mean_d, rstd_d, dep_out, x0, h1, m1, r1):
+    N, H = dep_out.shape
+    check(_lib.load().r3d_embed_fuse_fwd(_p(rgb_src), ns_r, _p(bias_r), _p(dep_src), ns_d, _p(bias_d), _p(lnd_g), _p(lnd_b),
+                                         _p(m_rgb), _p(m_dep), _p(drop), drop_scale, _p(ln1_g), _p(ln1_b), _p(rgb_out),
+                                         _p(dep_pre_out), _p(mean_d), _p(rstd_d), _p(dep_out), _p(x0), _p(h1), _p(m1),
+                                         _p(r1), N, H, _stream()), "r3d_embed_fuse_fwd")
+
+
+def embed_fuse_bwd(d_h1, x0, m1, r1, ln1_g, add1, add2, drop, drop_scale, m_rgb, m_dep, rgb, dep_pre, mean_d, rstd_d, lnd_g,
+                   lnd_b, d_rgb_pre, d_dep_pre, ws_n1, ws_dep):
+    N, H = rgb.shape
+    assert ws_n1.numel() >= 2 * N * H and ws_dep.numel() >= 2 * N * H
+    check(_lib.load().r3d_embed_fuse_bwd(_p(d_h1), _p(x0), _p(m1), _p(r1), _p(ln1_g), _p(add1), _p(add2), _p(drop),
+                                         drop_scale, _p(m_rgb), _p(m_dep), _p(rgb), _p(dep_pre), _p(mean_d), _p(rstd_d),
+                                         _p(lnd_g), _p(lnd_b), _p(d_rgb_pre), _p(d_dep_pre), _p(ws_n1), _p(ws_dep), N, H,
+                                         _stream()), "r3d_embed_fuse_bwd")
+
+
 # ----------------------------------------------------------------------------------------------------------
 # losses / optimiser / dropout / erank
 # ----------------------------------------------------------------------------------------------------------
 def losses_fwd_bwd(seg, act, dur, ld_dur, past_label, target, target_dur, B, S, Q, K, pad_idx, exclude_idx, loss_out,
                    counts, *, val_mode=False, dur_den=None, grad_scale=1.0, d_seg=None, d_act=None, d_dur=None,
-                   ld_ddur=1, ws=None):
+                   ld_ddur=1, ws=None, tick_a=None, tick_b=None):
+    """ws: zero-initialised float32 scratch of losses_ws_floats(B, S, Q) (kept zero-terminated by the kernel)."""
     lib = _lib.load()
     assert past_label.dtype == torch.int64 and target.dtype == torch.int64 and target_dur.dtype == torch.float32
     assert past_label.is_contiguous() and target.is_contiguous() and target_dur.is_contiguous()
     assert counts.dtype == torch.int64 and loss_out.dtype == torch.float32
     need = lib.r3d_losses_ws_floats(B, S, Q)
-    if ws is None or ws.numel() < need:
-        ws = torch.empty(need, dtype=torch.float32, device=act.device)
+    if ws is None:
+        ws = torch.zeros(need, dtype=torch.float32, device=act.device)
+    assert ws.numel() >= need
     check(lib.r3d_losses_fwd_bwd(_p(seg), _ld(seg) if seg is not None else 0, _p(act), _ld(act), _p(dur), ld_dur,
                                  _p(past_label), _p(target), _p(target_dur), B, S, Q, K, pad_idx, exclude_idx,
                                  1 if val_mode else 0, _p(dur_den), grad_scale, _p(d_seg),
                                  _ld(d_seg) if d_seg is not None else 0, _p(d_act), _ld(d_act) if d_act is not None else 0,
-                                 _p(d_dur), ld_ddur, _p(loss_out), _p(counts), _p(ws), _stream()), "r3d_losses_fwd_bwd")
+                                 _p(d_dur), ld_ddur, _p(loss_out), _p(counts), _p(ws), _p(tick_a), _p(tick_b), _stream()),
+          "r3d_losses_fwd_bwd")
+
+
+def losses_ws_floats(B, S, Q):
+    return int(_lib.load().r3d_losses_ws_floats(B, S, Q))
 
 
 def adamw_flat(p, g, m, v, lr_t, step_t, *, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, grad_scale=1.0):

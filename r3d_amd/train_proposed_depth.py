@@ -121,13 +121,14 @@ def train(args, model, train_loader, optimizer, scheduler, criterion, model_save
             if dp is not None:
                 dp.prepare_duration_denominator(trans_dur_future, pad_idx)
             eng.forward(features, depth_features, past_label, "train", training=model.training)
-            loss, counts = eng.losses(past_label, trans_future_target, trans_dur_future)
+            fused_opt = isinstance(optimizer, FlatAdamW)
+            loss, counts = eng.losses(past_label, trans_future_target, trans_dur_future, tick=fused_opt)
             eng.backward()
             if dp is not None:
                 dp.wait_grads()
-            if isinstance(optimizer, FlatAdamW):
+            if fused_opt:
                 eng.adamw(g["lr"], g["weight_decay"], betas=g["betas"], eps=g["eps"],
-                          grad_scale=dp.grad_scale if dp is not None else 1.0, tick_dropout=eng.last["drop"])
+                          grad_scale=dp.grad_scale if dp is not None else 1.0, ticked=True)
             else:                                   # any other torch optimiser: expose the arena gradients to it
                 if dp is not None:
                     eng.arena.grads.mul_(dp.grad_scale)

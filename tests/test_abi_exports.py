@@ -39,7 +39,7 @@ def test_gemm_plan_is_host_only_and_sane(lib):
     d = GemmDesc()
     d.M, d.N, d.K = 128, 128, 50176            # depth_projection forward at B=8, S=16, H=128
     assert lib.r3d_gemm_plan(C.byref(d)) == 0
-    assert d.tile in (1, 2, 3) and d.splitk >= 8 and d.k_per_split % 16 == 0
+    assert d.tile in (1, 2, 3, 4, 5) and d.splitk >= 8 and d.k_per_split % 16 == 0
     assert d.k_per_split * d.splitk >= 50176
     d2 = GemmDesc()
     d2.M, d2.N, d2.K = 128, 50176, 128         # depth_projection weight gradient

@@ -227,3 +227,33 @@ def test_step_parity_baseline_sizes(B, S, H, K, n_dec, oracle_lib):
     for n, p in tr.p.items():
         if p.grad is not None:
             close_rel(eng.arena.g(n), p.grad, f"H{H}/grad {n}", rtol=2e-3)
+
+
+@pytest.mark.parametrize("tag,training", [("step_tiny", False), ("step_cfg2", False), ("step_cfg2", True), ("step_k122_dec2", True)])
+def test_fused_embedding_seam_equals_composed(tag, training):
+    """embed.hip (slab sums + LN + exchange + norm1 in one launch per direction) against the composed launches: same
+    activations, same gradients (identical dropout masks when training)."""
+    fx = load_fixture(tag)
+    model = build_model(fx)
+    model.train(training)
+    eng = model.engine()
+    d = [t.cuda() for t in fixture_batch(fx)]
+    res = []
+    for seam in (False, True):
+        eng.use_fused_embed = seam
+        eng.forward(d[0], d[1], d[2], "train", training=training)          # same drop_offset -> same masks
+        assert eng.last["seam"] == seam
+        eng.losses(d[2], d[4], d[3])
+        eng.backward()
+        torch.cuda.synchronize()
+        w = eng.last["w"]
+        res.append(dict(acts={k: getattr(w, k).clone() for k in ("rgb", "dep", "dep_pre", "mean_d", "rstd_d", "x0", "h1",
+                                                                 "m1", "r1", "fused", "d_rgb_pre", "d_dep_pre")},
+                        grads=eng.arena.grads.clone(), loss=w.loss.clone()))
+    for k in res[0]["acts"]:
+        close_rel(res[1]["acts"][k], res[0]["acts"][k], f"{tag}/seam {k}", rtol=2e-5)
+    close_rel(res[1]["loss"], res[0]["loss"], "loss", rtol=1e-5)
+    a = eng.arena
+    for n in a.live_names:
+        o, k, _ = a.offsets[n]
+        close_rel(res[1]["grads"][o:o + k], res[0]["grads"][o:o + k], f"{tag}/seam grad {n}", rtol=5e-4)
