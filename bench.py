@@ -142,6 +142,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eval-dropout-off", action="store_true", help="bench the eval()-state step (dropout off)")
     ap.add_argument("--no-side-stream", action="store_true", help="keep the query self-attention branch on the main stream")
+    ap.add_argument("--fused-decoder", action="store_true", help="run the decoder layer as decoder.hip (one workgroup per "
+                                                                 "clip) instead of composed GEMM / attention / LN launches")
     ap.add_argument("--replicated-depth", action="store_true",
                     help="N>1: keep depth_projection replicated and all-reduce its 25.7 MB gradient (plain data parallel) "
                          "instead of sharding it over pixels")
@@ -172,6 +174,7 @@ def main():
         model.eval()
     eng = model.engine()
     eng.use_side_stream = not a.no_side_stream
+    eng.use_fused_decoder = a.fused_decoder
     from r3d_amd.parallel import DataParallelStep
     feats, depth, lab, dur, tgt = make_inputs(c, device, seed=1 + rank)
     x_dep2d = depth.reshape(c["B"] * c["S"], -1)

@@ -177,7 +177,8 @@ class FusionEngine:
         self.side2 = torch.cuda.Stream(self.device)     # independent branch (self-attention of the queries)
         self.ws_side2 = ops.GemmWorkspace(self.device)
         self.use_side_stream = True
-        self.use_fused_decoder = True           # one workgroup per clip and layer (decoder.hip) when the shape fits LDS
+        self.use_fused_decoder = False          # decoder.hip (one workgroup per clip and layer): measured 2 % slower than
+                                                # the composed launches at the bench shape since the GEMM epilogue rework
         self.use_fused_embed = True             # train mode: projections' slab sums + LN + exchange + norm1 in one launch
         self.shapes = {}
         self.train_mask = None            # cached train-mode selection (data independent)
