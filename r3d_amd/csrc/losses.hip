@@ -129,8 +129,11 @@ __device__ __forceinline__ void losses_unit(const LossArgs& a, float* part, int 
         out_l = sq; out_v = mc;             // every duration unit carries the same mask count
     }
     if (lane == 0) {
-        float4 o = make_float4(out_l, out_c, out_v, 0.f);
-        reinterpret_cast<float4*>(part)[u] = o;
+        // agent-scope (write-through) stores: they leave this XCD's L2, so the finishing workgroup on another XCD sees
+        // them without anybody paying a whole-L2 write-back fence
+        __hip_atomic_store(part + 4 * (size_t)u + 0, out_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(part + 4 * (size_t)u + 1, out_c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(part + 4 * (size_t)u + 2, out_v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -138,11 +141,13 @@ __device__ __forceinline__ void losses_finalize(const LossArgs& a, const float* 
     __shared__ double red[4][3][3];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int N = a.B * a.S, BQ = a.B * a.Q;
-    const float4* p4 = reinterpret_cast<const float4*>(part);
     // wave w sums units w, w+256... in a fixed order; 3 groups x {loss, correct, valid}
     double acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
     for (int u = threadIdx.x; u < N + BQ + a.B; u += 256) {
-        const float4 v = p4[u];
+        float4 v;
+        v.x = __hip_atomic_load(part + 4 * (size_t)u + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v.y = __hip_atomic_load(part + 4 * (size_t)u + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v.z = __hip_atomic_load(part + 4 * (size_t)u + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int g = u < N ? 0 : (u < N + BQ ? 1 : 2);
         acc[g][0] += v.x; acc[g][1] += v.y; acc[g][2] += v.z;
     }
@@ -171,20 +176,21 @@ __device__ __forceinline__ void losses_finalize(const LossArgs& a, const float* 
     }
 }
 
-// One launch: every workgroup finishes its 4 units, the LAST one to arrive (device-scope counter behind an agent
-// release fence; acquire fence before it reads the others' partials) adds them up in a fixed order -- bitwise
-// reproducible, and no second dependent launch (~5 us on this part) for a result the backward does not even consume.
+// One launch: every workgroup finishes its 4 units and publishes their partials with agent-scope write-through stores
+// (drained with vmcnt(0) before its arrival is counted); the LAST workgroup to arrive reads them back with agent-scope
+// loads and adds them up in a fixed order -- bitwise reproducible, no second dependent launch (~5 us on this part) for a
+// result the backward does not even consume, and no whole-L2 write-back fence (measured 13 us with __threadfence).
 __global__ __launch_bounds__(256) void losses_kernel(const LossArgs a, float* part, unsigned* arrivals) {
     __shared__ int is_last;
     const int lane = threadIdx.x & 63;
     const int u = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (u < a.B * a.S + a.B * a.Q + a.B) losses_unit(a, part, u, lane);
-    __threadfence();
+    __builtin_amdgcn_s_waitcnt(0);                     // this wave's write-through stores have left the CU
     __syncthreads();
-    if (threadIdx.x == 0) is_last = (atomicAdd(arrivals, 1u) == gridDim.x - 1) ? 1 : 0;
+    if (threadIdx.x == 0)
+        is_last = (__hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1 : 0;
     __syncthreads();
     if (!is_last) return;
-    __threadfence();
     losses_finalize(a, part);
     if (threadIdx.x == 0) *arrivals = 0u;             // ready for the next launch
 }

@@ -236,8 +236,16 @@ __global__ __launch_bounds__(256) void ln_param_finalize_batched_kernel(const r3
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + lane;
     float s = 0.f;
-    if (i < 2 * j.H)
-        for (int p = wave; p < blocks; p += 4) s += j.ws[(size_t)p * 2 * j.H + i];
+    if (i < 2 * j.H) {
+        float s4[4] = {0.f, 0.f, 0.f, 0.f};           // independent chains: 4 loads in flight per lane
+        int p = wave;
+        for (; p + 12 < blocks; p += 16) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s4[q] += j.ws[(size_t)(p + 4 * q) * 2 * j.H + i];
+        }
+        for (; p < blocks; p += 4) s4[0] += j.ws[(size_t)p * 2 * j.H + i];
+        s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+    }
     red[wave][lane] = s;
     __syncthreads();
     if (wave == 0 && i < 2 * j.H) {
