@@ -144,6 +144,9 @@ def main():
     ap.add_argument("--no-side-stream", action="store_true", help="keep the query self-attention branch on the main stream")
     ap.add_argument("--fused-decoder", action="store_true", help="run the decoder layer as decoder.hip (one workgroup per "
                                                                  "clip) instead of composed GEMM / attention / LN launches")
+    ap.add_argument("--fused-adamw", action="store_true",
+                    help="apply AdamW to depth_projection.weight in its weight-gradient GEMM's epilogue instead of writing "
+                         "the gradient and updating it in the flat AdamW launch (measured neutral: 376 vs 374 us/step)")
     ap.add_argument("--replicated-depth", action="store_true",
                     help="N>1: keep depth_projection replicated and all-reduce its 25.7 MB gradient (plain data parallel) "
                          "instead of sharding it over pixels")
@@ -181,6 +184,7 @@ def main():
     training = model.training
     dp = tp = None
     slot = [0]
+    fuse_adam = a.fused_adamw
 
     def step_eager():
         if dp is not None:
@@ -192,10 +196,11 @@ def main():
             tp.exchange_forward(eng._fw["w"])
         eng.forward_finish()
         eng.losses(lab, tgt, dur, tick=True)
-        eng.backward()
+        fuse = fuse_adam and (dp is None or tp is not None)      # that gradient needs no exchange
+        eng.backward(fused_adamw=dict(lr=c["lr"], weight_decay=c["wd"], grad_scale=gscale) if fuse else None)
         if dp is not None:
             dp.wait_grads()
-        eng.adamw(c["lr"], c["wd"], grad_scale=gscale, ticked=True)
+        eng.adamw(c["lr"], c["wd"], grad_scale=gscale, ticked=True, skip_depth=fuse)
 
     mode = "replicated"
     if world > 1:
@@ -263,10 +268,11 @@ def main():
                             eng.losses(lab, tgt, dur, tick=True)
                             eng.backward_main()
                     gC[s] = torch.cuda.CUDAGraph()
+                    eng.prepare_fused_adamw(dict(lr=c["lr"], weight_decay=c["wd"], grad_scale=gscale) if fuse_adam else None)
                     with torch.cuda.graph(gC[s]):
-                        tp.wgrad(w_, eng.ws)
+                        tp.wgrad(w_, eng.ws, eng._adam)
                 with torch.cuda.graph(gD):
-                    eng.adamw(c["lr"], c["wd"], grad_scale=gscale, ticked=True)
+                    eng.adamw(c["lr"], c["wd"], grad_scale=gscale, ticked=True, skip_depth=fuse_adam)
                 eng.grad_hook = hook
                 slot[0] = 0
                 tp.prefetch(x_dep2d, 0)

@@ -85,6 +85,13 @@ typedef struct r3d_gemm_desc {
     int32_t tile;            /* 0 = auto; workgroup tile: 1 = 32x32 (4 k-split waves), 2 = 64x64, 3 = 128x128,
                                 4 = 64x64 with 2 k-split wave groups, 5 = 128x128 with 2 k-split wave groups */
     int32_t vec;             /* filled by the library: operands allow 16-byte loads */
+    /* AdamW in the epilogue (adam_m != NULL; weight-gradient GEMMs with splitk == 1, tile 2 or 3, N % 4 == 0, 16-byte
+     * aligned C / moments, no other epilogue operand): the
+     * product alpha * A.B is the GRADIENT and is not stored; C is the PARAMETER, adam_m / adam_v its moments (same
+     * layout and ldc), all three updated in place exactly as r3d_adamw_flat would (lr, step: device scalars).  Saves the
+     * gradient's write and re-read and one pass over the parameter: depth_projection.weight is 86 % of the model. */
+    float* adam_m; float* adam_v; const float* adam_lr; const int64_t* adam_step;
+    float adam_beta1, adam_beta2, adam_eps, adam_wd, adam_gscale;
 } r3d_gemm_desc;
 
 int r3d_gemm_f32(const r3d_gemm_desc* d, void* stream);

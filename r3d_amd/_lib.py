@@ -31,6 +31,9 @@ class GemmDesc(C.Structure):
         ("splitk", C.c_int32), ("k_per_split", C.c_int32), ("partial", C.c_void_p),
         ("tile", C.c_int32),
         ("vec", C.c_int32),
+        ("adam_m", C.c_void_p), ("adam_v", C.c_void_p), ("adam_lr", C.c_void_p), ("adam_step", C.c_void_p),
+        ("adam_beta1", C.c_float), ("adam_beta2", C.c_float), ("adam_eps", C.c_float), ("adam_wd", C.c_float),
+        ("adam_gscale", C.c_float),
     ]
 
 

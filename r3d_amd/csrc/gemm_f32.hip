@@ -426,6 +426,54 @@ __device__ __forceinline__ void gemm_body(const r3d_gemm_desc& d, int tile, int 
         ++kt;
     }
 
+    if (WK == 1 && d.adam_m) {
+        // AdamW epilogue: the output tile (= the gradient) goes through LDS so that parameter and moments are streamed
+        // row-contiguously with 16-byte accesses (the MFMA layout gives a lane one column: 4-byte accesses, six
+        // arrays -- measured slower than the separate AdamW launch).  Same arithmetic and order as adamw_kernel.
+        constexpr int SO = BN + 4;
+        static_assert(BM * SO <= gemm_lds_floats<LA, LB, BM, BN, BK>(), "output tile does not fit the staging LDS");
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    smem[(wm_off + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * SO + wn_off + j * 32 + l31] = acc[i][j][r];
+        __syncthreads();
+        const float lr = *d.adam_lr;
+        const double stepd = (double)*d.adam_step;
+        const float bc1 = (float)(1.0 - pow((double)d.adam_beta1, stepd));
+        const float bc2_sqrt = (float)sqrt(1.0 - pow((double)d.adam_beta2, stepd));
+        const float decay = 1.0f - lr * d.adam_wd;
+        const float step_size = lr / bc1;
+        const float b2 = d.adam_beta2, eps = d.adam_eps, gs = d.alpha * d.adam_gscale;
+        const float omb1 = 1.0f - d.adam_beta1, omb2 = 1.0f - b2;
+        for (int f = threadIdx.x; f < BM * (BN / 4); f += NT) {
+            const int row = f / (BN / 4), c4 = f % (BN / 4);
+            const int gm = m0 + row, gn = n0 + 4 * c4;
+            if (gm >= d.M || gn >= d.N) continue;
+            const float4 gg = *reinterpret_cast<const float4*>(smem + row * SO + 4 * c4);
+            const size_t o = (size_t)gm * d.ldc + gn;
+            float4 pp = *reinterpret_cast<float4*>(d.C + o);
+            float4 mm = *reinterpret_cast<float4*>(d.adam_m + o);
+            float4 vv = *reinterpret_cast<float4*>(d.adam_v + o);
+#define R3D_ADAM_E(c)                                              \
+            {                                                      \
+                const float gr = gg.c * gs;                        \
+                pp.c *= decay;                                     \
+                mm.c = mm.c + (gr - mm.c) * omb1;                  \
+                vv.c = vv.c * b2 + gr * gr * omb2;                 \
+                const float den = sqrtf(vv.c) / bc2_sqrt + eps;    \
+                pp.c -= step_size * (mm.c / den);                  \
+            }
+            R3D_ADAM_E(x) R3D_ADAM_E(y) R3D_ADAM_E(z) R3D_ADAM_E(w)
+#undef R3D_ADAM_E
+            *reinterpret_cast<float4*>(d.C + o) = pp;
+            *reinterpret_cast<float4*>(d.adam_m + o) = mm;
+            *reinterpret_cast<float4*>(d.adam_v + o) = vv;
+        }
+        return;
+    }
     if (QUAD) {
         constexpr int PER_WAVE = 17 * 64;
         static_assert(4 * PER_WAVE <= gemm_lds_floats<LA, LB, BM, BN, BK>(), "k-split reduction does not fit");
@@ -631,6 +679,13 @@ static int gemm_validate(const r3d_gemm_desc* d) {
     if (d->a_row_xor < 0 || d->a_row_xor > 1) return R3D_EINVAL;
     if (d->mul && !d->aux) return R3D_EINVAL;
     if (d->bias_grad && (d->layout != R3D_GEMM_TN || d->splitk > 1)) return R3D_EINVAL;
+    if (d->adam_m) {                     // AdamW epilogue: nothing else may want the product
+        if (!d->adam_v || !d->adam_lr || !d->adam_step || d->splitk > 1) return R3D_EINVAL;
+        if (d->tile != 2 && d->tile != 3) return R3D_EINVAL;           // tiles without k-split waves
+        if ((d->N & 3) || (d->ldc & 3) || d->c_row_xor || d->alpha == 0.f) return R3D_EINVAL;
+        if (!r3d_aligned16(d->C) || !r3d_aligned16(d->adam_m) || !r3d_aligned16(d->adam_v)) return R3D_EALIGN;
+        if (d->bias || d->pre_out || d->act || d->drop_mask || d->mul || d->res1 || d->res2 || d->accumulate) return R3D_EINVAL;
+    }
     if (d->splitk > 1) {
         if (!d->partial || d->k_per_split <= 0 || (d->k_per_split % 16) != 0) return R3D_EINVAL;
         if (r3d_cdiv(d->K, d->k_per_split) > d->splitk) return R3D_EINVAL;

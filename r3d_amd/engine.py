@@ -193,6 +193,7 @@ class FusionEngine:
         self.tp = None                    # parallel.PixelShardedDepth: depth_projection tensor-parallel over pixels
         self._fw = None
         self.last = None
+        self._adam = None
         a = self.arena
         K, H = self.K, self.H
         o_w = a.offsets["fc.weight"][0]
@@ -462,8 +463,12 @@ class FusionEngine:
         return w.loss, w.counts
 
     # ------------------------------------------------------------------------------------------------------
-    def backward(self, d_seg=None, d_actdur=None):
-        """Adjoint of forward(); gradients land in the grad arena (written, not accumulated)."""
+    def backward(self, d_seg=None, d_actdur=None, fused_adamw=None):
+        """Adjoint of forward(); gradients land in the grad arena (written, not accumulated).
+        fused_adamw: dict(lr, weight_decay[, betas, eps, grad_scale]) -> depth_projection.weight (86 % of the model) is
+        updated INSIDE its weight-gradient GEMM (the gradient is never written); follow with adamw(..., skip_depth=True).
+        Only valid when that gradient needs no exchange (one GPU, or the pixel-sharded projection)."""
+        self.prepare_fused_adamw(fused_adamw)
         self.backward_main(d_seg, d_actdur)
         if self.last["tp"] is not None:         # before the small bucket: the weight gradient waits for this one
             self.last["tp"].exchange_backward(self.last["w"])
@@ -473,12 +478,28 @@ class FusionEngine:
         if self.grad_hook is not None:
             self.grad_hook("big_ready")
 
+    def prepare_fused_adamw(self, cfg):
+        """cfg: None or dict(lr, weight_decay[, betas, eps, grad_scale]); consumed by backward_depth_wgrad()."""
+        self._adam = None
+        if cfg is not None:
+            self.set_lr(cfg["lr"])
+            b = cfg.get("betas", (0.9, 0.999))
+            self._adam = dict(lr_t=self.lr_t, step_t=self.step_t, beta1=b[0], beta2=b[1], eps=cfg.get("eps", 1e-8),
+                              weight_decay=cfg["weight_decay"], grad_scale=cfg.get("grad_scale", 1.0))
+
     def backward_depth_wgrad(self):
         """depth_projection.weight gradient [H, 50176] = d_dep_pre^T . depth -- the last and largest kernel of the
         backward (81 % of the gradient bytes at H=128); everything else is complete before it starts."""
         st = self.last
+        adam = getattr(self, "_adam", None)
         if st["tp"] is not None:                # this rank's pixel columns, summed over every rank's clips
-            st["tp"].wgrad(st["w"], self.ws)
+            st["tp"].wgrad(st["w"], self.ws, adam)
+            return
+        if adam is not None:
+            a = self.arena
+            o, n, shp = a.offsets["depth_projection.weight"]
+            ops.gemm(GEMM_TN, st["w"].d_dep_pre, st["x_dep"], a.p("depth_projection.weight"), ws=self.ws,
+                     adam=dict(adam, m=a.exp_avg[o:o + n].view(shp), v=a.exp_avg_sq[o:o + n].view(shp)))
             return
         ops.gemm(GEMM_TN, st["w"].d_dep_pre, st["x_dep"], self.arena.g("depth_projection.weight"), ws=self.ws)
 
@@ -644,19 +665,24 @@ class FusionEngine:
             ops.rowmod_sum(gl["sain"], Q, g_qe, accumulate=True)
 
     # ------------------------------------------------------------------------------------------------------
-    def adamw(self, lr, weight_decay, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0, tick_dropout=False, ticked=False):
-        """One fused launch over the live prefix of the arena (main_darai.py:135; train_proposed_depth.py:215).
-        ticked: losses(tick=True) already advanced the counters in this step."""
-        a = self.arena
+    def set_lr(self, lr):
         if self._lr_host != float(lr):          # lr lives in device memory so a captured graph sees scheduler updates
             self.lr_t.fill_(float(lr))
             self._lr_host = float(lr)
+
+    def adamw(self, lr, weight_decay, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0, tick_dropout=False, ticked=False,
+              skip_depth=False):
+        """One fused launch over the live prefix of the arena (main_darai.py:135; train_proposed_depth.py:215).
+        ticked: losses(tick=True) already advanced the counters in this step.
+        skip_depth: backward(fused_adamw=...) already updated depth_projection.weight."""
+        a = self.arena
+        self.set_lr(lr)
         if not ticked:
             ops.tick(self.step_t, self.drop_offset if tick_dropout else None)
-        n = a.n_live if self.tp is None else a.bucket_small[1]
+        n = a.n_live if (self.tp is None and not skip_depth) else a.bucket_small[1]
         ops.adamw_flat(a.params[:n], a.grads[:n], a.exp_avg[:n], a.exp_avg_sq[:n], self.lr_t, self.step_t, beta1=betas[0],
                        beta2=betas[1], eps=eps, weight_decay=weight_decay, grad_scale=grad_scale)
-        if self.tp is not None:                 # depth_projection.weight: only this rank's pixel columns are live here
+        if self.tp is not None and not skip_depth:  # depth_projection.weight: only this rank's pixel columns are live
             t = self.tp
             ops.adamw_2d(t.w, t.g, t.m, t.v, self.lr_t, self.step_t, beta1=betas[0], beta2=betas[1], eps=eps,
                          weight_decay=weight_decay, grad_scale=grad_scale)
@@ -665,6 +691,8 @@ class FusionEngine:
         """forward + losses + backward + AdamW, all enqueued, no host sync.  Returns (loss[4], counts[4]) on device."""
         self.forward(feats, depth, past_label, "train", training)
         loss, counts = self.losses(past_label, target, target_dur, tick=True)
+        # (backward(fused_adamw=...) + adamw(skip_depth=True) would update depth_projection.weight inside its
+        #  weight-gradient GEMM; measured neutral at the bench shape, so the plain sequence stays the default)
         self.backward()
         self.adamw(lr, weight_decay, ticked=True)
         return loss, counts

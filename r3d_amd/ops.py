@@ -50,8 +50,10 @@ class GemmWorkspace:
 
 def gemm(layout, a, b, c, *, bias=None, act=0, pre_out=None, a_add=None, a_add_mod=0, a_row_xor=0, b_add=None, b_add_mod=0,
          drop_mask=None, drop_scale=1.0, aux=None, mul=0, res1=None, res2=None, alpha=1.0, accumulate=False,
-         c_row_xor=0, bias_grad=None, ws=None, tile=0, splitk=0, defer_reduce=False):
-    """C = epilogue(A op B), see r3d_gemm_desc.  Shapes: NT a[M,K] b[N,K]; NN a[M,K] b[K,N]; TN a[K,M] b[K,N].
+         c_row_xor=0, bias_grad=None, ws=None, tile=0, splitk=0, defer_reduce=False, adam=None):
+    """adam: dict(m, v, lr_t, step_t, beta1, beta2, eps, weight_decay, grad_scale) -> the product is a weight gradient
+    and C is the PARAMETER: AdamW is applied in the epilogue (C, m, v updated in place; the gradient is not stored).
+    C = epilogue(A op B), see r3d_gemm_desc.  Shapes: NT a[M,K] b[N,K]; NN a[M,K] b[K,N]; TN a[K,M] b[K,N].
     Returns the (filled) descriptor; with defer_reduce=True and split-K the caller reduces the slabs itself
     (e.g. through layernorm_fwd(nsplit=...))."""
     lib = _lib.load()
@@ -100,6 +102,14 @@ def gemm(layout, a, b, c, *, bias=None, act=0, pre_out=None, a_add=None, a_add_m
         assert layout == GEMM_TN and bias_grad.numel() == M
         d.bias_grad = bias_grad.data_ptr()
     check(lib.r3d_gemm_plan(C.byref(d)), "r3d_gemm_plan")
+    if adam is not None:
+        assert _ld(adam["m"]) == d.ldc and _ld(adam["v"]) == d.ldc and adam["m"].shape == c.shape
+        d.adam_m, d.adam_v = adam["m"].data_ptr(), adam["v"].data_ptr()
+        d.adam_lr, d.adam_step = adam["lr_t"].data_ptr(), adam["step_t"].data_ptr()
+        d.adam_beta1, d.adam_beta2, d.adam_eps = adam["beta1"], adam["beta2"], adam["eps"]
+        d.adam_wd, d.adam_gscale = adam["weight_decay"], adam["grad_scale"]
+        d.splitk, d.k_per_split = 1, K
+        d.tile = 3 if d.tile in (3, 5) else 2           # the AdamW epilogue needs a tile without k-split waves
     if tile:
         d.tile = tile
     if splitk:

@@ -145,8 +145,12 @@ class PixelShardedDepth:
         dist.all_reduce(g, group=self.pg)                    # a gather: every other rank contributed zeros here
         w.tp_dpre_all = g
 
-    def wgrad(self, w, ws):
-        self.gemm(GEMM_TN, w.tp_dpre_all, w.tp_in["x"], self.g, ws=ws)
+    def wgrad(self, w, ws, adam=None):
+        """adam (engine.backward(fused_adamw=...)): the owned columns are updated inside the GEMM's epilogue."""
+        if adam is not None:
+            self.gemm(GEMM_TN, w.tp_dpre_all, w.tp_in["x"], self.w, ws=ws, adam=dict(adam, m=self.m, v=self.v))
+        else:
+            self.gemm(GEMM_TN, w.tp_dpre_all, w.tp_in["x"], self.g, ws=ws)
 
     # -- replicated view (validation, checkpoints) -----------------------------------------------------------------
     def sync_full_weight(self):

@@ -257,3 +257,32 @@ def test_fused_embedding_seam_equals_composed(tag, training):
     for n in a.live_names:
         o, k, _ = a.offsets[n]
         close_rel(res[1]["grads"][o:o + k], res[0]["grads"][o:o + k], f"{tag}/seam grad {n}", rtol=5e-4)
+
+
+def test_adamw_in_weight_gradient_epilogue_equals_flat_adamw():
+    """backward(fused_adamw=...) updates depth_projection.weight inside its weight-gradient GEMM; after one step the
+    parameters and both moments must equal the flat AdamW launch on the stored gradient.  After a second step only the
+    well-conditioned criterion holds: a 1-ulp difference in step 1 flips the sign of noise-level gradients in step 2
+    and Adam turns a sign into +-lr (see test_step_parity)."""
+    fx = load_fixture("step_cfg2")
+    m = fx["meta"]
+    d = [t.cuda() for t in fixture_batch(fx)]
+    states = []
+    for fused in (False, True):
+        model = build_model(fx).eval()
+        eng = model.engine()
+        snaps = []
+        for _ in range(2):
+            eng.forward(d[0], d[1], d[2], "train", training=False)
+            eng.losses(d[2], d[4], d[3], tick=True)
+            eng.backward(fused_adamw=dict(lr=m["lr"], weight_decay=m["wd"]) if fused else None)
+            eng.adamw(m["lr"], m["wd"], ticked=True, skip_depth=fused)
+            torch.cuda.synchronize()
+            a = eng.arena
+            snaps.append((a.params[:a.n_live].clone(), a.exp_avg.clone(), a.exp_avg_sq.clone()))
+        states.append(snaps)
+    for x, y, what in zip(states[0][0], states[1][0], ("params", "exp_avg", "exp_avg_sq")):
+        close_rel(y, x, f"fused AdamW step 1 {what}", rtol=1e-6)
+    dlt = (states[0][1][0] - states[1][1][0]).abs()
+    assert float(dlt.max()) <= 2.1 * m["lr"]
+    assert float((dlt <= 1e-5 * (1 + states[0][1][0].abs())).double().mean()) > 0.99
