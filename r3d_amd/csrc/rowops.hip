@@ -145,7 +145,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
             const int cc = c < a.H ? c : a.H - 1;
             xv[e] = a.x[(size_t)row * a.ldx + cc];
             dv[e] = a.pair_in ? 0.5f * a.dy[(size_t)(row >> 1) * a.lddy + cc] : a.dy[(size_t)row * a.lddy + cc];
-            d2[e] = a.dy2 ? a.dy2[(size_t)row * a.lddy2 + cc] : 0.f;
+            d2[e] = a.dy2 ? (a.pair_in ? 0.5f * a.dy2[(size_t)(row >> 1) * a.lddy2 + cc] : a.dy2[(size_t)row * a.lddy2 + cc])
+                          : 0.f;
             a1[e] = a.add1 ? a.add1[(size_t)row * a.ldadd1 + cc] : 0.f;
             a2[e] = a.add2 ? a.add2[(size_t)row * a.ldadd2 + cc] : 0.f;
             km[e] = (a.dx2 && a.drop_mask) ? a.drop_scale * (float)a.drop_mask[(size_t)row * a.lddrop + cc] : 1.f;
@@ -406,7 +407,7 @@ R3D_EXPORT int r3d_layernorm_bwd(const float* dy, int lddy, int pair_in, const f
     R3D_REQUIRE(rows > 0 && H > 0 && H <= 2048 && ldx >= H && lddx >= H && lddy >= H);
     R3D_REQUIRE((dgamma == nullptr) == (dbeta == nullptr));
     R3D_REQUIRE(!pair_in || (rows % 2) == 0);
-    R3D_REQUIRE(!dy2 || (lddy2 >= H && !pair_in));
+    R3D_REQUIRE(!dy2 || lddy2 >= H);                  /* pair_in applies to dy2 as well */
     const int rpb = ln_bwd_rows_per_block(rows);
     const int blocks = r3d_cdiv(rows, rpb);
     R3D_REQUIRE(blocks == 1 || !dgamma || ws);

@@ -365,8 +365,19 @@ class FusionEngine:
         ops.gemm(GEMM_NT, w.f1, a.p(pre + "mlp.mlp.2.weight"), w.x3, bias=a.p(pre + "mlp.mlp.2.bias"), res1=w.x1,
                  res2=w.x0, ws=self.ws)
         ops.layernorm_fwd(w.x3, a.p("fuser.norm.weight"), a.p("fuser.norm.bias"), w.y, w.mf, w.rf, pair_out=w.fused)
-        # ---- segmentation head (:228-232)
-        ops.gemm(GEMM_NT, w.fused, a.p("fc_seg.weight"), w.seg, bias=a.p("fc_seg.bias"), ws=self.ws)
+        # ---- segmentation head (:228-232); with the composed decoder it shares a launch with the layer-0 key/value
+        # projection (both read `fused`, neither depends on the other)
+        if not fused_dec:
+            if not hasattr(w, "fwd_group"):
+                wi0 = a.p("transformer.decoder.layers.0.multihead_attn.in_proj_weight")
+                bi0 = a.p("transformer.decoder.layers.0.multihead_attn.in_proj_bias")
+                w.fwd_group = ops.GemmGroup(GEMM_NT, [
+                    dict(a=w.fused, b=a.p("fc_seg.weight"), c=w.seg, bias=a.p("fc_seg.bias")),
+                    dict(a=w.fused, b=wi0[H:], c=w.layers[0]["cakv"], bias=bi0[H:], a_add=pos, a_add_mod=S)],
+                    tile=1 if H < 256 else 2)
+            w.fwd_group.launch()
+        else:
+            ops.gemm(GEMM_NT, w.fused, a.p("fc_seg.weight"), w.seg, bias=a.p("fc_seg.bias"), ws=self.ws)
         # ---- decoder (transformer.py:75-128,161-191,281-330); memory = fused, encoder bypassed (:77-78)
         if fused_dec:
             self._decoder_fused(w, key_labels, drop, dsc)
@@ -385,7 +396,8 @@ class FusionEngine:
             c, pl = w.layers[l], f"transformer.decoder.layers.{l}."
             wi, bi = a.p(pl + "multihead_attn.in_proj_weight"), a.p(pl + "multihead_attn.in_proj_bias")
             # key = value = memory + pos (:300-302): the broadcast add is the GEMM's A-operand prologue
-            ops.gemm(GEMM_NT, w.fused, wi[H:], c["cakv"], a_add=pos, a_add_mod=S, bias=bi[H:], ws=self.ws)
+            if l > 0:                      # (layer 0: in the segmentation head's launch, see forward_finish)
+                ops.gemm(GEMM_NT, w.fused, wi[H:], c["cakv"], a_add=pos, a_add_mod=S, bias=bi[H:], ws=self.ws)
             if l == 0:
                 if multi:
                     main.wait_stream(s2)
@@ -582,8 +594,12 @@ class FusionEngine:
             ops.layernorm_bwd(dy, x, mean, rstd, a.p(gname), a.p(bname), dx, a.g(gname), a.g(bname), partial=w.lnp[site],
                               **kw)
 
-        # ---- heads
-        ops.gemm(GEMM_NN, d_actdur, self.w_head, w.d_tgtF, ws=ws)
+        # ---- heads: both input gradients in one launch (the segmentation one is only needed at the fuser's norm)
+        if not hasattr(w, "head_group"):
+            w.head_group = ops.GemmGroup(GEMM_NN, [dict(a=w.d_actdur, b=self.w_head, c=w.d_tgtF),
+                                                   dict(a=w.d_seg, b=a.p("fc_seg.weight"), c=w.d_fused2)],
+                                         tile=1 if H < 256 else 2)
+        w.head_group.launch()
         # ---- decoder
         last = w.layers[-1]
         ln_bwd("final", w.d_tgtF, last["t3"], w.mF, w.rF, "transformer.decoder.norm.weight",
@@ -628,11 +644,10 @@ class FusionEngine:
                     main.wait_stream(s2)
                     joined = True
                 dy, dy2 = gl["sain"], gl["t1pre"]
-        # ---- the seg head joins d(memory): d_fused itself is kept for the positional-embedding gradient (:190)
-        ops.gemm(GEMM_NN, d_seg, a.p("fc_seg.weight"), w.d_fused2, res1=w.d_fused, ws=ws)
-        # ---- fuser
+        # ---- fuser; d(memory) = decoder part (d_fused, kept for the positional-embedding gradient :190) + seg head part
         pre = "fuser.blocks.0."
-        ln_bwd("nf", w.d_fused2, w.x3, w.mf, w.rf, "fuser.norm.weight", "fuser.norm.bias", w.d_x3, pair_in=True)
+        ln_bwd("nf", w.d_fused, w.x3, w.mf, w.rf, "fuser.norm.weight", "fuser.norm.bias", w.d_x3, pair_in=True,
+               dy2=w.d_fused2)
         ops.gemm(GEMM_NN, w.d_x3, a.p(pre + "mlp.mlp.2.weight"), w.d_u, aux=w.u, mul=2, ws=ws)
         ops.gemm(GEMM_NN, w.d_u, a.p(pre + "mlp.mlp.0.weight"), w.d_h2, ws=ws)
         ln_bwd("n2", w.d_h2, w.x1, w.m2, w.r2, pre + "norm2.weight", pre + "norm2.bias", w.d_x1, add1=w.d_x3)

@@ -164,6 +164,14 @@ class GemmGroup:
                 d.bias_grad = pr["bias_grad"].data_ptr()
             if pr.get("b_add") is not None:
                 d.b_add, d.b_add_mod, d.b_add_ld = pr["b_add"].data_ptr(), pr["b_add_mod"], _ld(pr["b_add"])
+            if pr.get("a_add") is not None:
+                d.a_add, d.a_add_mod, d.a_add_ld = pr["a_add"].data_ptr(), pr["a_add_mod"], _ld(pr["a_add"])
+            if pr.get("bias") is not None:
+                assert pr["bias"].numel() == N
+                d.bias = pr["bias"].data_ptr()
+            if pr.get("res1") is not None:
+                d.res1, d.ldr1 = pr["res1"].data_ptr(), _ld(pr["res1"])
+            d.act = pr.get("act", 0)
         prefix = (C.c_int32 * (n + 1))()
         check(lib.r3d_gemm_grouped_prepare(arr, n, tile, prefix), "r3d_gemm_grouped_prepare")
         dev = problems[0]["a"].device
