@@ -141,7 +141,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="enqueue every step from Python instead of replaying hipGraphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eval-dropout-off", action="store_true", help="bench the eval()-state step (dropout off)")
-    ap.add_argument("--no-side-stream", action="store_true", help="keep the query self-attention branch on the main stream")
+    ap.add_argument("--side-stream", action="store_true", help="run the query self-attention branch on a second HIP stream")
     ap.add_argument("--fused-decoder", action="store_true", help="run the decoder layer as decoder.hip (one workgroup per "
                                                                  "clip) instead of composed GEMM / attention / LN launches")
     ap.add_argument("--fused-adamw", action="store_true",
@@ -176,7 +176,7 @@ def main():
     if a.eval_dropout_off:
         model.eval()
     eng = model.engine()
-    eng.use_side_stream = not a.no_side_stream
+    eng.use_side_stream = a.side_stream
     eng.use_fused_decoder = a.fused_decoder
     from r3d_amd.parallel import DataParallelStep
     feats, depth, lab, dur, tgt = make_inputs(c, device, seed=1 + rank)
@@ -224,7 +224,7 @@ def main():
                 if a.eval_dropout_off:
                     model.eval()
                 eng = model.engine()
-                eng.use_side_stream = not a.no_side_stream
+                eng.use_side_stream = a.side_stream
                 dp = DataParallelStep(eng)
                 dp.broadcast_parameters()
                 tp = None

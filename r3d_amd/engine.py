@@ -176,7 +176,8 @@ class FusionEngine:
         self.side = torch.cuda.Stream(self.device)      # weight-gradient stream: off the backward's critical path
         self.side2 = torch.cuda.Stream(self.device)     # independent branch (self-attention of the queries)
         self.ws_side2 = ops.GemmWorkspace(self.device)
-        self.use_side_stream = True
+        self.use_side_stream = False            # parameter-only branches on a second HIP stream: the cross-queue joins cost
+                                                # more than the branches hide (352 vs 339 us/step at the bench shape)
         self.use_fused_decoder = False          # decoder.hip (one workgroup per clip and layer): measured 2 % slower than
                                                 # the composed launches at the bench shape since the GEMM epilogue rework
         self.use_fused_embed = True             # train mode: projections' slab sums + LN + exchange + norm1 in one launch
@@ -249,8 +250,11 @@ class FusionEngine:
             ops.dropout_mask(w.drop_pool, DROP_P, self.drop_seed, self.drop_offset)
         tp = self.tp if (self.tp is not None and need_grad) else None
         seam = self.use_fused_embed and mode == "train" and H <= 1024
+        # (running this GEMM on the side stream beside the 5x longer depth projection was measured: the cross-queue
+        #  join costs more than the 5 us it hides)
         dr = ops.gemm(GEMM_NT, x_rgb, a.p("input_embed.weight"), w.rgb, bias=a.p("input_embed.bias"), act=1,
                       ws=self.ws_side if seam else self.ws, defer_reduce=seam)
+        rgb_done = None
         slabs_r = self.ws_side.buf if (seam and dr.splitk > 1) else None
         d = None
         if tp is None:
@@ -262,7 +266,7 @@ class FusionEngine:
         # (a later, larger request would re-allocate the workspace) -- nothing may use self.ws before that launch
         slabs = self.ws.buf if (d is not None and d.splitk > 1) else None
         self._fw = dict(w=w, x_rgb=x_rgb, x_dep=x_dep, labels=labels, mode=mode, drop=drop, d=d, tp=tp, B=B, S=S,
-                        slabs=slabs, seam=seam, dr=dr, slabs_r=slabs_r)
+                        slabs=slabs, seam=seam, dr=dr, slabs_r=slabs_r, rgb_done=rgb_done)
 
     def forward_finish(self):
         """Everything after the input projections; see forward()."""
@@ -302,6 +306,8 @@ class FusionEngine:
 
         seam = fw["seam"]
         pre = "fuser.blocks.0."
+        if fw["rgb_done"] is not None:
+            main.wait_event(fw["rgb_done"])
         if seam:
             # ---- one launch: slab sums of both projections, bias/ReLU, depth LayerNorm + ReLU (:183,195-197), token
             # exchange + embd_drop (:56-62,83) and the fuser block's norm1 (transformerblock.py:122)
@@ -333,8 +339,8 @@ class FusionEngine:
         if fused_dec:
             multi = False                     # the whole layer is one launch: nothing left to branch
         # ---- branch s2: layer-0 query self-attention (depends on parameters only);  main: the embeddings
-        if multi:
-            s2.wait_stream(main)
+        if multi and fw["rgb_done"] is None:
+            s2.wait_stream(main)              # (otherwise forward_begin already forked this branch)
         if not fused_dec:
             with torch.cuda.stream(s2):
                 sa_block(0, w.tgt0, ws2)
@@ -544,6 +550,9 @@ class FusionEngine:
         add(w.d_u, w.h2, a.g(pre + "mlp.mlp.0.weight"), a.g(pre + "mlp.mlp.0.bias"))
         add(w.d_x1, w.vsw, a.g(pre + "attn.proj.weight"), a.g(pre + "attn.proj.bias"))
         add(w.d_v, w.h1, a.g(pre + "attn.qkv.weight")[2 * H:], None)          # rows [0,2H) (Q,K) stay exactly zero
+        # input_embed's weight gradient reads the step's RGB batch: operand B is re-pointed per step (GemmGroup.set_b)
+        w.rgb_wgrad_idx = len(P)
+        add(w.d_rgb_pre, self.last["x_rgb"], a.g("input_embed.weight"), a.g("input_embed.bias"))
         w.wgrad_group = ops.GemmGroup(GEMM_TN, P, tile=1 if H < 256 else 2)
         J = [(w.lnp["final"], BQ, H, a.g("transformer.decoder.norm.weight"), a.g("transformer.decoder.norm.bias")),
              (w.lnp["nf"], 2 * N, H, a.g("fuser.norm.weight"), a.g("fuser.norm.bias")),
@@ -562,6 +571,27 @@ class FusionEngine:
              (w.d_dep_pre, None, 1, a.g("depth_projection.bias").view(1, H)),
              (w.glayers[self.L - 1]["caqin"], w.glayers[self.L - 1]["sain"], Q, a.g("query_embed.weight"))]
         w.rowsum_group = ops.RowsumGroup(R)
+        # The LayerNorm partial sums are column sums as well: when a site's (weight, bias) gradients are adjacent in the
+        # arena (they are: same size class, declaration order) its finalize is one more job of the row-sum launch.
+
+        def as_rowsum(job):
+            part, rows, Hh, dg, db = job
+            if db.data_ptr() != dg.data_ptr() + 4 * Hh:
+                return None
+            if rows < 0:
+                blocks = -rows
+            else:
+                rpb = max(4, ((rows + 255) // 256 + 3) // 4 * 4)
+                blocks = (rows + rpb - 1) // rpb
+                if blocks <= 1:
+                    return None                 # layernorm_bwd wrote the final values itself
+            o = (dg.data_ptr() - a.grads.data_ptr()) // 4
+            return (part[:blocks * 2 * Hh].view(blocks, 2 * Hh), None, 1, a.grads[o:o + 2 * Hh].view(1, 2 * Hh))
+        w.tail_groups = {}
+        for name, jobs in (("plain", J), ("seam", Js)):
+            conv = [as_rowsum(j) for j in jobs]
+            if all(c is not None for c in conv):
+                w.tail_groups[name] = ops.RowsumGroup(R + conv)
 
     def backward_main(self, d_seg=None, d_actdur=None):
         """Everything of the backward except depth_projection.weight.
@@ -669,10 +699,14 @@ class FusionEngine:
         if not joined:
             main.wait_stream(s2)
         # ---- everything that only feeds parameter gradients: 2 launches + the broadcast-parameter sums
+        w.wgrad_group.set_b(w.rgb_wgrad_idx, st["x_rgb"])
         w.wgrad_group.launch()
-        (w.ln_group_seam if st["seam"] else w.ln_group).launch()
-        ops.gemm(GEMM_TN, w.d_rgb_pre, st["x_rgb"], a.g("input_embed.weight"), bias_grad=a.g("input_embed.bias"), ws=ws)
-        w.rowsum_group.launch()            # pos_embedding (:190), depth_projection.bias, query_embed (top layer)
+        tail = w.tail_groups.get("seam" if st["seam"] else "plain")
+        if tail is not None:               # pos_embedding (:190), depth_projection.bias, query_embed (top layer) and
+            tail.launch()                  # every LayerNorm parameter gradient: one launch
+        else:
+            (w.ln_group_seam if st["seam"] else w.ln_group).launch()
+            w.rowsum_group.launch()
         g_qe = a.g("query_embed.weight")
         for l in reversed(range(self.L - 1)):                       # stacked decoders: remaining layers accumulate
             gl = w.glayers[l]

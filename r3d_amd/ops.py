@@ -178,6 +178,19 @@ class GemmGroup:
         self.descs = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
         self.prefix = torch.tensor(list(prefix), dtype=torch.int32, device=dev)
         self.n, self.total, self.layout, self.tile = n, int(prefix[n]), layout, tile
+        self._b_ptr = [pr["b"].data_ptr() for pr in problems]
+
+    def set_b(self, i, b):
+        """Re-point operand B of problem i (same shape and leading dimension), e.g. at this step's input batch.  A no-op
+        while the pointer is unchanged (always, under hipGraph replay with static inputs); otherwise one 8-byte upload."""
+        p = b.data_ptr()
+        if p == self._b_ptr[i]:
+            return
+        assert _ld(b) == _ld(self._keep[i]["b"]) and b.shape == self._keep[i]["b"].shape
+        off = i * C.sizeof(GemmDesc) + GemmDesc.B.offset
+        self.descs[off:off + 8].copy_(torch.frombuffer(bytearray(C.c_uint64(p)), dtype=torch.uint8), non_blocking=False)
+        self._b_ptr[i] = p
+        self._keep[i] = dict(self._keep[i], b=b)
 
     def launch(self):
         check(_lib.load().r3d_gemm_grouped_launch(_p(self.descs), _p(self.prefix), self.n, self.total, self.layout, self.tile,
