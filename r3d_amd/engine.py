@@ -180,6 +180,7 @@ class FusionEngine:
                                                 # more than the branches hide (352 vs 339 us/step at the bench shape)
         self.use_fused_decoder = False          # decoder.hip (one workgroup per clip and layer): measured 2 % slower than
                                                 # the composed launches at the bench shape since the GEMM epilogue rework
+        self.use_paired_launches = True         # one-layer decoder: independent GEMMs of the two chains share launches
         self.use_fused_embed = True             # train mode: projections' slab sums + LN + exchange + norm1 in one launch
         self.shapes = {}
         self.train_mask = None            # cached train-mode selection (data independent)
@@ -338,10 +339,13 @@ class FusionEngine:
         fused_dec = self.use_fused_decoder and ops.decoder_fused_supported(S, Q, H, heads)
         if fused_dec:
             multi = False                     # the whole layer is one launch: nothing left to branch
-        # ---- branch s2: layer-0 query self-attention (depends on parameters only);  main: the embeddings
+        # One decoder layer on one stream: the query self-attention sub-layer depends on parameters only, the fuser block
+        # only on the embeddings -- their GEMMs are paired into shared launches (ops.GemmGroup) instead of queueing
+        # behind each other.  Otherwise: branch s2 (or inline) first, then the fuser chain.
+        paired = self.use_paired_launches and (not fused_dec) and (not multi) and self.L == 1
         if multi and fw["rgb_done"] is None:
             s2.wait_stream(main)              # (otherwise forward_begin already forked this branch)
-        if not fused_dec:
+        if not fused_dec and not paired:
             with torch.cuda.stream(s2):
                 sa_block(0, w.tgt0, ws2)
         # ---- token selection + exchange (:33-66)
@@ -362,18 +366,23 @@ class FusionEngine:
             ops.token_exchange_fwd(w.rgb, w.dep, mask[0], mask[1], w.x0, drop_mask=dm("x0"), drop_scale=dsc)
             ops.layernorm_fwd(w.x0, a.p(pre + "norm1.weight"), a.p(pre + "norm1.bias"), w.h1, w.m1, w.r1)
         wv = a.p(pre + "attn.qkv.weight")[2 * H:]
-        ops.gemm(GEMM_NT, w.h1, wv, w.vsw, c_row_xor=1, ws=self.ws)            # V of the OTHER modality token
-        ops.gemm(GEMM_NT, w.vsw, a.p(pre + "attn.proj.weight"), w.x1, bias=a.p(pre + "attn.proj.bias"), res1=w.x0,
-                 ws=self.ws)
-        ops.layernorm_fwd(w.x1, a.p(pre + "norm2.weight"), a.p(pre + "norm2.bias"), w.h2, w.m2, w.r2)
-        ops.gemm(GEMM_NT, w.h2, a.p(pre + "mlp.mlp.0.weight"), w.f1, bias=a.p(pre + "mlp.mlp.0.bias"), act=2,
-                 pre_out=w.u, ws=self.ws)
-        ops.gemm(GEMM_NT, w.f1, a.p(pre + "mlp.mlp.2.weight"), w.x3, bias=a.p(pre + "mlp.mlp.2.bias"), res1=w.x1,
-                 res2=w.x0, ws=self.ws)
-        ops.layernorm_fwd(w.x3, a.p("fuser.norm.weight"), a.p("fuser.norm.bias"), w.y, w.mf, w.rf, pair_out=w.fused)
+        if paired:
+            self._forward_paired(w, fw, dm, dsc, drop, wv, pre, qpos, pos)
+        else:
+            ops.gemm(GEMM_NT, w.h1, wv, w.vsw, c_row_xor=1, ws=self.ws)        # V of the OTHER modality token
+            ops.gemm(GEMM_NT, w.vsw, a.p(pre + "attn.proj.weight"), w.x1, bias=a.p(pre + "attn.proj.bias"), res1=w.x0,
+                     ws=self.ws)
+            ops.layernorm_fwd(w.x1, a.p(pre + "norm2.weight"), a.p(pre + "norm2.bias"), w.h2, w.m2, w.r2)
+            ops.gemm(GEMM_NT, w.h2, a.p(pre + "mlp.mlp.0.weight"), w.f1, bias=a.p(pre + "mlp.mlp.0.bias"), act=2,
+                     pre_out=w.u, ws=self.ws)
+            ops.gemm(GEMM_NT, w.f1, a.p(pre + "mlp.mlp.2.weight"), w.x3, bias=a.p(pre + "mlp.mlp.2.bias"), res1=w.x1,
+                     res2=w.x0, ws=self.ws)
+            ops.layernorm_fwd(w.x3, a.p("fuser.norm.weight"), a.p("fuser.norm.bias"), w.y, w.mf, w.rf, pair_out=w.fused)
         # ---- segmentation head (:228-232); with the composed decoder it shares a launch with the layer-0 key/value
         # projection (both read `fused`, neither depends on the other)
-        if not fused_dec:
+        if paired:
+            pass                              # (in _forward_paired, together with the cross-attention query projection)
+        elif not fused_dec:
             if not hasattr(w, "fwd_group"):
                 wi0 = a.p("transformer.decoder.layers.0.multihead_attn.in_proj_weight")
                 bi0 = a.p("transformer.decoder.layers.0.multihead_attn.in_proj_bias")
@@ -388,11 +397,49 @@ class FusionEngine:
         if fused_dec:
             self._decoder_fused(w, key_labels, drop, dsc)
         else:
-            self._decoder_unfused(w, key_labels, dm, dsc, multi, main, s2, sa_block)
-        self.last = dict(w=w, x_rgb=x_rgb, x_dep=x_dep, mask=mask, idx=idx, drop=drop, mode=mode, tp=tp, seam=seam)
+            self._decoder_unfused(w, key_labels, dm, dsc, multi, main, s2, sa_block, paired)
+        self.last = dict(w=w, x_rgb=x_rgb, x_dep=x_dep, mask=mask, idx=idx, drop=drop, mode=mode, tp=tp, seam=seam,
+                         paired=paired)
         return dict(seg=w.seg.view(B, S, K), action=w.actdur[:, :K].view(B, Q, K), duration=w.actdur[:, K].view(B, Q))
 
-    def _decoder_unfused(self, w, key_labels, dm, dsc, multi, main, s2, sa_block):
+    def _forward_paired(self, w, fw, dm, dsc, drop, wv, pre, qpos, pos):
+        """Fuser block (transformerblock.py:118-135, :86-94) interleaved with the layer-0 query self-attention sub-layer
+        (transformer.py:289-293,300): independent GEMMs share a launch."""
+        a, H, Q, S, B, BQ, heads, dh = self.arena, self.H, self.Q, w.S, w.B, w.BQ, self.heads, self.dh
+        c, pl = w.layers[0], "transformer.decoder.layers.0."
+        key = ("fwd_pairs", bool(drop))
+        if key not in w.tables:
+            wi, bi = a.p(pl + "multihead_attn.in_proj_weight"), a.p(pl + "multihead_attn.in_proj_bias")
+            t = 1 if H < 256 else 2
+            g1 = ops.GemmGroup(GEMM_NT, [
+                dict(a=w.h1, b=wv, c=w.vsw, c_row_xor=1),                              # V of the OTHER modality token
+                dict(a=w.tgt0, b=a.p(pl + "self_attn.in_proj_weight"), c=c["sa_qkv"], a_add=qpos, a_add_mod=Q,
+                     bias=a.p(pl + "self_attn.in_proj_bias"))], tile=t)
+            g2 = ops.GemmGroup(GEMM_NT, [
+                dict(a=w.h2, b=a.p(pre + "mlp.mlp.0.weight"), c=w.f1, bias=a.p(pre + "mlp.mlp.0.bias"), act=2, pre_out=w.u),
+                dict(a=c["sa_o"], b=a.p(pl + "self_attn.out_proj.weight"), c=c["t1_pre"],
+                     bias=a.p(pl + "self_attn.out_proj.bias"), drop_mask=self._dm2(dm("d1_0"), BQ, H), drop_scale=dsc)],
+                tile=t)                                                             # layer 0: tgt = 0, no residual (:209)
+            g3 = ops.GemmGroup(GEMM_NT, [
+                dict(a=w.fused, b=a.p("fc_seg.weight"), c=w.seg, bias=a.p("fc_seg.bias")),          # (:228-232)
+                dict(a=w.fused, b=wi[H:], c=c["cakv"], bias=bi[H:], a_add=pos, a_add_mod=S),      # k = v = memory + pos
+                dict(a=c["t1"], b=wi[:H], c=c["caq"], a_add=qpos, a_add_mod=Q, bias=bi[:H])], tile=t)
+            w.tables[key] = (g1, g2, g3)
+        g1, g2, g3 = w.tables[key]
+        g1.launch()
+        ops.gemm(GEMM_NT, w.vsw, a.p(pre + "attn.proj.weight"), w.x1, bias=a.p(pre + "attn.proj.bias"), res1=w.x0,
+                 ws=self.ws)
+        ops.mha_core_fwd(c["sa_qkv"][:, :H], c["sa_qkv"][:, H:2 * H], c["sa_qkv"][:, 2 * H:], c["p_sa"], c["sa_o"], B, heads,
+                         Q, Q, dh, drop_mask=dm("sa_p0"), drop_scale=dsc)
+        ops.layernorm_fwd(w.x1, a.p(pre + "norm2.weight"), a.p(pre + "norm2.bias"), w.h2, w.m2, w.r2)
+        g2.launch()
+        ops.gemm(GEMM_NT, w.f1, a.p(pre + "mlp.mlp.2.weight"), w.x3, bias=a.p(pre + "mlp.mlp.2.bias"), res1=w.x1,
+                 res2=w.x0, ws=self.ws)
+        ops.layernorm_fwd(c["t1_pre"], a.p(pl + "norm1.weight"), a.p(pl + "norm1.bias"), c["t1"], c["m1"], c["r1"])
+        ops.layernorm_fwd(w.x3, a.p("fuser.norm.weight"), a.p("fuser.norm.bias"), w.y, w.mf, w.rf, pair_out=w.fused)
+        g3.launch()
+
+    def _decoder_unfused(self, w, key_labels, dm, dsc, multi, main, s2, sa_block, paired=False):
         """The decoder composed from the GEMM / attention / LayerNorm entry points (any shape)."""
         a, H, Q, K, heads, dh = self.arena, self.H, self.Q, self.K, self.heads, self.dh
         B, S, N, BQ = w.B, w.S, w.N, w.BQ
@@ -409,6 +456,7 @@ class FusionEngine:
                     main.wait_stream(s2)
             else:
                 sa_block(l, tgt, self.ws)
+            # (paired: the layer-0 sub-layer ran inside _forward_paired)
             ops.mha_core_fwd(c["caq"], c["cakv"][:, :H], c["cakv"][:, H:], c["p_ca"], c["ca_o"], B, heads, Q, S, dh,
                              key_labels=key_labels, pad_idx=self.pad_idx, drop_mask=dm(f"ca_p{l}"), drop_scale=dsc)
             ops.gemm(GEMM_NT, c["ca_o"], a.p(pl + "multihead_attn.out_proj.weight"), c["t2_pre"],
@@ -653,6 +701,8 @@ class FusionEngine:
                              gl["cakv"][:, :H], gl["cakv"][:, H:], B, heads, Q, S, dh, drop_mask=dmf(f"ca_p{l}"),
                              drop_scale=dsc)
             wi = p("multihead_attn.in_proj_weight")
+            if st.get("paired"):
+                break                          # one layer, one stream: continued below with paired launches
             # ---- query path of the cross attention + the self-attention sub-layer (branch s2)
             if multi:
                 s2.wait_stream(main)
@@ -676,10 +726,37 @@ class FusionEngine:
                 dy, dy2 = gl["sain"], gl["t1pre"]
         # ---- fuser; d(memory) = decoder part (d_fused, kept for the positional-embedding gradient :190) + seg head part
         pre = "fuser.blocks.0."
-        ln_bwd("nf", w.d_fused, w.x3, w.mf, w.rf, "fuser.norm.weight", "fuser.norm.bias", w.d_x3, pair_in=True,
-               dy2=w.d_fused2)
-        ops.gemm(GEMM_NN, w.d_x3, a.p(pre + "mlp.mlp.2.weight"), w.d_u, aux=w.u, mul=2, ws=ws)
-        ops.gemm(GEMM_NN, w.d_u, a.p(pre + "mlp.mlp.0.weight"), w.d_h2, ws=ws)
+        if st.get("paired"):
+            # the query-side branch (cross-attention query projection, norm1, self-attention: parameter gradients only
+            # for a one-layer decoder) and the memory-side chain into the fuser are independent: their GEMMs share launches
+            c, gl, pl = w.layers[0], w.glayers[0], "transformer.decoder.layers.0."
+            key = ("bwd_pairs",)
+            if key not in w.tables:
+                wi0 = a.p(pl + "multihead_attn.in_proj_weight")
+                t = 1 if H < 256 else 2
+                w.tables[key] = (
+                    ops.GemmGroup(GEMM_NN, [dict(a=gl["caq"], b=wi0[:H], c=gl["caqin"]),
+                                            dict(a=gl["cakv"], b=wi0[H:], c=w.d_fused)], tile=t),
+                    ops.GemmGroup(GEMM_NN, [dict(a=gl["sap"], b=a.p(pl + "self_attn.out_proj.weight"), c=gl["sao"]),
+                                            dict(a=w.d_x3, b=a.p(pre + "mlp.mlp.2.weight"), c=w.d_u, aux=w.u, mul=2)], tile=t),
+                    ops.GemmGroup(GEMM_NN, [dict(a=gl["saqkv"], b=a.p(pl + "self_attn.in_proj_weight"), c=gl["sain"]),
+                                            dict(a=w.d_u, b=a.p(pre + "mlp.mlp.0.weight"), c=w.d_h2)], tile=t))
+            gb1, gb2, gb3 = w.tables[key]
+            gb1.launch()
+            ln_bwd("d1_0", gl["caqin"], c["t1_pre"], c["m1"], c["r1"], pl + "norm1.weight", pl + "norm1.bias", gl["t1pre"],
+                   dy2=gl["t2pre"], dx2=gl["sap"], drop_mask=dm("d1_0", BQ, H), drop_scale=dsc)
+            ln_bwd("nf", w.d_fused, w.x3, w.mf, w.rf, "fuser.norm.weight", "fuser.norm.bias", w.d_x3, pair_in=True,
+                   dy2=w.d_fused2)
+            gb2.launch()
+            ops.mha_core_bwd(c["sa_qkv"][:, :H], c["sa_qkv"][:, H:2 * H], c["sa_qkv"][:, 2 * H:], c["p_sa"], gl["sao"],
+                             gl["saqkv"][:, :H], gl["saqkv"][:, H:2 * H], gl["saqkv"][:, 2 * H:], B, heads, Q, Q, dh,
+                             drop_mask=dmf("sa_p0"), drop_scale=dsc)
+            gb3.launch()
+        else:
+            ln_bwd("nf", w.d_fused, w.x3, w.mf, w.rf, "fuser.norm.weight", "fuser.norm.bias", w.d_x3, pair_in=True,
+                   dy2=w.d_fused2)
+            ops.gemm(GEMM_NN, w.d_x3, a.p(pre + "mlp.mlp.2.weight"), w.d_u, aux=w.u, mul=2, ws=ws)
+            ops.gemm(GEMM_NN, w.d_u, a.p(pre + "mlp.mlp.0.weight"), w.d_h2, ws=ws)
         ln_bwd("n2", w.d_h2, w.x1, w.m2, w.r2, pre + "norm2.weight", pre + "norm2.bias", w.d_x1, add1=w.d_x3)
         ops.gemm(GEMM_NN, w.d_x1, a.p(pre + "attn.proj.weight"), w.d_v, c_row_xor=1, ws=ws)     # un-swap
         ops.gemm(GEMM_NN, w.d_v, a.p(pre + "attn.qkv.weight")[2 * H:], w.d_h1, ws=ws)

@@ -48,17 +48,11 @@ class GemmWorkspace:
         return self.buf
 
 
-def gemm(layout, a, b, c, *, bias=None, act=0, pre_out=None, a_add=None, a_add_mod=0, a_row_xor=0, b_add=None, b_add_mod=0,
-         drop_mask=None, drop_scale=1.0, aux=None, mul=0, res1=None, res2=None, alpha=1.0, accumulate=False,
-         c_row_xor=0, bias_grad=None, ws=None, tile=0, splitk=0, defer_reduce=False, adam=None):
-    """adam: dict(m, v, lr_t, step_t, beta1, beta2, eps, weight_decay, grad_scale) -> the product is a weight gradient
-    and C is the PARAMETER: AdamW is applied in the epilogue (C, m, v updated in place; the gradient is not stored).
-    C = epilogue(A op B), see r3d_gemm_desc.  Shapes: NT a[M,K] b[N,K]; NN a[M,K] b[K,N]; TN a[K,M] b[K,N].
-    Returns the (filled) descriptor; with defer_reduce=True and split-K the caller reduces the slabs itself
-    (e.g. through layernorm_fwd(nsplit=...))."""
-    lib = _lib.load()
+def _fill_desc(d, layout, a, b, c, *, bias=None, act=0, pre_out=None, a_add=None, a_add_mod=0, a_row_xor=0, b_add=None,
+               b_add_mod=0, drop_mask=None, drop_scale=1.0, aux=None, mul=0, res1=None, res2=None, alpha=1.0,
+               accumulate=False, c_row_xor=0, bias_grad=None):
+    """Fills the problem and epilogue fields of a GemmDesc (not tile / split).  Returns (M, N, K)."""
     _f32(a, "A"), _f32(b, "B"), _f32(c, "C")
-    d = GemmDesc()
     if layout == GEMM_NT:
         M, K = a.shape
         N = b.shape[0]
@@ -101,6 +95,18 @@ def gemm(layout, a, b, c, *, bias=None, act=0, pre_out=None, a_add=None, a_add_m
     if bias_grad is not None:
         assert layout == GEMM_TN and bias_grad.numel() == M
         d.bias_grad = bias_grad.data_ptr()
+    return M, N, K
+
+
+def gemm(layout, a, b, c, *, ws=None, tile=0, splitk=0, defer_reduce=False, adam=None, **epi):
+    """C = epilogue(A op B), see r3d_gemm_desc.  Shapes: NT a[M,K] b[N,K]; NN a[M,K] b[K,N]; TN a[K,M] b[K,N].
+    Epilogue keywords: see _fill_desc.  Returns the (filled) descriptor; with defer_reduce=True and split-K the caller
+    reduces the slabs itself (layernorm_fwd(nsplit=...), embed_fuse_fwd).
+    adam: dict(m, v, lr_t, step_t, beta1, beta2, eps, weight_decay, grad_scale) -> the product is a weight gradient
+    and C is the PARAMETER: AdamW is applied in the epilogue (C, m, v updated in place; the gradient is not stored)."""
+    lib = _lib.load()
+    d = GemmDesc()
+    M, N, K = _fill_desc(d, layout, a, b, c, **epi)
     check(lib.r3d_gemm_plan(C.byref(d)), "r3d_gemm_plan")
     if adam is not None:
         assert _ld(adam["m"]) == d.ldc and _ld(adam["v"]) == d.ldc and adam["m"].shape == c.shape
@@ -120,7 +126,7 @@ def gemm(layout, a, b, c, *, bias=None, act=0, pre_out=None, a_add=None, a_add_m
             d.splitk, d.k_per_split = (K + kps - 1) // kps, kps
             if d.splitk < 2:
                 d.splitk, d.k_per_split = 1, K
-    if bias_grad is not None and d.splitk > 1:          # the fused column sum needs the whole K range in one block
+    if epi.get("bias_grad") is not None and d.splitk > 1:   # the fused column sum needs the whole K range in one block
         d.splitk, d.k_per_split = 1, K
     if d.splitk > 1:
         assert ws is not None, "split-K needs a GemmWorkspace"
@@ -134,44 +140,18 @@ def gemm(layout, a, b, c, *, bias=None, act=0, pre_out=None, a_add=None, a_add_m
 
 class GemmGroup:
     """A set of independent GEMMs of one layout that run as ONE launch (r3d_gemm_grouped_*).  Built once per shape:
-    descriptors and the workgroup prefix table are uploaded to device memory; launch() replays them."""
+    descriptors and the workgroup prefix table are uploaded to device memory; launch() replays them.  The problems may
+    use every epilogue of gemm() (each is latency-bound: what a group saves is the ~5 us of a dependent launch)."""
 
     def __init__(self, layout, problems, tile=1):
-        """problems: list of dicts with the keyword arguments of gemm() (a, b, c required)."""
+        """problems: list of dicts with the keyword arguments of gemm() (a, b, c required; no split-K)."""
         lib = _lib.load()
         n = len(problems)
         arr = (GemmDesc * n)()
-        self._keep = problems
+        self._keep = list(problems)
         for i, pr in enumerate(problems):
-            a, b, c = pr["a"], pr["b"], pr["c"]
-            d = arr[i]
-            if layout == GEMM_NT:
-                M, K = a.shape
-                N = b.shape[0]
-            elif layout == GEMM_NN:
-                M, K = a.shape
-                N = b.shape[1]
-            else:
-                K, M = a.shape
-                N = b.shape[1]
-            assert tuple(c.shape) == (M, N)
-            d.A, d.B, d.C = a.data_ptr(), b.data_ptr(), c.data_ptr()
-            d.layout, d.M, d.N, d.K = layout, M, N, K
-            d.lda, d.ldb, d.ldc = _ld(a), _ld(b), _ld(c)
-            d.alpha = 1.0
-            if pr.get("bias_grad") is not None:
-                assert layout == GEMM_TN and pr["bias_grad"].numel() == M
-                d.bias_grad = pr["bias_grad"].data_ptr()
-            if pr.get("b_add") is not None:
-                d.b_add, d.b_add_mod, d.b_add_ld = pr["b_add"].data_ptr(), pr["b_add_mod"], _ld(pr["b_add"])
-            if pr.get("a_add") is not None:
-                d.a_add, d.a_add_mod, d.a_add_ld = pr["a_add"].data_ptr(), pr["a_add_mod"], _ld(pr["a_add"])
-            if pr.get("bias") is not None:
-                assert pr["bias"].numel() == N
-                d.bias = pr["bias"].data_ptr()
-            if pr.get("res1") is not None:
-                d.res1, d.ldr1 = pr["res1"].data_ptr(), _ld(pr["res1"])
-            d.act = pr.get("act", 0)
+            kw = {k: v for k, v in pr.items() if k not in ("a", "b", "c")}
+            _fill_desc(arr[i], layout, pr["a"], pr["b"], pr["c"], **kw)
         prefix = (C.c_int32 * (n + 1))()
         check(lib.r3d_gemm_grouped_prepare(arr, n, tile, prefix), "r3d_gemm_grouped_prepare")
         dev = problems[0]["a"].device
