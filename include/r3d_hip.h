@@ -139,6 +139,26 @@ int r3d_layernorm_bwd(const float* dy, int lddy, int pair_in, const float* dy2, 
 /* With defer_finalize != 0 the reduction of the per-block partial dgamma/dbeta left in ws is done later by this call
  * (so the host can take it off the critical path). */
 int r3d_layernorm_bwd_finalize(const float* ws, int rows, int H, float* dgamma, float* dbeta, void* stream);
+/* Up to 4 independent LayerNorm sites of the same width in ONE launch (what a step saves is the dependent launch, ~5 us).
+ * The job structs carry exactly the arguments of r3d_layernorm_fwd / r3d_layernorm_bwd (backward: ws must be given when
+ * the site needs it -- parameter reductions are always deferred to r3d_layernorm_bwd_finalize*; rows_per_block and
+ * nblocks are filled by the library).  Host arrays; copied into the kernel argument. */
+typedef struct r3d_ln_fwd_job {
+    const float* x; int32_t ldx, nsplit; const float* bias; float* pre_out;
+    const float* gamma; const float* beta; float* y; int32_t ldy; float* mean; float* rstd;
+    float* pair_out; int32_t rows, H, relu;
+} r3d_ln_fwd_job;
+typedef struct r3d_ln_bwd_job {
+    const float* dy; int32_t lddy, pair_in; const float* dy2; int32_t lddy2;
+    const float* x; int32_t ldx; const float* mean; const float* rstd; const float* gamma; const float* beta; int32_t relu;
+    const float* add1; int32_t ldadd1; const float* add2; int32_t ldadd2;
+    float* dx; int32_t lddx;
+    float* dx2; int32_t lddx2; const uint8_t* drop_mask; int32_t lddrop; float drop_scale;
+    float* dgamma; float* dbeta; float* ws;
+    int32_t rows, H, rows_per_block, nblocks;
+} r3d_ln_bwd_job;
+int r3d_layernorm_fwd_multi(const r3d_ln_fwd_job* jobs, int njobs, void* stream);
+int r3d_layernorm_bwd_multi(r3d_ln_bwd_job* jobs, int njobs, void* stream);
 /* The same for many LayerNorm sites in one launch; jobs live in device memory. */
 /* rows > 0: ws holds the partials r3d_layernorm_bwd left for that many rows; rows < 0: exactly -rows (dgamma, dbeta)
  * pairs [-rows][2][H] written by another producer (r3d_embed_fuse_bwd). */

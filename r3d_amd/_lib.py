@@ -37,6 +37,24 @@ class GemmDesc(C.Structure):
     ]
 
 
+class LnFwdJob(C.Structure):
+    """struct r3d_ln_fwd_job"""
+    _fields_ = [("x", C.c_void_p), ("ldx", C.c_int32), ("nsplit", C.c_int32), ("bias", C.c_void_p), ("pre_out", C.c_void_p),
+                ("gamma", C.c_void_p), ("beta", C.c_void_p), ("y", C.c_void_p), ("ldy", C.c_int32), ("mean", C.c_void_p),
+                ("rstd", C.c_void_p), ("pair_out", C.c_void_p), ("rows", C.c_int32), ("H", C.c_int32), ("relu", C.c_int32)]
+
+
+class LnBwdJob(C.Structure):
+    """struct r3d_ln_bwd_job"""
+    _fields_ = [("dy", C.c_void_p), ("lddy", C.c_int32), ("pair_in", C.c_int32), ("dy2", C.c_void_p), ("lddy2", C.c_int32),
+                ("x", C.c_void_p), ("ldx", C.c_int32), ("mean", C.c_void_p), ("rstd", C.c_void_p), ("gamma", C.c_void_p),
+                ("beta", C.c_void_p), ("relu", C.c_int32), ("add1", C.c_void_p), ("ldadd1", C.c_int32), ("add2", C.c_void_p),
+                ("ldadd2", C.c_int32), ("dx", C.c_void_p), ("lddx", C.c_int32), ("dx2", C.c_void_p), ("lddx2", C.c_int32),
+                ("drop_mask", C.c_void_p), ("lddrop", C.c_int32), ("drop_scale", C.c_float), ("dgamma", C.c_void_p),
+                ("dbeta", C.c_void_p), ("ws", C.c_void_p), ("rows", C.c_int32), ("H", C.c_int32),
+                ("rows_per_block", C.c_int32), ("nblocks", C.c_int32)]
+
+
 class RowsumJob(C.Structure):
     """struct r3d_rowsum_job"""
     _fields_ = [("src1", C.c_void_p), ("src2", C.c_void_p), ("dst", C.c_void_p), ("ld1", C.c_int32), ("ld2", C.c_int32),
@@ -61,6 +79,8 @@ _SIGNATURES = {
     "r3d_gemm_plan": ([C.POINTER(GemmDesc)], C.c_int),
     "r3d_gemm_grouped_prepare": ([C.POINTER(GemmDesc), _I, _I, C.POINTER(C.c_int32)], C.c_int),
     "r3d_gemm_grouped_launch": ([_P, _P, _I, _I, _I, _I, _P], C.c_int),
+    "r3d_layernorm_fwd_multi": ([_P, _I, _P], C.c_int),
+    "r3d_layernorm_bwd_multi": ([_P, _I, _P], C.c_int),
     "r3d_layernorm_bwd_finalize_batched": ([_P, _I, _I, _P], C.c_int),
     "r3d_layernorm_fwd": ([_P, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P], C.c_int),
     "r3d_layernorm_bwd_ws_floats": ([_I, _I], C.c_int64),

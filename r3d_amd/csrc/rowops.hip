@@ -9,11 +9,7 @@ namespace r3d {
 
 constexpr float kLnEps = 1e-5f;   // nn.LayerNorm default; SURVEY.md Appendix A.2
 
-struct LnFwdArgs {
-    const float* x; int ldx; int nsplit; const float* bias; float* pre_out;
-    const float* gamma; const float* beta; float* y; int ldy; float* mean; float* rstd;
-    float* pair_out; int rows; int H; int relu;
-};
+typedef r3d_ln_fwd_job LnFwdArgs;      // public struct (include/r3d_hip.h): the multi-job entry point takes arrays of it
 
 // Every load below is UNCONDITIONAL from a clamped column (a load under a lane-dependent branch makes hipcc wait
 // vmcnt(0) right behind it) and all loads of a workgroup's rows are issued before the first reduction: the kernels are
@@ -76,8 +72,21 @@ __device__ __forceinline__ void ln_fwd_finish(const LnFwdArgs& a, int row, int l
     }
 }
 
+struct LnFwdMulti { LnFwdArgs j[4]; };
+struct LnBwdMulti;
+
 template <int EPL>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs a) {
+__device__ __forceinline__ void ln_fwd_block(const LnFwdArgs& a);
+
+template <int EPL>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs a) { ln_fwd_block<EPL>(a); }
+
+// Independent LayerNorm sites of equal width in ONE launch (blockIdx.y = site): what is saved is the dependent launch.
+template <int EPL>
+__global__ __launch_bounds__(256) void ln_fwd_multi_kernel(const LnFwdMulti m) { ln_fwd_block<EPL>(m.j[blockIdx.y]); }
+
+template <int EPL>
+__device__ __forceinline__ void ln_fwd_block(const LnFwdArgs& a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int unit = blockIdx.x * 4 + wave;
     float gam[EPL], bet[EPL];
@@ -108,19 +117,27 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs a) {
     }
 }
 
-struct LnBwdArgs {
-    const float* dy; int lddy; int pair_in; const float* dy2; int lddy2;
-    const float* x; int ldx; const float* mean; const float* rstd; const float* gamma; const float* beta; int relu;
-    const float* add1; int ldadd1; const float* add2; int ldadd2;
-    float* dx; int lddx;
-    float* dx2; int lddx2; const uint8_t* drop_mask; int lddrop; float drop_scale;
-    float* dgamma; float* dbeta; float* ws;       // ws: [gridDim.x][2][H] when gridDim.x > 1
-    int rows; int H; int rows_per_block;
-};
+typedef r3d_ln_bwd_job LnBwdArgs;      // public struct; rows_per_block / nblocks are filled by the library
+struct LnBwdMulti { LnBwdArgs j[4]; };
+
+template <int EPL>
+__device__ __forceinline__ void ln_bwd_block(const LnBwdArgs& a, float* red);
 
 template <int EPL>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float red[];     // [4][2][H]
+    ln_bwd_block<EPL>(a, red);
+}
+
+template <int EPL>
+__global__ __launch_bounds__(256) void ln_bwd_multi_kernel(const LnBwdMulti m) {
+    extern __shared__ __attribute__((aligned(16))) float red[];     // [4][2][H]
+    ln_bwd_block<EPL>(m.j[blockIdx.y], red);
+}
+
+template <int EPL>
+__device__ __forceinline__ void ln_bwd_block(const LnBwdArgs& a, float* red) {
+    if ((int)blockIdx.x >= a.nblocks) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r_begin = blockIdx.x * a.rows_per_block;
     const int r_end = min(a.rows, r_begin + a.rows_per_block);
@@ -193,7 +210,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
         const int which = c / a.H, col = c % a.H;
         const float s = red[(0 * 2 + which) * a.H + col] + red[(1 * 2 + which) * a.H + col] +
                         red[(2 * 2 + which) * a.H + col] + red[(3 * 2 + which) * a.H + col];
-        if (gridDim.x == 1) (which == 0 ? a.dgamma : a.dbeta)[col] = s;
+        if (a.nblocks == 1) (which == 0 ? a.dgamma : a.dbeta)[col] = s;
         else a.ws[((size_t)blockIdx.x * 2 + which) * a.H + col] = s;
     }
 }
@@ -412,7 +429,7 @@ R3D_EXPORT int r3d_layernorm_bwd(const float* dy, int lddy, int pair_in, const f
     const int blocks = r3d_cdiv(rows, rpb);
     R3D_REQUIRE(blocks == 1 || !dgamma || ws);
     LnBwdArgs a{dy, lddy, pair_in, dy2, lddy2, x, ldx, mean, rstd, gamma, beta, relu, add1, ldadd1, add2, ldadd2, dx, lddx,
-                dx2, lddx2, drop_mask, lddrop, drop_scale, dgamma, dbeta, ws, rows, H, rpb};
+                dx2, lddx2, drop_mask, lddrop, drop_scale, dgamma, dbeta, ws, rows, H, rpb, blocks};
     hipStream_t s = (hipStream_t)stream;
     const size_t shmem = (size_t)8 * H * sizeof(float);
     int rc = launch_epl(ln_bwd_kernel<32>, ln_bwd_kernel<16>, ln_bwd_kernel<8>, ln_bwd_kernel<2>, H, dim3(blocks),
@@ -424,6 +441,46 @@ R3D_EXPORT int r3d_layernorm_bwd(const float* dy, int lddy, int pair_in, const f
         R3D_LAUNCH_CHECK();
     }
     return R3D_OK;
+}
+
+R3D_EXPORT int r3d_layernorm_fwd_multi(const r3d_ln_fwd_job* jobs, int njobs, void* stream) {
+    R3D_REQUIRE(jobs && njobs >= 1 && njobs <= 4);
+    LnFwdMulti m{};
+    int units = 0, H = jobs[0].H;
+    for (int i = 0; i < njobs; ++i) {
+        const r3d_ln_fwd_job& a = jobs[i];
+        R3D_REQUIRE(a.x && a.gamma && a.beta && a.y && a.mean && a.rstd);
+        R3D_REQUIRE(a.rows > 0 && a.H == H && H > 0 && H <= 2048 && a.ldy >= H && a.nsplit >= 0);
+        R3D_REQUIRE(a.nsplit > 0 || a.ldx >= H);
+        R3D_REQUIRE(!a.pair_out || (a.rows % 2) == 0);
+        const int u = a.pair_out ? a.rows / 2 : a.rows;
+        units = u > units ? u : units;
+        m.j[i] = a;
+    }
+    return launch_epl(ln_fwd_multi_kernel<32>, ln_fwd_multi_kernel<16>, ln_fwd_multi_kernel<8>, ln_fwd_multi_kernel<2>, H,
+                      dim3(r3d_cdiv(units, 4), njobs), 0, (hipStream_t)stream, m);
+}
+
+R3D_EXPORT int r3d_layernorm_bwd_multi(r3d_ln_bwd_job* jobs, int njobs, void* stream) {
+    R3D_REQUIRE(jobs && njobs >= 1 && njobs <= 4);
+    LnBwdMulti m{};
+    int maxb = 0;
+    const int H = jobs[0].H;
+    for (int i = 0; i < njobs; ++i) {
+        r3d_ln_bwd_job& a = jobs[i];
+        R3D_REQUIRE(a.dy && a.x && a.mean && a.rstd && a.gamma && a.beta && a.dx);
+        R3D_REQUIRE(a.rows > 0 && a.H == H && H > 0 && H <= 2048 && a.ldx >= H && a.lddx >= H && a.lddy >= H);
+        R3D_REQUIRE((a.dgamma == nullptr) == (a.dbeta == nullptr));
+        R3D_REQUIRE(!a.pair_in || (a.rows % 2) == 0);
+        R3D_REQUIRE(!a.dy2 || a.lddy2 >= H);
+        a.rows_per_block = ln_bwd_rows_per_block(a.rows);
+        a.nblocks = r3d_cdiv(a.rows, a.rows_per_block);
+        R3D_REQUIRE(a.nblocks == 1 || !a.dgamma || a.ws);
+        maxb = a.nblocks > maxb ? a.nblocks : maxb;
+        m.j[i] = a;
+    }
+    return launch_epl(ln_bwd_multi_kernel<32>, ln_bwd_multi_kernel<16>, ln_bwd_multi_kernel<8>, ln_bwd_multi_kernel<2>, H,
+                      dim3(maxb, njobs), (size_t)8 * H * sizeof(float), (hipStream_t)stream, m);
 }
 
 static int colsum_chunks(int rows) { int c = r3d_cdiv(rows, 64); return c < 1 ? 1 : (c > 32 ? 32 : c); }

@@ -435,8 +435,11 @@ class FusionEngine:
         g2.launch()
         ops.gemm(GEMM_NT, w.f1, a.p(pre + "mlp.mlp.2.weight"), w.x3, bias=a.p(pre + "mlp.mlp.2.bias"), res1=w.x1,
                  res2=w.x0, ws=self.ws)
-        ops.layernorm_fwd(c["t1_pre"], a.p(pl + "norm1.weight"), a.p(pl + "norm1.bias"), c["t1"], c["m1"], c["r1"])
-        ops.layernorm_fwd(w.x3, a.p("fuser.norm.weight"), a.p("fuser.norm.bias"), w.y, w.mf, w.rf, pair_out=w.fused)
+        ops.layernorm_fwd_multi([                      # decoder norm1 and the fuser's final norm + token mean: one launch
+            dict(x=c["t1_pre"], gamma=a.p(pl + "norm1.weight"), beta=a.p(pl + "norm1.bias"), y=c["t1"], mean=c["m1"],
+                 rstd=c["r1"]),
+            dict(x=w.x3, gamma=a.p("fuser.norm.weight"), beta=a.p("fuser.norm.bias"), y=w.y, mean=w.mf, rstd=w.rf,
+                 pair_out=w.fused)])
         g3.launch()
 
     def _decoder_unfused(self, w, key_labels, dm, dsc, multi, main, s2, sa_block, paired=False):
@@ -743,10 +746,14 @@ class FusionEngine:
                                             dict(a=w.d_u, b=a.p(pre + "mlp.mlp.0.weight"), c=w.d_h2)], tile=t))
             gb1, gb2, gb3 = w.tables[key]
             gb1.launch()
-            ln_bwd("d1_0", gl["caqin"], c["t1_pre"], c["m1"], c["r1"], pl + "norm1.weight", pl + "norm1.bias", gl["t1pre"],
-                   dy2=gl["t2pre"], dx2=gl["sap"], drop_mask=dm("d1_0", BQ, H), drop_scale=dsc)
-            ln_bwd("nf", w.d_fused, w.x3, w.mf, w.rf, "fuser.norm.weight", "fuser.norm.bias", w.d_x3, pair_in=True,
-                   dy2=w.d_fused2)
+            def lnj(site, dy, x, mean, rstd, gname, bname, dx, **kw):
+                return dict(dy=dy, x=x, mean=mean, rstd=rstd, gamma=a.p(gname), beta=a.p(bname), dx=dx, dgamma=a.g(gname),
+                            dbeta=a.g(bname), partial=w.lnp[site], **kw)
+            ops.layernorm_bwd_multi([                  # decoder norm1 and the fuser's final norm: one launch
+                lnj("d1_0", gl["caqin"], c["t1_pre"], c["m1"], c["r1"], pl + "norm1.weight", pl + "norm1.bias", gl["t1pre"],
+                    dy2=gl["t2pre"], dx2=gl["sap"], drop_mask=dm("d1_0", BQ, H), drop_scale=dsc),
+                lnj("nf", w.d_fused, w.x3, w.mf, w.rf, "fuser.norm.weight", "fuser.norm.bias", w.d_x3, pair_in=True,
+                    dy2=w.d_fused2)])
             gb2.launch()
             ops.mha_core_bwd(c["sa_qkv"][:, :H], c["sa_qkv"][:, H:2 * H], c["sa_qkv"][:, 2 * H:], c["p_sa"], gl["sao"],
                              gl["saqkv"][:, :H], gl["saqkv"][:, H:2 * H], gl["saqkv"][:, 2 * H:], B, heads, Q, Q, dh,

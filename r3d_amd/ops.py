@@ -12,6 +12,10 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _pv(t):
+    return None if t is None else t.data_ptr()
+
+
 def _p(t):
     if t is None:
         return None
@@ -259,6 +263,46 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, beta, dx, dgamma, dbeta, *, pair_in=
                                 _ld(dx2) if dx2 is not None else 0, _p(drop_mask),
                                 _ld(drop_mask) if drop_mask is not None else 0, drop_scale, _p(dgamma), _p(dbeta),
                                 _p(wsb), rows, H, 1 if partial is not None else 0, _stream()), "r3d_layernorm_bwd")
+
+
+def layernorm_fwd_multi(jobs):
+    """jobs: up to 4 dicts (x, gamma, beta, y, mean, rstd[, relu, pair_out]) of independent sites, equal width."""
+    from ._lib import LnFwdJob
+    arr = (LnFwdJob * len(jobs))()
+    for i, j in enumerate(jobs):
+        rows, H = j["x"].shape
+        a = arr[i]
+        a.x, a.ldx, a.nsplit = j["x"].data_ptr(), _ld(j["x"]), 0
+        a.gamma, a.beta, a.y, a.ldy = j["gamma"].data_ptr(), j["beta"].data_ptr(), j["y"].data_ptr(), _ld(j["y"])
+        a.mean, a.rstd = j["mean"].data_ptr(), j["rstd"].data_ptr()
+        a.pair_out = j["pair_out"].data_ptr() if j.get("pair_out") is not None else None
+        a.rows, a.H, a.relu = rows, H, 1 if j.get("relu") else 0
+    check(_lib.load().r3d_layernorm_fwd_multi(arr, len(jobs), _stream()), "r3d_layernorm_fwd_multi")
+
+
+def layernorm_bwd_multi(jobs):
+    """jobs: up to 4 dicts with the arguments of layernorm_bwd (dy, x, mean, rstd, gamma, beta, dx, dgamma, dbeta,
+    partial required; pair_in, relu, dy2, add1, add2, dx2, drop_mask, drop_scale optional)."""
+    from ._lib import LnBwdJob
+    arr = (LnBwdJob * len(jobs))()
+    for i, j in enumerate(jobs):
+        rows, H = j["x"].shape
+        a = arr[i]
+        g = lambda k: j.get(k)                    # noqa: E731
+        a.dy, a.lddy, a.pair_in = j["dy"].data_ptr(), _ld(j["dy"]), 1 if g("pair_in") else 0
+        a.dy2, a.lddy2 = _pv(g("dy2")), _ld(g("dy2")) if g("dy2") is not None else 0
+        a.x, a.ldx, a.mean, a.rstd = j["x"].data_ptr(), _ld(j["x"]), j["mean"].data_ptr(), j["rstd"].data_ptr()
+        a.gamma, a.beta, a.relu = j["gamma"].data_ptr(), j["beta"].data_ptr(), 1 if g("relu") else 0
+        a.add1, a.ldadd1 = _pv(g("add1")), _ld(g("add1")) if g("add1") is not None else 0
+        a.add2, a.ldadd2 = _pv(g("add2")), _ld(g("add2")) if g("add2") is not None else 0
+        a.dx, a.lddx = j["dx"].data_ptr(), _ld(j["dx"])
+        a.dx2, a.lddx2 = _pv(g("dx2")), _ld(g("dx2")) if g("dx2") is not None else 0
+        a.drop_mask, a.lddrop = _pv(g("drop_mask")), _ld(g("drop_mask")) if g("drop_mask") is not None else 0
+        a.drop_scale = g("drop_scale") or 1.0
+        a.dgamma, a.dbeta, a.ws = j["dgamma"].data_ptr(), j["dbeta"].data_ptr(), j["partial"].data_ptr()
+        a.rows, a.H = rows, H
+        assert j["partial"].numel() >= _lib.load().r3d_layernorm_bwd_ws_floats(rows, H)
+    check(_lib.load().r3d_layernorm_bwd_multi(arr, len(jobs), _stream()), "r3d_layernorm_bwd_multi")
 
 
 def layernorm_bwd_finalize(partial, rows, H, dgamma, dbeta):
