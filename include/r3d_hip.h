@@ -83,7 +83,9 @@ typedef struct r3d_gemm_desc {
     int32_t c_row_xor;       /* output (and pre_out/aux/res/drop operand) row index = m ^ c_row_xor: pair swap at store */
     int32_t splitk, k_per_split; float* partial;
     int32_t tile;            /* 0 = auto; workgroup tile: 1 = 32x32 (4 k-split waves), 2 = 64x64, 3 = 128x128,
-                                4 = 64x64 with 2 k-split wave groups, 5 = 128x128 with 2 k-split wave groups */
+                                4 = 64x64 with 2 k-split wave groups, 5 = 128x128 with 2 k-split wave groups,
+                                6 = persistent 64-column panels with A^T resident in registers (TN, K <= 128, M <= 128,
+                                    plain epilogue: the weight gradient of a wide layer from few rows) */
     int32_t vec;             /* filled by the library: operands allow 16-byte loads */
     /* AdamW in the epilogue (adam_m != NULL; weight-gradient GEMMs with splitk == 1, tile 2 or 3, N % 4 == 0, 16-byte
      * aligned C / moments, no other epilogue operand): the

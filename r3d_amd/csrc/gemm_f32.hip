@@ -602,9 +602,128 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const r3d_gemm_desc 
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Weight gradient of a WIDE layer from FEW rows: C[M, N] = A^T . B with A [K, M], B [K, N], K <= 128 rows (tokens),
+// M <= 128 (hidden), N huge (depth_projection: 50176 pixels).  The tiled kernel gives each 64x64 output tile its own
+// workgroup, whose whole life is two k-steps: prologue latency, not MFMA, sets its time (33 us, 32 % of peak).  Here a
+// workgroup is PERSISTENT over 64-column panels of B:
+//   * A^T (all of dY, 64 KB) is read once per workgroup; every wave keeps its 32-row slice of A for all K in REGISTERS
+//     (64 VGPRs) -- the MFMA A-operand never touches LDS again;
+//   * B panels [K][64] stream through a double-buffered LDS image (k-major, 32-lane-contiguous ds_read_b32), the loads
+//     of panel p+1 are issued before the MFMAs of panel p;
+//   * 8 waves = 4 (M) x 2 (N) wave tiles of 32x32: one panel is 64 MFMAs per wave = the CU's MFMA pipes for ~4 us;
+//     784 panels = 196 workgroups x 4 panels, perfectly balanced (measured 26 us = 63 TFLOP/s; the 60 idle CUs and
+//     the 3 us prologue are what is left).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kPanelN = 64;
+
+__global__ __launch_bounds__(512, 1) void wgrad_panel_kernel(const r3d_gemm_desc d, const int npanels,
+                                                             const int panels_per_wg) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int SB = kPanelN + 4;                       // [K][68]: a row of 64 floats + pad
+    const int K = d.K, M = d.M, N = d.N;
+    float* Bs0 = lds;
+    float* Bs1 = lds + 128 * SB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;               // 4 x 2 wave tiles of 32 x 32
+    const int m_row = wm * 32 + l31;
+    const bool m_ok = m_row < M;
+    // ---- this wave's A fragments for every k: areg[s] = A[k = 2 s + lhi][m_row]  (coalesced 128-byte row segments)
+    float areg[64];
+#pragma unroll
+    for (int s = 0; s < 64; ++s) {
+        const int k = 2 * s + lhi;
+        areg[s] = (k < K && m_ok) ? d.A[(size_t)k * d.lda + m_row] : 0.f;
+    }
+    const int p_begin = blockIdx.x * panels_per_wg;
+    const int p_end = min(npanels, p_begin + panels_per_wg);
+    // B panel loader: 128 rows x 16 float4 = 2048 float4 / 512 threads = 4 each
+    float4 breg[4];
+    auto load_panel = [&](int p) {
+        const int n0 = p * kPanelN;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int f = tid + 512 * t, k = f >> 4, c4 = f & 15;
+            const int kc = k < K ? k : K - 1;
+            const int nc = n0 + 4 * c4 < N ? n0 + 4 * c4 : 0;    // N % 4 == 0 (validated): a float4 is all-in or all-out
+            breg[t] = *reinterpret_cast<const float4*>(d.B + (size_t)kc * d.ldb + nc);
+        }
+    };
+    auto store_panel = [&](float* bs) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int f = tid + 512 * t, k = f >> 4, c4 = f & 15;
+            *reinterpret_cast<float4*>(bs + k * SB + 4 * c4) = (k < K) ? breg[t] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    if (p_begin >= p_end) return;
+    load_panel(p_begin);
+    store_panel(Bs0);
+    __syncthreads();
+    // The 16 stores of a finished panel are issued after the MFMAs of the NEXT one (fire-and-forget: nothing waits for
+    // them before the kernel ends).
+    f32x16 prev;
+    int prev_n = -1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) prev[r] = 0.f;
+    for (int p = p_begin; p < p_end; ++p) {
+        float* bs = ((p - p_begin) & 1) ? Bs1 : Bs0;
+        float* bo = ((p - p_begin) & 1) ? Bs0 : Bs1;
+        const bool more = p + 1 < p_end;
+        if (more) load_panel(p + 1);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float* bcol = bs + wn * 32 + l31;
+        const bool st = prev_n >= 0 && prev_n < N;
+        // 64 MFMAs on one accumulator, B operands from LDS.  Left alone, hipcc issues every ds_read right in front of its
+        // MFMA and waits lgkmcnt(0) (seen in the ISA), so the schedule is pinned: 16 operands in flight first, then
+        // 8 MFMAs / 8 more operands alternately.
+#pragma unroll
+        for (int s = 0; s < 64; ++s) {
+            const float b = bcol[(2 * s + lhi) * SB];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[s], b, acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);          // 8 x ds_read2_b32 = 16 operands ahead
+#pragma unroll
+        for (int g = 0; g < 6; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);      // 8 MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);      // 4 x ds_read2_b32 = 8 operands
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+        if (more) store_panel(bo);           // before the C stores: on this ISA stores count in vmcnt like the B loads
+        if (st) {
+            // C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                if (m < M) d.C[(size_t)m * d.ldc + prev_n] = d.alpha * prev[r];
+            }
+        }
+        prev = acc;
+        prev_n = p * kPanelN + wn * 32 + l31;
+        __syncthreads();
+    }
+    if (prev_n >= 0 && prev_n < N) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            if (m < M) d.C[(size_t)m * d.ldc + prev_n] = d.alpha * prev[r];
+        }
+    }
+}
+
+static bool wgrad_panel_ok(const r3d_gemm_desc& d) {
+    if (d.layout != R3D_GEMM_TN || d.K > 128 || d.M > 128 || d.N < 2048 || (d.N & 3) || (d.ldb & 3)) return false;
+    if (d.splitk > 1 || d.b_add || d.bias || d.pre_out || d.act || d.drop_mask || d.mul || d.res1 || d.res2) return false;
+    if (d.accumulate || d.bias_grad || d.c_row_xor || d.adam_m) return false;
+    return r3d_aligned16(d.B);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------
-static const int kTileSz[6] = {0, 32, 64, 128, 64, 128};
+static const int kTileSz[7] = {0, 32, 64, 128, 64, 128, 64};
 
 template <int LA, int LB, int BM, int BN, int BK, int WM, int WN, int WK>
 static int launch_cfg(const r3d_gemm_desc& d, int nsplit, hipStream_t s) {
@@ -667,7 +786,7 @@ static int gemm_validate(const r3d_gemm_desc* d) {
     if (!d || !d->A || !d->B || !d->C) return R3D_EINVAL;
     if (d->M <= 0 || d->N <= 0 || d->K <= 0) return R3D_EINVAL;
     if (d->layout < 0 || d->layout > 2) return R3D_EINVAL;
-    if (d->tile < 1 || d->tile > 5) return R3D_EINVAL;
+    if (d->tile < 1 || d->tile > 6) return R3D_EINVAL;
     const int a_min = (d->layout == R3D_GEMM_TN) ? d->M : d->K;
     const int b_min = (d->layout == R3D_GEMM_NT) ? d->K : d->N;
     if (d->lda < a_min || d->ldb < b_min || d->ldc < d->N) return R3D_EINVAL;
@@ -742,6 +861,11 @@ R3D_EXPORT int r3d_gemm_plan(r3d_gemm_desc* d) {
     d->tile = bt;
     d->splitk = bs;
     d->k_per_split = (bs > 1) ? bk : d->K;
+    {                                    // few-row weight gradient of a wide layer: the persistent panel kernel
+        r3d_gemm_desc t = *d;
+        t.splitk = 1;
+        if (wgrad_panel_ok(t)) { d->tile = 6; d->splitk = 1; d->k_per_split = d->K; }
+    }
     return R3D_OK;
 }
 
@@ -752,6 +876,22 @@ R3D_EXPORT int r3d_gemm_f32(const r3d_gemm_desc* dp, void* stream) {
     d.vec = gemm_can_vec(d) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     const int ns = nsplits_of(d);
+    if (d.tile == 6) {                   // persistent panel kernel (few-row weight gradient of a wide layer)
+        if (!wgrad_panel_ok(d)) return R3D_EINVAL;
+        const int npanels = r3d_cdiv(d.N, kPanelN);
+        const int per = r3d_cdiv(npanels, 256);                 // panels per workgroup: balanced over <= 256 workgroups
+        const int wgs = r3d_cdiv(npanels, per);
+        const size_t lds = (size_t)2 * 128 * (kPanelN + 4) * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute((const void*)wgrad_panel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(wgrad_panel_kernel, dim3(wgs), dim3(512), lds, s, d, npanels, per);
+        R3D_LAUNCH_CHECK();
+        return R3D_OK;
+    }
     switch (d.layout) {
         case R3D_GEMM_NT: return launch_layout<0, 0>(d, ns, s);
         case R3D_GEMM_NN: return launch_layout<0, 1>(d, ns, s);

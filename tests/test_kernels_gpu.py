@@ -80,6 +80,25 @@ def test_gemm_splitk_and_auto_plan(ops, layout):
         assert_close(Cd.cpu(), _gemm_ref(layout, Av, Bv), 2e-4, 2e-4 * math.sqrt(K), f"splitk7 L{layout} {M,N,K}")
 
 
+@pytest.mark.parametrize("K,M,N", [(128, 128, 50176), (96, 64, 4100), (128, 128, 2048), (56, 96, 8192)])
+def test_gemm_persistent_panel_weight_gradient(ops, K, M, N):
+    """tile 6: the few-row weight gradient of a wide layer (A^T in registers, B streamed in 64-column panels); the
+    planner picks it for depth_projection.weight's gradient.  Ragged K, M and a last partial panel included."""
+    A, B = rnd(K, M, seed=K + M), rnd(K, N, seed=N)
+    Cd = torch.full((M, N), float("nan"), device="cuda")
+    d = ops.gemm(2, dev(A), dev(B), Cd)
+    torch.cuda.synchronize()
+    assert d.tile == 6 and d.splitk == 1
+    assert_close(Cd.cpu(), A.double().t() @ B.double(), 1e-4, 1e-4 * math.sqrt(K), f"panel wgrad {K, M, N}")
+    # strided operands (views of wider matrices) and alpha
+    Aw, Bw, Cw = dev(rnd(K, M + 8, seed=1)), dev(rnd(K, N + 12, seed=2)), torch.zeros(M, N + 4, device="cuda")
+    ops.gemm(2, Aw[:, :M], Bw[:, :N], Cw[:, :N], alpha=0.5, tile=6)
+    torch.cuda.synchronize()
+    assert_close(Cw[:, :N].cpu(), 0.5 * (Aw[:, :M].cpu().double().t() @ Bw[:, :N].cpu().double()), 1e-4, 1e-4 * math.sqrt(K),
+                 "panel wgrad strided")
+    assert float(Cw[:, N:].abs().max()) == 0.0
+
+
 def test_gemm_epilogue_and_prologue(ops):
     ws = ops.GemmWorkspace("cuda")
     M, N, K = 96, 72, 64
