@@ -250,6 +250,20 @@ int r3d_embed_fuse_bwd(const float* d_h1, const float* x0, const float* m1, cons
                        const float* mean_d, const float* rstd_d, const float* lnd_gamma, const float* lnd_beta,
                        float* d_rgb_pre, float* d_dep_pre, float* ws_n1, float* ws_dep, int N, int H, void* stream);
 
+/* ---- the decoder's tail, one launch per direction (row-local on the B*Q query rows) ------------------------------
+ * forward : last layer's norm3 (transformer.py:329) -> decoder.norm (:182-183) -> heads fc | fc_len as one [n_head, H]
+ *           product (futr_safuser_tokenfusion.py:219-226).  x = pre-norm3 rows [rows, H] contiguous.
+ * backward: heads' input gradient -> decoder.norm backward -> norm3 backward; dx = gradient w.r.t. x, dx2 = dx * dropout3
+ *           mask (:328).  LayerNorm parameter gradients: partials wsF / ws3 in r3d_layernorm_bwd's layout for `rows` rows,
+ *           or final values in dgF/dbF/dg3/db3 when one block covers all rows (rows <= 4). */
+int r3d_decoder_tail_fwd(const float* x, const float* g3, const float* b3, const float* gF, const float* bF,
+                         const float* w_head, const float* b_head, int n_head, float* t3, float* m3, float* r3, float* tgtF,
+                         float* mF, float* rF, float* out, int ld_out, int rows, int H, void* stream);
+int r3d_decoder_tail_bwd(const float* d_out, int ld_dout, const float* w_head, int n_head, const float* t3, const float* mF,
+                         const float* rF, const float* gF, const float* x, const float* m3, const float* r3, const float* g3,
+                         const uint8_t* drop_mask, float drop_scale, float* dx, float* dx2, float* dgF, float* dbF,
+                         float* dg3, float* db3, float* wsF, float* ws3, int rows, int H, void* stream);
+
 /* ---- losses: utils.py:325-328,358-378,410-490 as composed at train/train_proposed_depth.py:171-213 ------------- */
 int r3d_losses_fwd_bwd(const float* seg_logits, int ld_seg, const float* act_logits, int ld_act, const float* dur,
                        int ld_dur, const int64_t* past_label, const int64_t* target, const float* target_dur, int B, int S,

@@ -106,6 +106,9 @@ _SIGNATURES = {
                             _P], C.c_int),
     "r3d_embed_fuse_bwd": ([_P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
                            C.c_int),
+    "r3d_decoder_tail_fwd": ([_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P], C.c_int),
+    "r3d_decoder_tail_bwd": ([_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I,
+                              _P], C.c_int),
     "r3d_losses_fwd_bwd": ([_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _F, _P, _I, _P, _I,
                             _P, _I, _P, _P, _P, _P, _P, _P], C.c_int),
     "r3d_losses_ws_floats": ([_I, _I, _I], C.c_int64),

@@ -180,6 +180,7 @@ class FusionEngine:
                                                 # more than the branches hide (352 vs 339 us/step at the bench shape)
         self.use_fused_decoder = False          # decoder.hip (one workgroup per clip and layer): measured 2 % slower than
                                                 # the composed launches at the bench shape since the GEMM epilogue rework
+        self.use_fused_tail = True              # last norm3 + decoder.norm + heads (and their adjoints): one launch each
         self.use_paired_launches = True         # one-layer decoder: independent GEMMs of the two chains share launches
         self.use_fused_embed = True             # train mode: projections' slab sums + LN + exchange + norm1 in one launch
         self.shapes = {}
@@ -470,6 +471,12 @@ class FusionEngine:
                      drop_mask=self._dm2(dm(f"ff_{l}"), BQ, 4 * H), drop_scale=dsc, ws=self.ws)
             ops.gemm(GEMM_NT, c["ff1"], a.p(pl + "linear2.weight"), c["t3_pre"], bias=a.p(pl + "linear2.bias"),
                      drop_mask=self._dm2(dm(f"d3_{l}"), BQ, H), drop_scale=dsc, res1=c["t2"], ws=self.ws)
+            if l == self.L - 1 and self.use_fused_tail:
+                # last norm3 + decoder.norm (:182-183) + anticipation heads (:219-226, fc | fc_len = one [K+1, H] product)
+                ops.decoder_tail_fwd(c["t3_pre"], a.p(pl + "norm3.weight"), a.p(pl + "norm3.bias"),
+                                     a.p("transformer.decoder.norm.weight"), a.p("transformer.decoder.norm.bias"),
+                                     self.w_head, self.b_head, c["t3"], c["m3"], c["r3"], w.tgtF, w.mF, w.rF, w.actdur)
+                return
             ops.layernorm_fwd(c["t3_pre"], a.p(pl + "norm3.weight"), a.p(pl + "norm3.bias"), c["t3"], c["m3"], c["r3"])
             tgt = c["t3"]
         ops.layernorm_fwd(tgt, a.p("transformer.decoder.norm.weight"), a.p("transformer.decoder.norm.bias"), w.tgtF,
@@ -675,24 +682,39 @@ class FusionEngine:
             ops.layernorm_bwd(dy, x, mean, rstd, a.p(gname), a.p(bname), dx, a.g(gname), a.g(bname), partial=w.lnp[site],
                               **kw)
 
-        # ---- heads: both input gradients in one launch (the segmentation one is only needed at the fuser's norm)
-        if not hasattr(w, "head_group"):
-            w.head_group = ops.GemmGroup(GEMM_NN, [dict(a=w.d_actdur, b=self.w_head, c=w.d_tgtF),
-                                                   dict(a=w.d_seg, b=a.p("fc_seg.weight"), c=w.d_fused2)],
-                                         tile=1 if H < 256 else 2)
-        w.head_group.launch()
-        # ---- decoder
         last = w.layers[-1]
-        ln_bwd("final", w.d_tgtF, last["t3"], w.mF, w.rF, "transformer.decoder.norm.weight",
-               "transformer.decoder.norm.bias", w.d_t)
+        tail = self.use_fused_tail
+        paired = bool(st.get("paired"))
+        if tail:
+            # ---- heads' input gradient + decoder.norm backward + the last norm3 backward: one launch.  The segmentation
+            # head's input gradient (only needed at the fuser's norm) rides in a later group (paired) or goes alone.
+            Lm, plm = self.L - 1, f"transformer.decoder.layers.{self.L - 1}."
+            ops.decoder_tail_bwd(w.d_actdur, self.w_head, last["t3"], w.mF, w.rF, a.p("transformer.decoder.norm.weight"),
+                                 last["t3_pre"], last["m3"], last["r3"], a.p(plm + "norm3.weight"),
+                                 None if not drop else w.drop[f"d3_{Lm}"], dsc, w.glayers[Lm]["t3pre"], w.glayers[Lm]["ff2"],
+                                 a.g("transformer.decoder.norm.weight"), a.g("transformer.decoder.norm.bias"),
+                                 a.g(plm + "norm3.weight"), a.g(plm + "norm3.bias"), w.lnp["final"], w.lnp[f"d3_{Lm}"])
+            if not paired:
+                ops.gemm(GEMM_NN, d_seg, a.p("fc_seg.weight"), w.d_fused2, ws=ws)
+        else:
+            # ---- heads: both input gradients in one launch (the segmentation one is only needed at the fuser's norm)
+            if not hasattr(w, "head_group"):
+                w.head_group = ops.GemmGroup(GEMM_NN, [dict(a=w.d_actdur, b=self.w_head, c=w.d_tgtF),
+                                                       dict(a=w.d_seg, b=a.p("fc_seg.weight"), c=w.d_fused2)],
+                                             tile=1 if H < 256 else 2)
+            w.head_group.launch()
+            # ---- decoder
+            ln_bwd("final", w.d_tgtF, last["t3"], w.mF, w.rF, "transformer.decoder.norm.weight",
+                   "transformer.decoder.norm.bias", w.d_t)
         dy, dy2 = w.d_t, None                 # gradient w.r.t. t3 of the current layer (= dy + dy2)
         first_fused = True
         for l in reversed(range(self.L)):
             c, gl, pl = w.layers[l], w.glayers[l], f"transformer.decoder.layers.{l}."
             p = lambda n: a.p(pl + n)         # noqa: E731
             # norm3 -> (t2 residual, FFN)
-            ln_bwd(f"d3_{l}", dy, c["t3_pre"], c["m3"], c["r3"], pl + "norm3.weight", pl + "norm3.bias", gl["t3pre"],
-                   dy2=dy2, dx2=gl["ff2"], drop_mask=dm(f"d3_{l}", BQ, H), drop_scale=dsc)
+            if not (tail and l == self.L - 1):
+                ln_bwd(f"d3_{l}", dy, c["t3_pre"], c["m3"], c["r3"], pl + "norm3.weight", pl + "norm3.bias", gl["t3pre"],
+                       dy2=dy2, dx2=gl["ff2"], drop_mask=dm(f"d3_{l}", BQ, H), drop_scale=dsc)
             ops.gemm(GEMM_NN, gl["ff2"], p("linear2.weight"), gl["ff1"], drop_mask=dm(f"ff_{l}", BQ, 4 * H),
                      drop_scale=dsc, aux=c["ff1"], mul=1, ws=ws)
             ops.gemm(GEMM_NN, gl["ff1"], p("linear1.weight"), gl["t2"], res1=gl["t3pre"], ws=ws)
@@ -733,13 +755,15 @@ class FusionEngine:
             # the query-side branch (cross-attention query projection, norm1, self-attention: parameter gradients only
             # for a one-layer decoder) and the memory-side chain into the fuser are independent: their GEMMs share launches
             c, gl, pl = w.layers[0], w.glayers[0], "transformer.decoder.layers.0."
-            key = ("bwd_pairs",)
+            key = ("bwd_pairs", bool(tail))
             if key not in w.tables:
                 wi0 = a.p(pl + "multihead_attn.in_proj_weight")
                 t = 1 if H < 256 else 2
+                first = [dict(a=gl["caq"], b=wi0[:H], c=gl["caqin"]), dict(a=gl["cakv"], b=wi0[H:], c=w.d_fused)]
+                if tail:                       # the segmentation head's input gradient (see the tail launch above)
+                    first.append(dict(a=w.d_seg, b=a.p("fc_seg.weight"), c=w.d_fused2))
                 w.tables[key] = (
-                    ops.GemmGroup(GEMM_NN, [dict(a=gl["caq"], b=wi0[:H], c=gl["caqin"]),
-                                            dict(a=gl["cakv"], b=wi0[H:], c=w.d_fused)], tile=t),
+                    ops.GemmGroup(GEMM_NN, first, tile=t),
                     ops.GemmGroup(GEMM_NN, [dict(a=gl["sap"], b=a.p(pl + "self_attn.out_proj.weight"), c=gl["sao"]),
                                             dict(a=w.d_x3, b=a.p(pre + "mlp.mlp.2.weight"), c=w.d_u, aux=w.u, mul=2)], tile=t),
                     ops.GemmGroup(GEMM_NN, [dict(a=gl["saqkv"], b=a.p(pl + "self_attn.in_proj_weight"), c=gl["sain"]),

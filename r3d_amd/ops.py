@@ -408,6 +408,22 @@ def decoder_layer_fwd(table, B, S, Q, H, heads, pad_idx, drop_scale, n_head_out)
           "r3d_decoder_layer_fwd")
 
 
+def decoder_tail_fwd(x, g3, b3, gF, bF, w_head, b_head, t3, m3, r3, tgtF, mF, rF, out):
+    rows, H = x.shape
+    assert x.is_contiguous() and t3.is_contiguous() and tgtF.is_contiguous()
+    check(_lib.load().r3d_decoder_tail_fwd(_p(x), _p(g3), _p(b3), _p(gF), _p(bF), _p(w_head), _p(b_head), w_head.shape[0],
+                                           _p(t3), _p(m3), _p(r3), _p(tgtF), _p(mF), _p(rF), _p(out), _ld(out), rows, H,
+                                           _stream()), "r3d_decoder_tail_fwd")
+
+
+def decoder_tail_bwd(d_out, w_head, t3, mF, rF, gF, x, m3, r3, g3, drop_mask, drop_scale, dx, dx2, dgF, dbF, dg3, db3, wsF, ws3):
+    rows, H = x.shape
+    check(_lib.load().r3d_decoder_tail_bwd(_p(d_out), _ld(d_out), _p(w_head), w_head.shape[0], _p(t3), _p(mF), _p(rF), _p(gF),
+                                           _p(x), _p(m3), _p(r3), _p(g3), _p(drop_mask), drop_scale, _p(dx), _p(dx2),
+                                           _p(dgF), _p(dbF), _p(dg3), _p(db3), _p(wsF), _p(ws3), rows, H, _stream()),
+          "r3d_decoder_tail_bwd")
+
+
 def embed_fuse_fwd(rgb_src, ns_r, bias_r, dep_src, ns_d, bias_d, lnd_g, lnd_b, m_rgb, m_dep, drop, drop_scale, ln1_g, ln1_b,
                    rgb_out, dep_pre_out, mean_d, rstd_d, dep_out, x0, h1, m1, r1):
     N, H = dep_out.shape

@@ -298,3 +298,38 @@ def test_adamw_in_weight_gradient_epilogue_equals_flat_adamw():
         dlt = (states[0][k][0] - states[1][k][0]).abs()
         assert float(dlt.max()) <= 2.1 * m["lr"] * (k + 1)
         assert float((dlt <= 1e-5 * (1 + states[0][k][0].abs())).double().mean()) > 0.99
+
+
+@pytest.mark.parametrize("flags", [dict(use_fused_tail=False), dict(use_paired_launches=False),
+                                   dict(use_fused_tail=False, use_paired_launches=False),
+                                   dict(use_fused_tail=False, use_paired_launches=False, use_fused_embed=False),
+                                   dict(use_side_stream=True), dict(use_fused_decoder=True)])
+@pytest.mark.parametrize("tag,training", [("step_cfg2", True), ("step_k122_dec2", False)])
+def test_launch_fusion_paths_agree(tag, training, flags):
+    """Every launch-fusion switch of the engine (decoder tail kernel, paired GEMM launches, embedding seam, side stream,
+    fused decoder layer) must leave losses and gradients unchanged (identical dropout masks when training)."""
+    fx = load_fixture(tag)
+    model = build_model(fx)
+    model.train(training)
+    eng = model.engine()
+    d = [t.cuda() for t in fixture_batch(fx)]
+    res = []
+    for alt in (False, True):
+        if not alt:
+            defaults = {k: getattr(eng, k) for k in flags}
+        else:
+            for k, v in flags.items():
+                setattr(eng, k, v)
+        eng.forward(d[0], d[1], d[2], "train", training=training)          # same drop_offset -> same masks
+        eng.losses(d[2], d[4], d[3])
+        eng.backward()
+        torch.cuda.synchronize()
+        res.append((eng.last["w"].loss.clone(), eng.arena.grads.clone()))
+        if alt:
+            for k, v in defaults.items():
+                setattr(eng, k, v)
+    close_rel(res[1][0], res[0][0], "loss", rtol=1e-5)
+    a = eng.arena
+    for n in a.live_names:
+        o, k, _ = a.offsets[n]
+        close_rel(res[1][1][o:o + k], res[0][1][o:o + k], f"{tag}/{flags} grad {n}", rtol=5e-4)
