@@ -200,7 +200,7 @@ def main():
         eng.backward(fused_adamw=dict(lr=c["lr"], weight_decay=c["wd"], grad_scale=gscale) if fuse else None)
         if dp is not None:
             dp.wait_grads()
-        eng.adamw(c["lr"], c["wd"], grad_scale=gscale, ticked=True, skip_depth=fuse)
+        eng.adamw(c["lr"], c["wd"], grad_scale=gscale, ticked=True, skip_depth=fuse, prefill_dropout=True)
 
     mode = "replicated"
     if world > 1:

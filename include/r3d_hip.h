@@ -280,6 +280,10 @@ int64_t r3d_losses_ws_floats(int B, int S, int Q);
  * grad_scale first (1/world after a sum all-reduce).  lr and the 1-based step are read from device memory. */
 int r3d_adamw_flat(float* p, const float* g, float* m, float* v, int64_t n, const float* lr, const int64_t* step,
                    float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream);
+/* r3d_adamw_flat and r3d_dropout_mask (the NEXT step's masks: the pool is free once the backward has run) in one launch. */
+int r3d_adamw_flat_dropout(float* p, const float* g, float* m, float* v, int64_t n, const float* lr, const int64_t* step,
+                           float beta1, float beta2, float eps, float weight_decay, float grad_scale, uint8_t* mask,
+                           int64_t n_mask, float p_drop, uint64_t seed, const int64_t* offset, void* stream);
 /* The same update on a [rows x cols] block (leading dimension ld) of p/g/m/v: a pixel shard of depth_projection.weight. */
 int r3d_adamw_2d(float* p, const float* g, float* m, float* v, int rows, int cols, int ld, const float* lr,
                  const int64_t* step, float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream);

@@ -113,6 +113,7 @@ _SIGNATURES = {
                             _P, _I, _P, _P, _P, _P, _P, _P], C.c_int),
     "r3d_losses_ws_floats": ([_I, _I, _I], C.c_int64),
     "r3d_adamw_flat": ([_P, _P, _P, _P, _L, _P, _P, _F, _F, _F, _F, _F, _P], C.c_int),
+    "r3d_adamw_flat_dropout": ([_P, _P, _P, _P, _L, _P, _P, _F, _F, _F, _F, _F, _P, _L, _F, C.c_uint64, _P, _P], C.c_int),
     "r3d_adamw_2d": ([_P, _P, _P, _P, _I, _I, _I, _P, _P, _F, _F, _F, _F, _F, _P], C.c_int),
     "r3d_dropout_mask": ([_P, _L, _F, C.c_uint64, _P, _P], C.c_int),
     "r3d_erank_lds_bytes": ([_I, _I], C.c_int64),

@@ -11,10 +11,9 @@
 
 namespace r3d {
 
-__global__ __launch_bounds__(256) void adamw_kernel(float4* __restrict__ p, const float4* __restrict__ g,
-                                                    float4* __restrict__ m, float4* __restrict__ v, size_t n4,
-                                                    const float* lr_ptr, const int64_t* step_ptr, float b1, float b2,
-                                                    float eps, float wd, float gscale) {
+__device__ __forceinline__ void adamw_body(float4* __restrict__ p, const float4* __restrict__ g, float4* __restrict__ m,
+                                           float4* __restrict__ v, size_t n4, const float* lr_ptr, const int64_t* step_ptr,
+                                           float b1, float b2, float eps, float wd, float gscale, unsigned bid, unsigned nb) {
     const float lr = *lr_ptr;
     const double step = (double)*step_ptr;
     const float bc1 = (float)(1.0 - pow((double)b1, step));
@@ -22,7 +21,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float4* __restrict__ p, cons
     const float decay = 1.0f - lr * wd;
     const float step_size = lr / bc1;
     const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    for (size_t i = (size_t)bid * 256 + threadIdx.x; i < n4; i += (size_t)nb * 256) {
         float4 pp = p[i], gg = g[i], mm = m[i], vv = v[i];
 #define R3D_ADAM1(c)                                               \
         {                                                          \
@@ -37,6 +36,13 @@ __global__ __launch_bounds__(256) void adamw_kernel(float4* __restrict__ p, cons
 #undef R3D_ADAM1
         p[i] = pp; m[i] = mm; v[i] = vv;
     }
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(float4* __restrict__ p, const float4* __restrict__ g,
+                                                    float4* __restrict__ m, float4* __restrict__ v, size_t n4,
+                                                    const float* lr_ptr, const int64_t* step_ptr, float b1, float b2,
+                                                    float eps, float wd, float gscale) {
+    adamw_body(p, g, m, v, n4, lr_ptr, step_ptr, b1, b2, eps, wd, gscale, blockIdx.x, gridDim.x);
 }
 
 // The same update on a [rows x cols] block of a row-major matrix with leading dimension ld: a COLUMN shard of
@@ -90,11 +96,11 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 ctr, uint2 key) {
 }
 
 // mask[i] = 1 with probability (1-p).  4 elements per Philox call.
-__global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* mask, size_t n, uint32_t thresh, uint64_t seed,
-                                                           const int64_t* offset_ptr) {
+__device__ __forceinline__ void dropout_body(uint8_t* mask, size_t n, uint32_t thresh, uint64_t seed,
+                                             const int64_t* offset_ptr, unsigned bid, unsigned nb) {
     const uint64_t off = offset_ptr ? (uint64_t)*offset_ptr : 0ull;
     const size_t n4 = (n + 3) / 4;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    for (size_t i = (size_t)bid * 256 + threadIdx.x; i < n4; i += (size_t)nb * 256) {
         const uint4 r = philox4x32_10(make_uint4((uint32_t)i, (uint32_t)(i >> 32), (uint32_t)off, (uint32_t)(off >> 32)),
                                       make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
         const uint32_t u[4] = {r.x, r.y, r.z, r.w};
@@ -102,6 +108,23 @@ __global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* mask, size_t
         for (int j = 0; j < 4; ++j)
             if (i * 4 + j < n) mask[i * 4 + j] = (u[j] >= thresh) ? 1 : 0;
     }
+}
+
+__global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* mask, size_t n, uint32_t thresh, uint64_t seed,
+                                                           const int64_t* offset_ptr) {
+    dropout_body(mask, n, thresh, seed, offset_ptr, blockIdx.x, gridDim.x);
+}
+
+// AdamW and the NEXT step's dropout masks in one launch: the first nb_adam workgroups stream the arenas, the rest fill
+// the mask pool (it is free once the backward has run) -- a dependent launch at the head of every step less.
+__global__ __launch_bounds__(256) void adamw_dropout_kernel(float4* __restrict__ p, const float4* __restrict__ g,
+                                                            float4* __restrict__ m, float4* __restrict__ v, size_t n4,
+                                                            const float* lr_ptr, const int64_t* step_ptr, float b1, float b2,
+                                                            float eps, float wd, float gscale, unsigned nb_adam,
+                                                            uint8_t* mask, size_t n_mask, uint32_t thresh, uint64_t seed,
+                                                            const int64_t* offset_ptr) {
+    if (blockIdx.x < nb_adam) adamw_body(p, g, m, v, n4, lr_ptr, step_ptr, b1, b2, eps, wd, gscale, blockIdx.x, nb_adam);
+    else dropout_body(mask, n_mask, thresh, seed, offset_ptr, blockIdx.x - nb_adam, gridDim.x - nb_adam);
 }
 
 }  // namespace r3d
@@ -117,6 +140,27 @@ R3D_EXPORT int r3d_adamw_flat(float* p, const float* g, float* m, float* v, int6
     const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
     hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float4*)p, (const float4*)g,
                        (float4*)m, (float4*)v, n4, lr, step, beta1, beta2, eps, weight_decay, grad_scale);
+    R3D_LAUNCH_CHECK();
+    return R3D_OK;
+}
+
+/* r3d_adamw_flat and r3d_dropout_mask(mask, n_mask, p_drop, seed, offset) in ONE launch (the masks are the next step's). */
+R3D_EXPORT int r3d_adamw_flat_dropout(float* p, const float* g, float* m, float* v, int64_t n, const float* lr,
+                                      const int64_t* step, float beta1, float beta2, float eps, float weight_decay,
+                                      float grad_scale, uint8_t* mask, int64_t n_mask, float p_drop, uint64_t seed,
+                                      const int64_t* offset, void* stream) {
+    R3D_REQUIRE(p && g && m && v && lr && step && n > 0 && mask && n_mask > 0 && p_drop >= 0.f && p_drop < 1.f);
+    R3D_REQUIRE((n % 4) == 0);
+    if (!(r3d_aligned16(p) && r3d_aligned16(g) && r3d_aligned16(m) && r3d_aligned16(v))) return R3D_EALIGN;
+    const size_t n4 = (size_t)n / 4;
+    const unsigned nb_adam = (unsigned)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+    const double t = (double)p_drop * 4294967296.0;
+    const uint32_t thresh = (uint32_t)(t >= 4294967295.0 ? 4294967295.0 : t);
+    const size_t m4 = ((size_t)n_mask + 3) / 4;
+    const unsigned nb_drop = (unsigned)((m4 + 255) / 256 < 512 ? (m4 + 255) / 256 : 512);
+    hipLaunchKernelGGL(adamw_dropout_kernel, dim3(nb_adam + nb_drop), dim3(256), 0, (hipStream_t)stream, (float4*)p,
+                       (const float4*)g, (float4*)m, (float4*)v, n4, lr, step, beta1, beta2, eps, weight_decay, grad_scale,
+                       nb_adam, mask, (size_t)n_mask, thresh, seed, offset);
     R3D_LAUNCH_CHECK();
     return R3D_OK;
 }

@@ -197,6 +197,7 @@ class FusionEngine:
         self._fw = None
         self.last = None
         self._adam = None
+        self._drop_ready = None           # workspace whose dropout pool already holds the masks of the next forward
         a = self.arena
         K, H = self.K, self.H
         o_w = a.offsets["fc.weight"][0]
@@ -249,7 +250,10 @@ class FusionEngine:
         w = self._shape(B, S, need_grad)
         drop = training and need_grad
         if drop:
-            ops.dropout_mask(w.drop_pool, DROP_P, self.drop_seed, self.drop_offset)
+            if self._drop_ready is w:     # the previous step's AdamW launch already filled the pool for this offset
+                self._drop_ready = None
+            else:
+                ops.dropout_mask(w.drop_pool, DROP_P, self.drop_seed, self.drop_offset)
         tp = self.tp if (self.tp is not None and need_grad) else None
         seam = self.use_fused_embed and mode == "train" and H <= 1024
         # (running this GEMM on the side stream beside the 5x longer depth projection was measured: the cross-queue
@@ -828,17 +832,26 @@ class FusionEngine:
             self._lr_host = float(lr)
 
     def adamw(self, lr, weight_decay, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0, tick_dropout=False, ticked=False,
-              skip_depth=False):
+              skip_depth=False, prefill_dropout=False):
         """One fused launch over the live prefix of the arena (main_darai.py:135; train_proposed_depth.py:215).
         ticked: losses(tick=True) already advanced the counters in this step.
-        skip_depth: backward(fused_adamw=...) already updated depth_projection.weight."""
+        skip_depth: backward(fused_adamw=...) already updated depth_projection.weight.
+        prefill_dropout: the same launch also fills the dropout pool of the step's workspace with the NEXT step's masks
+        (valid while the next forward uses the same shape and the dropout offset is not advanced again)."""
         a = self.arena
         self.set_lr(lr)
         if not ticked:
             ops.tick(self.step_t, self.drop_offset if tick_dropout else None)
         n = a.n_live if (self.tp is None and not skip_depth) else a.bucket_small[1]
-        ops.adamw_flat(a.params[:n], a.grads[:n], a.exp_avg[:n], a.exp_avg_sq[:n], self.lr_t, self.step_t, beta1=betas[0],
-                       beta2=betas[1], eps=eps, weight_decay=weight_decay, grad_scale=grad_scale)
+        st = self.last
+        if prefill_dropout and st is not None and st["drop"] and (ticked or tick_dropout):
+            ops.adamw_flat_dropout(a.params[:n], a.grads[:n], a.exp_avg[:n], a.exp_avg_sq[:n], self.lr_t, self.step_t,
+                                   st["w"].drop_pool, DROP_P, self.drop_seed, self.drop_offset, beta1=betas[0], beta2=betas[1],
+                                   eps=eps, weight_decay=weight_decay, grad_scale=grad_scale)
+            self._drop_ready = st["w"]
+        else:
+            ops.adamw_flat(a.params[:n], a.grads[:n], a.exp_avg[:n], a.exp_avg_sq[:n], self.lr_t, self.step_t,
+                           beta1=betas[0], beta2=betas[1], eps=eps, weight_decay=weight_decay, grad_scale=grad_scale)
         if self.tp is not None and not skip_depth:  # depth_projection.weight: only this rank's pixel columns are live
             t = self.tp
             ops.adamw_2d(t.w, t.g, t.m, t.v, self.lr_t, self.step_t, beta1=betas[0], beta2=betas[1], eps=eps,
@@ -851,5 +864,5 @@ class FusionEngine:
         # (backward(fused_adamw=...) + adamw(skip_depth=True) would update depth_projection.weight inside its
         #  weight-gradient GEMM; measured neutral at the bench shape, so the plain sequence stays the default)
         self.backward()
-        self.adamw(lr, weight_decay, ticked=True)
+        self.adamw(lr, weight_decay, ticked=True, prefill_dropout=True)
         return loss, counts

@@ -479,6 +479,17 @@ def adamw_flat(p, g, m, v, lr_t, step_t, *, beta1=0.9, beta2=0.999, eps=1e-8, we
                              _stream()), "r3d_adamw_flat")
 
 
+def adamw_flat_dropout(p, g, m, v, lr_t, step_t, mask, p_drop, seed, offset_t, *, beta1=0.9, beta2=0.999, eps=1e-8,
+                       weight_decay=0.0, grad_scale=1.0):
+    """adamw_flat + dropout_mask(mask, p_drop, seed, offset_t) in one launch (the masks are the next step's)."""
+    lib = _lib.load()
+    n = p.numel()
+    assert g.numel() == n and m.numel() == n and v.numel() == n and mask.dtype == torch.uint8
+    check(lib.r3d_adamw_flat_dropout(_p(p), _p(g), _p(m), _p(v), n, _p(lr_t), _p(step_t), beta1, beta2, eps, weight_decay,
+                                     grad_scale, _p(mask), mask.numel(), p_drop, seed, _p(offset_t), _stream()),
+          "r3d_adamw_flat_dropout")
+
+
 def adamw_2d(p, g, m, v, lr_t, step_t, *, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, grad_scale=1.0):
     """p, g, m, v: [rows, cols] views with the same (possibly larger) row stride."""
     lib = _lib.load()

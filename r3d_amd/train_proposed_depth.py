@@ -128,7 +128,7 @@ def train(args, model, train_loader, optimizer, scheduler, criterion, model_save
                 dp.wait_grads()
             if fused_opt:
                 eng.adamw(g["lr"], g["weight_decay"], betas=g["betas"], eps=g["eps"],
-                          grad_scale=dp.grad_scale if dp is not None else 1.0, ticked=True)
+                          grad_scale=dp.grad_scale if dp is not None else 1.0, ticked=True, prefill_dropout=True)
             else:                                   # any other torch optimiser: expose the arena gradients to it
                 if dp is not None:
                     eng.arena.grads.mul_(dp.grad_scale)

@@ -333,3 +333,23 @@ def test_launch_fusion_paths_agree(tag, training, flags):
     for n in a.live_names:
         o, k, _ = a.offsets[n]
         close_rel(res[1][1][o:o + k], res[0][1][o:o + k], f"{tag}/{flags} grad {n}", rtol=5e-4)
+
+
+def test_dropout_prefill_in_adamw_launch_gives_the_same_masks():
+    """adamw(prefill_dropout=True) fills the next step's dropout pool inside the optimiser launch; three training steps
+    (dropout on) must be bit-identical to generating the masks at the head of each step."""
+    fx = load_fixture("step_cfg2")
+    m = fx["meta"]
+    d = [t.cuda() for t in fixture_batch(fx)]
+    outs = []
+    for prefill in (False, True):
+        model = build_model(fx).train()
+        eng = model.engine()
+        for _ in range(3):
+            eng.forward(d[0], d[1], d[2], "train", training=True)
+            eng.losses(d[2], d[4], d[3], tick=True)
+            eng.backward()
+            eng.adamw(m["lr"], m["wd"], ticked=True, prefill_dropout=prefill)
+        torch.cuda.synchronize()
+        outs.append((eng.arena.params.clone(), eng.last["w"].drop_pool.clone(), eng.last["w"].loss.clone()))
+    assert torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][0], outs[1][0])
