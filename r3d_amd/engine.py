@@ -766,6 +766,13 @@ class FusionEngine:
                 first = [dict(a=gl["caq"], b=wi0[:H], c=gl["caqin"]), dict(a=gl["cakv"], b=wi0[H:], c=w.d_fused)]
                 if tail:                       # the segmentation head's input gradient (see the tail launch above)
                     first.append(dict(a=w.d_seg, b=a.p("fc_seg.weight"), c=w.d_fused2))
+                # W_proj . W_v (parameters only): with it the two chained GEMMs at the end of the fuser's backward,
+                # d_v = swap(d_x1 . W_proj) and d_h1 = d_v . W_v = swap(d_x1 . (W_proj . W_v)), share one launch
+                w.wc = torch.empty(H, H, dtype=torch.float32, device=self.device)
+                first.append(dict(a=a.p(pre + "attn.proj.weight"), b=a.p(pre + "attn.qkv.weight")[2 * H:], c=w.wc))
+                w.tables[("bwd_vh1",)] = ops.GemmGroup(GEMM_NN, [
+                    dict(a=w.d_x1, b=a.p(pre + "attn.proj.weight"), c=w.d_v, c_row_xor=1),
+                    dict(a=w.d_x1, b=w.wc, c=w.d_h1, c_row_xor=1)], tile=t)
                 w.tables[key] = (
                     ops.GemmGroup(GEMM_NN, first, tile=t),
                     ops.GemmGroup(GEMM_NN, [dict(a=gl["sap"], b=a.p(pl + "self_attn.out_proj.weight"), c=gl["sao"]),
@@ -793,8 +800,11 @@ class FusionEngine:
             ops.gemm(GEMM_NN, w.d_x3, a.p(pre + "mlp.mlp.2.weight"), w.d_u, aux=w.u, mul=2, ws=ws)
             ops.gemm(GEMM_NN, w.d_u, a.p(pre + "mlp.mlp.0.weight"), w.d_h2, ws=ws)
         ln_bwd("n2", w.d_h2, w.x1, w.m2, w.r2, pre + "norm2.weight", pre + "norm2.bias", w.d_x1, add1=w.d_x3)
-        ops.gemm(GEMM_NN, w.d_x1, a.p(pre + "attn.proj.weight"), w.d_v, c_row_xor=1, ws=ws)     # un-swap
-        ops.gemm(GEMM_NN, w.d_v, a.p(pre + "attn.qkv.weight")[2 * H:], w.d_h1, ws=ws)
+        if st.get("paired"):
+            w.tables[("bwd_vh1",)].launch()
+        else:
+            ops.gemm(GEMM_NN, w.d_x1, a.p(pre + "attn.proj.weight"), w.d_v, c_row_xor=1, ws=ws)     # un-swap
+            ops.gemm(GEMM_NN, w.d_v, a.p(pre + "attn.qkv.weight")[2 * H:], w.d_h1, ws=ws)
         mask = st["mask"]
         if st["seam"]:                      # norm1 backward + exchange backward + depth LayerNorm backward: one launch
             ops.embed_fuse_bwd(w.d_h1, w.x0, w.m1, w.r1, a.p(pre + "norm1.weight"), w.d_x1, w.d_x3, dmf("x0"), dsc, mask[0],
