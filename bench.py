@@ -259,6 +259,7 @@ def main():
                         sh["work"] = None
                     torch.cuda.synchronize()
                     gA[s] = torch.cuda.CUDAGraph()
+                    eng._drop_ready = eng.last["w"] if training else None             # masks come from gD's AdamW launch
                     with torch.cuda.graph(gA[s]):
                         eng.forward_begin(feats, depth, lab, "train", training)       # consumes the slot-s shard
                     w_ = eng._fw["w"]
@@ -272,7 +273,8 @@ def main():
                     with torch.cuda.graph(gC[s]):
                         tp.wgrad(w_, eng.ws, eng._adam)
                 with torch.cuda.graph(gD):
-                    eng.adamw(c["lr"], c["wd"], grad_scale=gscale, ticked=True, skip_depth=fuse_adam)
+                    eng.adamw(c["lr"], c["wd"], grad_scale=gscale, ticked=True, skip_depth=fuse_adam, prefill_dropout=True)
+                eng._drop_ready = None
                 eng.grad_hook = hook
                 slot[0] = 0
                 tp.prefetch(x_dep2d, 0)
@@ -299,6 +301,7 @@ def main():
                 hook = eng.grad_hook
                 eng.grad_hook = None
                 g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                eng._drop_ready = eng.last["w"] if training else None                 # masks come from g3's AdamW launch
                 with torch.cuda.graph(g1):
                     eng.forward(feats, depth, lab, "train", training)
                     eng.losses(lab, tgt, dur, tick=True)
@@ -306,7 +309,8 @@ def main():
                 with torch.cuda.graph(g2):
                     eng.backward_depth_wgrad()
                 with torch.cuda.graph(g3):
-                    eng.adamw(c["lr"], c["wd"], grad_scale=gscale, ticked=True)
+                    eng.adamw(c["lr"], c["wd"], grad_scale=gscale, ticked=True, prefill_dropout=True)
+                eng._drop_ready = None
                 eng.grad_hook = hook
 
                 def run_step():
