@@ -61,17 +61,17 @@ __global__ __launch_bounds__(256) void embed_fuse_fwd_kernel(const EmbedFwdArgs 
             s4[0] = a.rgb_src[rowo + cc[e]];
         }
         ar[e] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
-        float d4[4] = {0.f, 0.f, 0.f, 0.f};
+        float d8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // depth: ~61 slabs -> 8 loads in flight per column
         {
             const float* p = a.dep_src + rowo + cc[e];
             int s = wave;
-            for (; s + 12 < a.ns_d; s += 16) {
+            for (; s + 28 < a.ns_d; s += 32) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) d4[q] += p[(size_t)(s + 4 * q) * stride];
+                for (int q = 0; q < 8; ++q) d8[q] += p[(size_t)(s + 4 * q) * stride];
             }
-            for (; s < a.ns_d; s += 4) d4[0] += p[(size_t)s * stride];
+            for (int q = 0; s < a.ns_d; s += 4, ++q) d8[q & 7] += p[(size_t)s * stride];
         }
-        ad[e] = (d4[0] + d4[1]) + (d4[2] + d4[3]);
+        ad[e] = ((d8[0] + d8[1]) + (d8[2] + d8[3])) + ((d8[4] + d8[5]) + (d8[6] + d8[7]));
     }
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {

@@ -50,6 +50,18 @@ __global__ __launch_bounds__(256) void decoder_tail_fwd_kernel(const TailFwdArgs
         x[e] = a.x[(size_t)row * H + cc[e]];
         g3[e] = a.g3[cc[e]]; b3[e] = a.b3[cc[e]]; gF[e] = a.gF[cc[e]]; bF[e] = a.bF[cc[e]];
     }
+    // head weights of this lane's columns, up front (K + 1 = 18 rows for DARai): the loads travel under the two norms
+    constexpr int NHP = (EPL <= 2) ? 24 : 1;
+    float wh[NHP][EPL];
+    const bool pre = a.n_head <= NHP;
+    if (pre) {
+#pragma unroll
+        for (int k = 0; k < NHP; ++k) {
+            const int kc = k < a.n_head ? k : a.n_head - 1;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) wh[k][e] = a.w_head[(size_t)kc * H + cc[e]];
+        }
+    }
     float y3[EPL], yF[EPL], m, r;
     ln_apply<EPL>(x, g3, b3, H, lane, y3, m, r);
     if (lane == 0) { a.m3[row] = m; a.r3[row] = r; }
@@ -61,6 +73,24 @@ __global__ __launch_bounds__(256) void decoder_tail_fwd_kernel(const TailFwdArgs
 #pragma unroll
     for (int e = 0; e < EPL; ++e)
         if (lane + 64 * e < H) a.tgtF[(size_t)row * H + lane + 64 * e] = yF[e];
+    if (pre) {
+        float p[NHP];
+#pragma unroll
+        for (int k = 0; k < NHP; ++k) {
+            float t = 0.f;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) t += yF[e] * wh[k][e];
+            p[k] = t;
+        }
+#pragma unroll
+        for (int k = 0; k < NHP; ++k) {
+            if (k < a.n_head) {                       // wave-uniform
+                const float t = wave_sum(p[k]);
+                if (lane == 0) a.out[(size_t)row * a.ld_out + k] = t + a.b_head[k];
+            }
+        }
+        return;
+    }
     // heads: 6 outputs per pass (their weight rows are loaded together, then 6 wave reductions)
     for (int k0 = 0; k0 < a.n_head; k0 += 6) {
         float p[6];
