@@ -1,0 +1,147 @@
+"""Host-side helpers around the hot path: the inference decode of predict(), checkpoint
+interchange with the reference's `.ckpt` files, and a device-resident input pipeline.  Plumbing only: nothing here is on
+the timed path and nothing computes on the CPU what the HIP path computes.
+
+Reference counterparts: utils.py:325-328 (normalize_duration), :330-339 (read_mapping_dict), :341-356 (eval_file),
+evaluation/predict_utkinects.py:331-353 (duration -> frame expansion), train/train_proposed_depth.py:243-248 and
+main_darai.py:133,161 (checkpoint names and the `module.` prefix of nn.DataParallel)."""
+import collections
+
+import numpy as np
+import torch
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# inference decode
+# ---------------------------------------------------------------------------------------------------------------------
+def normalize_duration(input, mask):
+    """exp(x) * mask, L1-normalised over the last dim (utils.py:325-328; eps 1e-12 as F.normalize)."""
+    x = torch.exp(input) * mask
+    return x / x.abs().sum(dim=-1, keepdim=True).clamp_min(1e-12)
+
+
+def read_mapping_dict(file_path):
+    """'<index> <name>' per line -> {name: index} (utils.py:330-339)."""
+    out = {}
+    with open(file_path, "r") as fh:
+        for line in fh.read().split("\n")[:-1]:
+            idx, name = line.split()[:2]
+            out[name] = int(idx)
+    return out
+
+
+def eval_file(gt_content, recog_content, obs_percentage, classes):
+    """Per-class true / false frame counts over the anticipated span (utils.py:341-356)."""
+    last = min(len(recog_content), len(gt_content))
+    start = int(obs_percentage * len(gt_content))
+    n_t, n_f = np.zeros(len(classes)), np.zeros(len(classes))
+    for g, r in zip(gt_content[start:last], recog_content[start:last]):
+        g = g.replace(" ", "")
+        if g == r:
+            n_t[classes[g]] += 1
+        else:
+            n_f[classes[g]] += 1
+    return n_t, n_f
+
+
+def mean_over_classes(n_t, n_f):
+    """MoC as printed by predict() (predict_utkinects.py:381-392): mean of per-class accuracy over classes that occur."""
+    tot = n_t + n_f
+    ok = tot != 0
+    return float((n_t[ok] / tot[ok]).mean()) if ok.any() else 0.0
+
+
+def expand_durations(action_logits, duration, future_len, none_idx):
+    """One clip's decoder outputs -> a label per anticipated frame (predict_utkinects.py:331-353).
+    action_logits [Q, K], duration [Q] (raw fc_len outputs); queries from the first NONE on carry no duration."""
+    labels = action_logits.argmax(-1)
+    q = labels.numel()
+    mask = torch.ones(q, dtype=duration.dtype, device=duration.device)
+    none_at = (labels == none_idx).nonzero()
+    if none_at.numel():
+        mask[int(none_at[0]):] = 0
+    dur = normalize_duration(duration.reshape(1, -1), mask.reshape(1, -1)).reshape(-1)
+    seg = (0.5 + future_len * dur).long().cpu().tolist()
+    lab = labels.cpu().tolist()
+    out = torch.ones(future_len, dtype=torch.long)          # the reference initialises with class 1 (:343)
+    start = 0
+    for i in range(q):
+        out[start:start + seg[i]] = lab[i]
+        start += seg[i]
+        if i == q - 1:
+            out[start - seg[i]:] = lab[i]                   # the last action runs to the end (:349-350)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# checkpoints
+# ---------------------------------------------------------------------------------------------------------------------
+def strip_module_prefix(state_dict):
+    """nn.DataParallel checkpoints (main_darai.py:133) prefix every key with 'module.'."""
+    return collections.OrderedDict((k[7:] if k.startswith("module.") else k, v) for k, v in state_dict.items())
+
+
+def load_checkpoint(model, path, strict=True):
+    """Loads a reference `seed_{seed}_best.ckpt` / `..._checkpoint{epoch}.ckpt` (a plain state_dict, with or without the
+    'module.' prefix) into r3d_amd's FUTR.  weights_only: nothing in the file is executed."""
+    sd = strip_module_prefix(torch.load(path, map_location="cpu", weights_only=True))
+    target = model.module if hasattr(model, "module") else model
+    return target.load_state_dict(sd, strict=strict)
+
+
+def save_checkpoint(model, path, data_parallel_keys=False):
+    """Writes the state_dict under the reference's key names; data_parallel_keys=True adds the 'module.' prefix so
+    that the reference's DataParallel-wrapped predict scripts (main_darai.py:161) load it unchanged."""
+    target = model.module if hasattr(model, "module") else model
+    sd = target.state_dict()
+    if data_parallel_keys:
+        sd = collections.OrderedDict(("module." + k, v) for k, v in sd.items())
+    torch.save(sd, path)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# device-resident input pipeline
+# ---------------------------------------------------------------------------------------------------------------------
+class InputPrefetcher:
+    """Wraps any iterable of the 5-tuple batches of BaseDataset.my_collate (basedataset_darai_depth.py:185-206) and keeps
+    the NEXT batch on the device while the current step runs: pinned staging buffers + async copies on a side stream.
+    The reference moves every batch synchronously inside the step (train_proposed_depth.py:132-137): 25.7 MB of depth
+    per step at the bench shape, 0.4 ms over PCIe -- longer than the whole HIP step."""
+
+    def __init__(self, loader, device):
+        self.loader, self.device = loader, torch.device(device)
+        self.stream = torch.cuda.Stream(self.device)
+
+    def _stage(self, data):
+        if data is None:
+            return None
+        out = []
+        with torch.cuda.stream(self.stream):
+            for i, t in enumerate(data):
+                t = torch.as_tensor(t)
+                if i in (2, 4):
+                    t = t.long()                                    # labels: float for NTU / UTKinect (cast at utils.py:365)
+                elif t.dtype != torch.float32:
+                    t = t.float()
+                if not t.is_cuda:
+                    t = t.pin_memory() if not t.is_pinned() else t
+                out.append(t.to(self.device, non_blocking=True).contiguous())
+        return out
+
+    def __iter__(self):
+        end = object()
+        it = iter(self.loader)
+        raw = next(it, end)
+        nxt = self._stage(raw) if raw is not end else end
+        while nxt is not end:
+            cur = nxt
+            if cur is not None:                                     # (None items pass through: train() skips them, :128)
+                torch.cuda.current_stream(self.device).wait_stream(self.stream)
+                for t in cur:
+                    t.record_stream(torch.cuda.current_stream(self.device))
+            raw = next(it, end)                                     # stage the following batch before handing this one out
+            nxt = self._stage(raw) if raw is not end else end
+            yield cur
+
+    def __len__(self):
+        return len(self.loader)

@@ -1,0 +1,54 @@
+"""SURVEY 8(f) rows beside the hot path, on the GPU: the inference decode (predict_clip) against the oracle's eval-mode
+forward, and the device-resident input pipeline (InputPrefetcher) feeding train() the same batches as a plain list."""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import futr_oracle as O  # noqa: E402
+from tests.helpers import load_fixture, fixture_params, fixture_batch  # noqa: E402
+from tests.test_engine_gpu import build_model  # noqa: E402
+
+
+def test_predict_clip_matches_oracle_decode(oracle_lib):
+    from r3d_amd.predict import predict_clip
+    from r3d_amd import utils as U
+    fx = load_fixture("val_h128")
+    m = fx["meta"]
+    feats, depth, lab, dur, tgt = fixture_batch(fx, pad_tail=False)
+    model = build_model(fx).train()                       # predict_clip must switch to eval and restore
+    res = predict_clip(model, feats[0].cuda(), depth[0].cuda(), future_len=37)
+    assert model.training
+    oout, oaux = O.forward(fixture_params(fx), (feats[:1], lab[:1]), depth[:1], "val", m["pad_idx"], m["n_head"], m["n_dec"])
+    assert torch.equal(res["action_labels"].cpu(), oout["action"][0].argmax(-1))
+    assert torch.equal(res["seg_labels"].cpu(), oout["seg"][0].argmax(-1))
+    want = U.expand_durations(oout["action"][0].detach(), oout["duration"][0].detach(), 37, m["n_class"] - 1)
+    assert torch.equal(res["frames"], want)
+
+
+def test_input_prefetcher_feeds_the_same_training(tmp_path):
+    from r3d_amd.train_proposed_depth import train
+    from r3d_amd.optim import FlatAdamW, LinearWarmupCosineAnnealingLR
+    from r3d_amd.utils import InputPrefetcher
+    fx = load_fixture("train_loop")
+    m = fx["meta"]
+    batches = [[t for t in fixture_batch(fx, seed=200 + i)] for i in range(3)] + [None]
+    val = [[t[:1] for t in fixture_batch(fx, seed=300)]]
+    finals = []
+    for wrap in (False, True):
+        model = build_model(fx)
+        args = argparse.Namespace(epochs=1, input_type="i3d_transcript", seg=True, anticipate=True, task="long",
+                                  min_batch=1)
+        opt = FlatAdamW(model.parameters(), 1e-3, weight_decay=5e-3)
+        sch = LinearWarmupCosineAnnealingLR(opt, warmup_epochs=2, max_epochs=4)
+        sch.step()                                        # epoch 0 runs at lr 0 in the reference's schedule
+        loader = InputPrefetcher(batches, "cuda") if wrap else batches
+        vloader = InputPrefetcher(val, "cuda") if wrap else val
+        model.eval()                                      # dropout off: the two runs must agree exactly
+        train(args, model, loader, opt, sch, None, str(tmp_path), m["pad_idx"], torch.device("cuda"), vloader, seed=1)
+        torch.cuda.synchronize()
+        finals.append(model.engine().arena.params.clone())
+    assert torch.equal(finals[0], finals[1])
