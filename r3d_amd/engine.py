@@ -49,12 +49,15 @@ class ParamArena:
                 return (0, 0 if n == "fc.weight" else 1)        # adjacent: [fc.weight ; fc_len.weight] = [K+1, H]
             if n in ("fc.bias", "fc_len.bias"):
                 return (2, 0 if n == "fc.bias" else 1)          # adjacent: [fc.bias ; fc_len.bias] = [K+1]
+            if n == "pos_embedding":
+                return (2, 9)          # last of the small bucket: only its first S rows ever get a gradient (:190), so a
+                                       # data-parallel step all-reduces the bucket up to row S and skips ~1 MB of zeros
             return (1, 0) if p.numel() % 4 == 0 else (2, 2)
         order = sorted(range(len(live)), key=lambda i: (key(live[i]), i))
         live = [live[i] for i in order]
         self.offsets, off = {}, 0
         for n, p in live:
-            if n == "depth_projection.weight":
+            if n in ("depth_projection.weight", "pos_embedding"):
                 off = (off + 3) // 4 * 4
             self.offsets[n] = (off, p.numel(), tuple(p.shape))
             off += p.numel()

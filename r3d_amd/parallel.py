@@ -188,8 +188,22 @@ class DataParallelStep:
         if stage == "big_ready" and self.tp is not None:
             return                        # that gradient is already complete on the rank that owns the columns
         buf = self.small if stage == "small_ready" else self.big
+        if stage == "small_ready":
+            buf = buf[:self._small_live()]
         if buf.numel():
             self.works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def _small_live(self):
+        """Floats of the small bucket that can be non-zero: pos_embedding [1, 2000, H] sits last in it and only its first
+        S rows (the clip length of this step) receive a gradient -- the rest is exact zeros on every rank."""
+        a, last = self.eng.arena, getattr(self.eng, "last", None)
+        offs = getattr(a, "offsets", None)
+        if not last or not offs or "pos_embedding" not in offs:
+            return self.small.numel()
+        o, n, shp = offs["pos_embedding"]
+        if o + n != a.bucket_small[1]:
+            return self.small.numel()
+        return min(self.small.numel(), o - a.bucket_small[0] + last["w"].S * shp[-1])
 
     def wait_grads(self):
         for w in self.works:
