@@ -241,6 +241,45 @@ def token_fusion(rgb, dep, mode, world_scores=None):
     return torch.stack([ex_rgb, ex_dep], dim=2), idx_rgb, idx_dep, s_rgb, s_dep
 
 
+def token_fusion_bn(p, state, rgb, dep, training, momentum=0.1, eps=1e-5):
+    """CMFuser.token_fusion of the BN-blend variant (model/futr_safuser_batchnormalization.py:38-76):
+    BatchNorm1d over (B,T) per channel on both embeddings (:45-46; batch statistics + running-stat update when
+    training, running statistics otherwise), score = |BN gamma| (:48-49), k = int(0.1 C) smallest (:58-60),
+    exchanged = alpha * own + (1 - alpha) * other on the selected channels (:65-74), stack (:75).
+    state: dict of the BatchNorm buffers (running_mean / running_var / num_batches_tracked), updated in place."""
+    B, T, C = rgb.shape
+
+    def bn(x, pre):
+        y = F.batch_norm(x.permute(0, 2, 1), state[pre + "running_mean"], state[pre + "running_var"], p[pre + "weight"],
+                         p[pre + "bias"], training, momentum, eps)
+        if training:
+            state[pre + "num_batches_tracked"] += 1
+        return y.permute(0, 2, 1)
+    r, d = bn(rgb, "fuser.bn_rgb."), bn(dep, "fuser.bn_depth.")
+    k = max(0, int(C * 0.1))
+    g_r, g_d = p["fuser.bn_rgb.weight"].detach().abs(), p["fuser.bn_depth.weight"].detach().abs()
+    idx_rgb = torch.from_numpy(select_smallest(g_r.numpy(), k))
+    idx_dep = torch.from_numpy(select_smallest(g_d.numpy(), k))
+    m_rgb = torch.zeros(C, dtype=torch.bool)
+    m_dep = torch.zeros(C, dtype=torch.bool)
+    m_rgb[idx_rgb] = True
+    m_dep[idx_dep] = True
+    alpha = p["fuser.alpha"].view(C)
+    ex_rgb = torch.where(m_rgb, alpha * r + (1 - alpha) * d, r)
+    ex_dep = torch.where(m_dep, alpha * d + (1 - alpha) * r, d)
+    return torch.stack([ex_rgb, ex_dep], dim=2), idx_rgb, idx_dep, g_r, g_d
+
+
+def cm_fuser_bn(p, state, rgb, dep, training, n_head):
+    """CMFuser.forward of the BN-blend variant (futr_safuser_batchnormalization.py:84-107): no x_res (:97,101)."""
+    B, T, C = rgb.shape
+    stacked, idx_rgb, idx_dep, s_rgb, s_dep = token_fusion_bn(p, state, rgb, dep, training)
+    x = fuser_block(p, stacked.reshape(B * T, 2, C), n_head)
+    x = layer_norm(x, p["fuser.norm.weight"], p["fuser.norm.bias"])
+    fused = x.mean(dim=1).view(B, T, C)
+    return fused, dict(idx_rgb=idx_rgb, idx_dep=idx_dep, score_rgb=s_rgb, score_dep=s_dep)
+
+
 def fuser_block(p, x, n_head):
     """Block (model/extras/transformerblock.py:118-135) with Attention (:7-36) under the additive
     mask [[-inf,0],[0,-inf]] (futr_safuser_tokenfusion.py:68-72,77) and MLP (:79-93, exact-erf GELU).
@@ -299,8 +338,11 @@ def decoder(p, memory, pos, query_pos, key_padding_mask, n_head, n_layers):
     return layer_norm(tgt, p["transformer.decoder.norm.weight"], p["transformer.decoder.norm.bias"])
 
 
-def forward(p, inputs, depth, mode, pad_idx, n_head=8, n_layers=1, want_seg=True, want_anticipate=True):
+def forward(p, inputs, depth, mode, pad_idx, n_head=8, n_layers=1, want_seg=True, want_anticipate=True, bn_state=None,
+            bn_training=False):
     """FUTR.forward (model/futr_safuser_tokenfusion.py:164-239), input_type 'i3d_transcript'.
+    bn_state (dict of BatchNorm buffers) selects the BN-blend fuser of model/futr_safuser_batchnormalization.py (same
+    FUTR around it, :110-270); bn_training = module.training.
     Returns (outputs dict, aux dict with fused features / selected indices)."""
     src, src_label = inputs
     B, S, _ = src.shape
@@ -310,7 +352,10 @@ def forward(p, inputs, depth, mode, pad_idx, n_head=8, n_layers=1, want_seg=True
     d = depth.reshape(B, S, -1)                                                      # :194
     d = F.linear(d, p["depth_projection.weight"], p["depth_projection.bias"])        # :195
     d = F.relu(layer_norm(d, p["depth_layernorm.weight"], p["depth_layernorm.bias"]))  # :196-197
-    fused, aux = cm_fuser(p, rgb, d, mode, n_head)                                   # :199
+    if bn_state is not None:
+        fused, aux = cm_fuser_bn(p, bn_state, rgb, d, bn_training, n_head)
+    else:
+        fused, aux = cm_fuser(p, rgb, d, mode, n_head)                               # :199
     qpos = p["query_embed.weight"].unsqueeze(0)                                      # :205-209
     tgt = decoder(p, fused, pos, qpos, kpm, n_head, n_layers)                        # :211
     out = {}
@@ -461,17 +506,23 @@ LIVE_PREFIXES = ("input_embed.", "depth_projection.", "depth_layernorm.", "pos_e
                  "fuser.blocks.", "fuser.norm.", "transformer.decoder.", "fc_seg.", "fc.", "fc_len.")
 
 
-def is_live(name):
+def is_live(name, bn=False):
     """Parameters that receive a gradient in the reference step; everything else has
-    grad=None and is skipped by AdamW."""
+    grad=None and is skipped by AdamW.  bn: the BN-blend variant also trains fuser.alpha and the two BatchNorms."""
+    if bn and name.startswith(("fuser.alpha", "fuser.bn_rgb.", "fuser.bn_depth.")):
+        return True
     return name.startswith(LIVE_PREFIXES)
 
 
 class CpuTrainer:
     """fwd + 3 losses + autograd bwd + AdamW over a parameter dict (reference semantics)."""
 
-    def __init__(self, params, pad_idx, n_head=8, n_layers=1, lr=1e-3, wd=5e-3):
-        self.p = {k: v.clone().requires_grad_(is_live(k)) for k, v in params.items()}
+    def __init__(self, params, pad_idx, n_head=8, n_layers=1, lr=1e-3, wd=5e-3, bn_state=None, bn_training=True):
+        """bn_state: BatchNorm buffers -> the BN-blend variant (its alpha / bn_* parameters must be in params)."""
+        self.bn_state = None if bn_state is None else {k: v.clone() for k, v in bn_state.items()}
+        self.bn_training = bn_training
+        live = (lambda k: is_live(k, bn=True)) if bn_state is not None else is_live
+        self.p = {k: v.clone().requires_grad_(live(k)) for k, v in params.items()}
         self.pad_idx, self.n_head, self.n_layers = pad_idx, n_head, n_layers
         self.lr, self.wd = lr, wd
         self.m = {k: torch.zeros_like(v) for k, v in self.p.items() if v.requires_grad}
@@ -482,7 +533,8 @@ class CpuTrainer:
         feats, depth, lab, dur, tgt = batch
         for q in self.p.values():
             q.grad = None
-        out, aux = forward(self.p, (feats, lab), depth, "train", self.pad_idx, self.n_head, self.n_layers)
+        out, aux = forward(self.p, (feats, lab), depth, "train", self.pad_idx, self.n_head, self.n_layers,
+                           bn_state=self.bn_state, bn_training=self.bn_training)
         res = losses(out, lab, dur, tgt, self.pad_idx)
         res["loss"].backward()
         if apply:

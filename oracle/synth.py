@@ -64,6 +64,10 @@ def fill_value(name, shape, index):
         v = np.float32(1.0) + np.float32(0.25) * u
     elif is_norm and leaf == "bias":
         v = np.float32(0.1) * u
+    elif name in ("fuser.bn_rgb.weight", "fuser.bn_depth.weight"):      # BN-blend variant: |gamma| is the selection score
+        v = np.float32(1.0) + np.float32(0.5) * u
+    elif name == "fuser.alpha":                                         # blend weight, torch.rand-like range
+        v = np.float32(0.5) + np.float32(0.45) * u
     elif name == "query_embed.weight":
         v = u
     elif name == "pos_embedding":

@@ -4,7 +4,9 @@ import numpy as np
 import pytest
 import torch
 
-from oracle import futr_oracle as O
+import json
+
+from oracle import futr_oracle as O, synth
 from tests.helpers import load_fixture, fixture_params, fixture_batch, stats, assert_close
 
 def check_stats(got, ref, rtol=1e-4):
@@ -89,3 +91,32 @@ def test_scheduler_restatement_shape():
     lrs = [O.warmup_cosine_lr(e, 1e-3, 10, 60) for e in range(60)]
     assert lrs[0] == 0.0 and abs(lrs[9] - 1e-3) < 1e-12 and abs(lrs[10] - 1e-3) < 1e-12
     assert all(lrs[i] >= lrs[i + 1] for i in range(10, 59)) and lrs[59] > 0
+
+
+@pytest.mark.parametrize("tag", ["bn_tiny", "bn_cfg2"])
+def test_oracle_bn_blend_variant_matches_reference_fixture(tag):
+    """The BN-blend fuser (model/futr_safuser_batchnormalization.py): train-state step (batch statistics, running-stat
+    update) and eval-state forward of the oracle against values produced by the imported reference."""
+    fx = load_fixture(tag)
+    m = fx["meta"]
+    batch = [torch.from_numpy(x) for x in synth.make_batch(m["B"], m["S"], m["n_class"], m["pad_idx"], m["seed"],
+                                                           depth_hw=tuple(m["depth_hw"]))]
+    C = m["H"]
+    st0 = {}
+    for pre in ("fuser.bn_rgb.", "fuser.bn_depth."):
+        st0[pre + "running_mean"], st0[pre + "running_var"] = torch.zeros(C), torch.ones(C)
+        st0[pre + "num_batches_tracked"] = torch.zeros((), dtype=torch.long)
+    tr = O.CpuTrainer(fixture_params(fx), m["pad_idx"], m["n_head"], m["n_dec"], bn_state=st0, bn_training=True)
+    res, out, aux = tr.step(batch, apply=False)
+    for k, fk in (("action", "out_action"), ("duration", "out_duration"), ("seg", "out_seg")):
+        assert_close(out[k].detach(), fx[fk], 1e-4, 1e-5, f"{tag}/{k}")
+    assert np.array_equal(np.sort(aux["idx_rgb"].numpy()), fx["idx_rgb"]) and np.array_equal(np.sort(aux["idx_dep"].numpy()), fx["idx_dep"])
+    assert_close(torch.stack([res[k].detach() for k in ("loss_seg", "loss_action", "loss_dur", "loss")]), fx["losses"], 1e-5, 1e-6, "losses")
+    for n in ("fuser.alpha", "fuser.bn_rgb.weight", "fuser.bn_depth.bias"):
+        assert_close(tr.p[n].grad, fx["grad::" + n], 2e-4, 1e-6, f"grad {n}")
+    for n in json.loads(str(fx["buffer_names"])):
+        assert_close(tr.bn_state[n].float(), fx["buf::" + n], 1e-5, 1e-6, n)
+    with torch.no_grad():
+        eo, _ = O.forward(tr.p, (batch[0], batch[2]), batch[1], "train", m["pad_idx"], m["n_head"], m["n_dec"],
+                          bn_state=tr.bn_state, bn_training=False)
+    assert_close(eo["action"], fx["eval_action"], 1e-4, 1e-5, "eval action")
