@@ -250,6 +250,33 @@ int r3d_embed_fuse_bwd(const float* d_h1, const float* x0, const float* m1, cons
                        const float* mean_d, const float* rstd_d, const float* lnd_gamma, const float* lnd_beta,
                        float* d_rgb_pre, float* d_dep_pre, float* ws_n1, float* ws_dep, int N, int H, void* stream);
 
+/* ---- the BN-blend token fuser of model/futr_safuser_batchnormalization.py:38-76 -------------------------
+ * r3d_bn_stats     : BatchNorm1d statistics of both embeddings [N, C] (batch statistics + running-stat update when
+ *                    training, running statistics otherwise) -> mean / rstd [2][C], absgamma [2][C] (selection score).
+ * r3d_bn_blend_fwd : x0 [2N, C] = embd_drop(blend(BN(rgb), BN(dep))) with alpha on the selected channels, h1 = norm1(x0).
+ * r3d_bn_blend_bwd : norm1 backward (+ add1), dropout, blend backward -> five [N, C] term matrices whose column sums
+ *                    (r3d_rowmod_sum_batched, mod = 1) are d beta_rgb, d gamma_rgb, d beta_dep, d gamma_dep, d alpha;
+ *                    norm1 parameter partials ws_n1 [N][2][C] (finalize job with rows = -N).
+ * r3d_bn_bwd_apply : BatchNorm input gradients from those sums; d_rgb_pre includes input_embed's ReLU. */
+int r3d_bn_stats(const float* x_rgb, const float* x_dep, float* run_mean_rgb, float* run_var_rgb, int64_t* nbt_rgb,
+                 float* run_mean_dep, float* run_var_dep, int64_t* nbt_dep, const float* gamma_rgb, const float* gamma_dep,
+                 float* mean, float* rstd, float* absgamma, int N, int C, int training, float momentum, void* stream);
+int r3d_bn_blend_fwd(const float* rgb, const float* dep, const float* mean, const float* rstd, const float* gamma_rgb,
+                     const float* beta_rgb, const float* gamma_dep, const float* beta_dep, const float* alpha,
+                     const float* mask_rgb, const float* mask_dep, const uint8_t* drop_mask, float drop_scale,
+                     const float* ln1_gamma, const float* ln1_beta, float* x0, float* h1, float* m1, float* r1, int N, int C,
+                     void* stream);
+int r3d_bn_blend_bwd(const float* d_h1, const float* x0, const float* m1, const float* r1, const float* ln1_gamma,
+                     const float* add1, const uint8_t* drop_mask, float drop_scale, const float* rgb, const float* dep,
+                     const float* mean, const float* rstd, const float* gamma_rgb, const float* beta_rgb,
+                     const float* gamma_dep, const float* beta_dep, const float* alpha, const float* mask_rgb,
+                     const float* mask_dep, float* t_drb, float* t_drbx, float* t_ddb, float* t_ddbx, float* t_dal,
+                     float* ws_n1, int N, int C, void* stream);
+int r3d_bn_bwd_apply(const float* rgb, const float* dep, const float* mean, const float* rstd, const float* gamma_rgb,
+                     const float* gamma_dep, const float* t_drb, const float* t_ddb, const float* dgamma_rgb,
+                     const float* dbeta_rgb, const float* dgamma_dep, const float* dbeta_dep, float* d_rgb_pre, float* d_dep,
+                     int N, int C, int training, void* stream);
+
 /* ---- the decoder's tail, one launch per direction (row-local on the B*Q query rows) ------------------------------
  * forward : last layer's norm3 (transformer.py:329) -> decoder.norm (:182-183) -> heads fc | fc_len as one [n_head, H]
  *           product (futr_safuser_tokenfusion.py:219-226).  x = pre-norm3 rows [rows, H] contiguous.

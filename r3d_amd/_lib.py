@@ -106,6 +106,10 @@ _SIGNATURES = {
                             _P], C.c_int),
     "r3d_embed_fuse_bwd": ([_P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
                            C.c_int),
+    "r3d_bn_stats": ([_P] * 13 + [_I, _I, _I, _F, _P], C.c_int),
+    "r3d_bn_blend_fwd": ([_P] * 12 + [_F] + [_P] * 6 + [_I, _I, _P], C.c_int),
+    "r3d_bn_blend_bwd": ([_P] * 7 + [_F] + [_P] * 17 + [_I, _I, _P], C.c_int),
+    "r3d_bn_bwd_apply": ([_P] * 14 + [_I, _I, _I, _P], C.c_int),
     "r3d_decoder_tail_fwd": ([_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P], C.c_int),
     "r3d_decoder_tail_bwd": ([_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I,
                               _P], C.c_int),

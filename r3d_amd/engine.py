@@ -27,6 +27,9 @@ EXCLUDE_CLASS_IDX = 47          # hard-coded at train/train_proposed_depth.py:18
 DROP_P = 0.1                    # every nn.Dropout on the path (futr_safuser_tokenfusion.py:26; transformer.py:22)
 
 
+BN_LIVE_PREFIXES = ("fuser.alpha", "fuser.bn_rgb.", "fuser.bn_depth.")    # the BN-blend variant's extra trainable parameters
+
+
 def is_live(name):
     """Parameters that receive a gradient in the reference step; the rest keep grad=None."""
     return name.startswith(LIVE_PREFIXES)
@@ -36,10 +39,11 @@ class ParamArena:
     """Flat arenas; live parameters first (AdamW touches only that prefix), depth_projection.weight last among them
     so that everything else forms one contiguous all-reduce bucket that is ready before the big weight gradient."""
 
-    def __init__(self, named_params, device):
+    def __init__(self, named_params, device, extra_live=()):
         named = list(named_params)
-        live = [(n, p) for n, p in named if is_live(n)]
-        dead = [(n, p) for n, p in named if not is_live(n)]
+        self.is_live = lambda n: is_live(n) or (bool(extra_live) and n.startswith(tuple(extra_live)))
+        live = [(n, p) for n, p in named if self.is_live(n)]
+        dead = [(n, p) for n, p in named if not self.is_live(n)]
 
         def key(item):
             n, p = item
@@ -94,7 +98,7 @@ class ParamArena:
         """Expose the arena gradients as p.grad views (after a fused backward) so that any torch optimiser, gradient
         clipping or inspection code sees them.  Parameters the reference leaves without a gradient keep grad=None."""
         for n, p in named_params:
-            p.grad = self.g(n) if is_live(n) else None
+            p.grad = self.g(n) if self.is_live(n) else None
 
 
 class _Shape:
@@ -107,6 +111,9 @@ class _Shape:
         self.B, self.S, self.N, self.BQ = B, S, N, BQ
         self.rgb, self.dep, self.dep_pre = f(N, H), f(N, H), f(N, H)
         self.mean_d, self.rstd_d = f(N), f(N)
+        if eng.bn:
+            self.bn_mean, self.bn_rstd, self.bn_absg = f(2, H), f(2, H), f(2, H)
+            self.bn_idx = torch.empty(2, max(1, int(H * 0.1)), dtype=torch.int64, device=dev)     # k = int(0.1 C) (:58)
         self.sums = torch.empty(2, H, dtype=torch.float64, device=dev)
         self.idx = torch.empty(2, H // 4, dtype=torch.int64, device=dev)
         self.mask = f(2, H)
@@ -148,6 +155,8 @@ class _Shape:
             self.d_x3, self.d_u, self.d_h1, self.d_h2, self.d_x1, self.d_v, self.d_x0 = (
                 f(2 * N, H), f(2 * N, 4 * H), f(2 * N, H), f(2 * N, H), f(2 * N, H), f(2 * N, H), f(2 * N, H))
             self.d_rgb_pre, self.d_dep, self.d_dep_pre = f(N, H), f(N, H), f(N, H)
+            if eng.bn:                                   # per-element terms of the BatchNorm / alpha parameter gradients
+                self.bn_terms = [f(N, H) for _ in range(5)]
             # dropout keep-masks (one Philox launch fills the whole pool)
             sizes = dict(x0=2 * N * H)
             for l in range(L):
@@ -173,7 +182,10 @@ class FusionEngine:
         self.pad_idx = module.src_pad_idx
         self.P, self.D = module.depth_projection.in_features, module.input_embed.in_features
         assert self.H % 8 == 0 and self.H % self.heads == 0
-        self.arena = ParamArena(list(module.named_parameters()), self.device)
+        # BN-blend fuser variant (model/futr_safuser_batchnormalization.py): BatchNorm on both embeddings, |gamma| scores,
+        # alpha blend, no x_res; it takes the composed (un-paired, un-seamed) path around its own seam kernels
+        self.bn = hasattr(module.fuser, "bn_rgb")
+        self.arena = ParamArena(list(module.named_parameters()), self.device, BN_LIVE_PREFIXES if self.bn else ())
         self.ws = ops.GemmWorkspace(self.device)
         self.ws_side = ops.GemmWorkspace(self.device)
         self.side = torch.cuda.Stream(self.device)      # weight-gradient stream: off the backward's critical path
@@ -184,8 +196,8 @@ class FusionEngine:
         self.use_fused_decoder = False          # decoder.hip (one workgroup per clip and layer): measured 2 % slower than
                                                 # the composed launches at the bench shape since the GEMM epilogue rework
         self.use_fused_tail = True              # last norm3 + decoder.norm + heads (and their adjoints): one launch each
-        self.use_paired_launches = True         # one-layer decoder: independent GEMMs of the two chains share launches
-        self.use_fused_embed = True             # train mode: projections' slab sums + LN + exchange + norm1 in one launch
+        self.use_paired_launches = not self.bn   # one-layer decoder: independent GEMMs of the two chains share launches
+        self.use_fused_embed = not self.bn       # train mode: projections' slab sums + LN + exchange + norm1 in one launch
         self.shapes = {}
         self.train_mask = None            # cached train-mode selection (data independent)
         self.drop_seed = 0x5EED
@@ -231,10 +243,12 @@ class FusionEngine:
         return self.train_mask
 
     # ------------------------------------------------------------------------------------------------------
-    def forward(self, feats, depth, labels, mode="train", training=False, need_grad=True):
+    def forward(self, feats, depth, labels, mode="train", training=False, need_grad=True, bn_training=None):
         """feats [B,S,D] f32, depth [B,S,...] f32 (flattened to [N,P]), labels [B,S] int64 (train mode only).
+        bn_training (BN-blend variant): batch statistics + running-stat update; default = `training`.
         Returns dict of views into the workspace: seg [B,S,K], action [B,Q,K], duration [B,Q] (strided views)."""
         self.forward_begin(feats, depth, labels, mode, training, need_grad)
+        self._fw["bn_training"] = training if bn_training is None else bn_training
         if self._fw["tp"] is not None:
             self._fw["tp"].exchange_forward(self._fw["w"])
         return self.forward_finish()
@@ -357,7 +371,7 @@ class FusionEngine:
             with torch.cuda.stream(s2):
                 sa_block(0, w.tgt0, ws2)
         # ---- token selection + exchange (:33-66)
-        if seam:
+        if seam or self.bn:
             pass
         elif mode == "train":
             idx, mask = self._train_masks(B, S)
@@ -370,7 +384,19 @@ class FusionEngine:
             ops.token_select(H // 4, w.idx, w.mask, score_sum=w.sums, count=count)
             idx, mask = w.idx, w.mask
         # ---- SA-Fuser block in closed form (transformerblock.py:118-135) + x_res + norm + mean (:86-94)
-        if not seam:
+        if self.bn:
+            # BatchNorm statistics (+ running-stat update), |gamma| scores, k = int(0.1 C) smallest, alpha blend + dropout
+            # + norm1 (futr_safuser_batchnormalization.py:45-75,95; transformerblock.py:122)
+            mod = self.module.fuser
+            bt = bool(fw.get("bn_training", False))
+            ops.bn_stats(w.rgb, w.dep, mod.bn_rgb, mod.bn_depth, w.bn_mean, w.bn_rstd, w.bn_absg, bt)
+            ops.token_select(w.bn_idx.shape[1], w.bn_idx, w.mask, score_f=w.bn_absg)
+            idx, mask = w.bn_idx, w.mask
+            ops.bn_blend_fwd(w.rgb, w.dep, w.bn_mean, w.bn_rstd, a.p("fuser.bn_rgb.weight"), a.p("fuser.bn_rgb.bias"),
+                             a.p("fuser.bn_depth.weight"), a.p("fuser.bn_depth.bias"), a.p("fuser.alpha").view(-1), mask[0],
+                             mask[1], dm("x0"), dsc, a.p(pre + "norm1.weight"), a.p(pre + "norm1.bias"), w.x0, w.h1, w.m1,
+                             w.r1)
+        elif not seam:
             ops.token_exchange_fwd(w.rgb, w.dep, mask[0], mask[1], w.x0, drop_mask=dm("x0"), drop_scale=dsc)
             ops.layernorm_fwd(w.x0, a.p(pre + "norm1.weight"), a.p(pre + "norm1.bias"), w.h1, w.m1, w.r1)
         wv = a.p(pre + "attn.qkv.weight")[2 * H:]
@@ -384,7 +410,7 @@ class FusionEngine:
             ops.gemm(GEMM_NT, w.h2, a.p(pre + "mlp.mlp.0.weight"), w.f1, bias=a.p(pre + "mlp.mlp.0.bias"), act=2,
                      pre_out=w.u, ws=self.ws)
             ops.gemm(GEMM_NT, w.f1, a.p(pre + "mlp.mlp.2.weight"), w.x3, bias=a.p(pre + "mlp.mlp.2.bias"), res1=w.x1,
-                     res2=w.x0, ws=self.ws)
+                     res2=None if self.bn else w.x0, ws=self.ws)        # (the BN-blend variant has no x_res, :97,101)
             ops.layernorm_fwd(w.x3, a.p("fuser.norm.weight"), a.p("fuser.norm.bias"), w.y, w.mf, w.rf, pair_out=w.fused)
         # ---- segmentation head (:228-232); with the composed decoder it shares a launch with the layer-0 key/value
         # projection (both read `fused`, neither depends on the other)
@@ -407,7 +433,7 @@ class FusionEngine:
         else:
             self._decoder_unfused(w, key_labels, dm, dsc, multi, main, s2, sa_block, paired)
         self.last = dict(w=w, x_rgb=x_rgb, x_dep=x_dep, mask=mask, idx=idx, drop=drop, mode=mode, tp=tp, seam=seam,
-                         paired=paired)
+                         paired=paired, bn_training=bool(fw.get("bn_training", False)))
         return dict(seg=w.seg.view(B, S, K), action=w.actdur[:, :K].view(B, Q, K), duration=w.actdur[:, K].view(B, Q))
 
     def _forward_paired(self, w, fw, dm, dsc, drop, wv, pre, qpos, pos):
@@ -632,6 +658,15 @@ class FusionEngine:
         Js = [(w.lnp_seam["n1"], -N, H) + j[3:] if j[0] is w.lnp["n1"] else
               ((w.lnp_seam["dep"], -N, H) + j[3:] if j[0] is w.lnp["dep"] else j) for j in J]
         w.ln_group_seam = ops.LnFinalizeGroup(Js)
+        Jb = None
+        if self.bn:                            # norm1's partials come from r3d_bn_blend_bwd (one per frame)
+            Jb = [(w.lnp_seam["n1"], -N, H) + j[3:] if j[0] is w.lnp["n1"] else j for j in J]
+            t = w.bn_terms
+            w.bn_sums = ops.RowsumGroup([(t[0], None, 1, a.g("fuser.bn_rgb.bias").view(1, H)),
+                                         (t[1], None, 1, a.g("fuser.bn_rgb.weight").view(1, H)),
+                                         (t[2], None, 1, a.g("fuser.bn_depth.bias").view(1, H)),
+                                         (t[3], None, 1, a.g("fuser.bn_depth.weight").view(1, H)),
+                                         (t[4], None, 1, a.g("fuser.alpha").view(1, H))])
         R = [(w.d_fused, None, S, a.g("pos_embedding")[0, :S]),
              (w.d_dep_pre, None, 1, a.g("depth_projection.bias").view(1, H)),
              (w.glayers[self.L - 1]["caqin"], w.glayers[self.L - 1]["sain"], Q, a.g("query_embed.weight"))]
@@ -653,7 +688,7 @@ class FusionEngine:
             o = (dg.data_ptr() - a.grads.data_ptr()) // 4
             return (part[:blocks * 2 * Hh].view(blocks, 2 * Hh), None, 1, a.grads[o:o + 2 * Hh].view(1, 2 * Hh))
         w.tail_groups = {}
-        for name, jobs in (("plain", J), ("seam", Js)):
+        for name, jobs in (("plain", J), ("seam", Js)) + ((("bn", Jb),) if Jb is not None else ()):
             conv = [as_rowsum(j) for j in jobs]
             if all(c is not None for c in conv):
                 w.tail_groups[name] = ops.RowsumGroup(R + conv)
@@ -813,6 +848,18 @@ class FusionEngine:
             ops.embed_fuse_bwd(w.d_h1, w.x0, w.m1, w.r1, a.p(pre + "norm1.weight"), w.d_x1, w.d_x3, dmf("x0"), dsc, mask[0],
                                mask[1], w.rgb, w.dep_pre, w.mean_d, w.rstd_d, a.p("depth_layernorm.weight"),
                                a.p("depth_layernorm.bias"), w.d_rgb_pre, w.d_dep_pre, w.lnp_seam["n1"], w.lnp_seam["dep"])
+        elif self.bn:
+            t = w.bn_terms
+            ops.bn_blend_bwd(w.d_h1, w.x0, w.m1, w.r1, a.p(pre + "norm1.weight"), w.d_x1, dmf("x0"), dsc, w.rgb, w.dep,
+                             w.bn_mean, w.bn_rstd, a.p("fuser.bn_rgb.weight"), a.p("fuser.bn_rgb.bias"),
+                             a.p("fuser.bn_depth.weight"), a.p("fuser.bn_depth.bias"), a.p("fuser.alpha").view(-1), mask[0],
+                             mask[1], t[0], t[1], t[2], t[3], t[4], w.lnp_seam["n1"])
+            w.bn_sums.launch()                 # column sums -> d gamma / d beta of both BatchNorms, d alpha
+            ops.bn_bwd_apply(w.rgb, w.dep, w.bn_mean, w.bn_rstd, a.p("fuser.bn_rgb.weight"), a.p("fuser.bn_depth.weight"),
+                             t[0], t[2], a.g("fuser.bn_rgb.weight"), a.g("fuser.bn_rgb.bias"), a.g("fuser.bn_depth.weight"),
+                             a.g("fuser.bn_depth.bias"), w.d_rgb_pre, w.d_dep, st["bn_training"])
+            ln_bwd("dep", w.d_dep, w.dep_pre, w.mean_d, w.rstd_d, "depth_layernorm.weight", "depth_layernorm.bias",
+                   w.d_dep_pre, relu=True)
         else:
             ln_bwd("n1", w.d_h1, w.x0, w.m1, w.r1, pre + "norm1.weight", pre + "norm1.bias", w.d_x0, add1=w.d_x1,
                    add2=w.d_x3)
@@ -826,10 +873,11 @@ class FusionEngine:
         # ---- everything that only feeds parameter gradients: 2 launches + the broadcast-parameter sums
         w.wgrad_group.set_b(w.rgb_wgrad_idx, st["x_rgb"])
         w.wgrad_group.launch()
-        tail = w.tail_groups.get("seam" if st["seam"] else "plain")
+        tail = w.tail_groups.get("bn" if self.bn else ("seam" if st["seam"] else "plain"))
         if tail is not None:               # pos_embedding (:190), depth_projection.bias, query_embed (top layer) and
             tail.launch()                  # every LayerNorm parameter gradient: one launch
         else:
+            assert not self.bn, "BN-blend variant: LayerNorm gradient slots must be adjacent in the arena"
             (w.ln_group_seam if st["seam"] else w.ln_group).launch()
             w.rowsum_group.launch()
         g_qe = a.g("query_embed.weight")

@@ -109,6 +109,8 @@ class FUTR(nn.Module):
     """FUTR(n_class, hidden_dim, src_pad_idx, device, args, n_query=8, n_head=8, num_encoder_layers=6,
     num_decoder_layers=6, query_num=49) -- model/futr_safuser_tokenfusion.py:103-152."""
 
+    _fuser_cls = CMFuser                # (the BN-blend variant swaps in its own fuser, futr_safuser_batchnormalization.py)
+
     def __init__(self, n_class, hidden_dim, src_pad_idx, device, args, n_query=8, n_head=8, num_encoder_layers=6,
                  num_decoder_layers=6, query_num=49, depth_pixels=224 * 224):
         super().__init__()
@@ -134,7 +136,7 @@ class FUTR(nn.Module):
         self.l3_attention = nn.MultiheadAttention(hidden_dim, n_head, batch_first=True)
         self.query_attention = nn.MultiheadAttention(hidden_dim, n_head, batch_first=True)
         self.query_embed = nn.Embedding(self.n_query, hidden_dim)
-        self.fuser = CMFuser(dim=hidden_dim, depth=1, num_heads=n_head)
+        self.fuser = self._fuser_cls(dim=hidden_dim, depth=1, num_heads=n_head)
         self.fc_seg = nn.Linear(hidden_dim, n_class)
         nn.init.xavier_uniform_(self.fc_seg.weight)
         self.fc = nn.Linear(hidden_dim, n_class)
@@ -218,10 +220,6 @@ class _FusedForward(torch.autograd.Function):
         else:
             w.d_seg.copy_(d_seg.reshape(-1, K))
         eng.backward()
-        grads = [eng.arena.g(n).clone() if _is_live(n) else None for n in ctx.names]
+        grads = [eng.arena.g(n).clone() if eng.arena.is_live(n) else None for n in ctx.names]
         return (None,) * 7 + tuple(grads)
 
-
-def _is_live(name):
-    from ..engine import is_live
-    return is_live(name)

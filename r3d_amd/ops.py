@@ -408,6 +408,39 @@ def decoder_layer_fwd(table, B, S, Q, H, heads, pad_idx, drop_scale, n_head_out)
           "r3d_decoder_layer_fwd")
 
 
+def bn_stats(x_rgb, x_dep, bn_rgb, bn_dep, mean, rstd, absg, training, momentum=0.1):
+    """bn_rgb / bn_dep: the nn.BatchNorm1d parameter / buffer holders (weight, running_mean, running_var, num_batches_tracked)."""
+    N, Cc = x_rgb.shape
+    check(_lib.load().r3d_bn_stats(_p(x_rgb), _p(x_dep), _p(bn_rgb.running_mean), _p(bn_rgb.running_var),
+                                   _p(bn_rgb.num_batches_tracked), _p(bn_dep.running_mean), _p(bn_dep.running_var),
+                                   _p(bn_dep.num_batches_tracked), _p(bn_rgb.weight), _p(bn_dep.weight), _p(mean), _p(rstd),
+                                   _p(absg), N, Cc, 1 if training else 0, momentum, _stream()), "r3d_bn_stats")
+
+
+def bn_blend_fwd(rgb, dep, mean, rstd, g_r, b_r, g_d, b_d, alpha, m_rgb, m_dep, drop, drop_scale, ln1_g, ln1_b, x0, h1, m1, r1):
+    N, Cc = rgb.shape
+    check(_lib.load().r3d_bn_blend_fwd(_p(rgb), _p(dep), _p(mean), _p(rstd), _p(g_r), _p(b_r), _p(g_d), _p(b_d), _p(alpha),
+                                       _p(m_rgb), _p(m_dep), _p(drop), drop_scale, _p(ln1_g), _p(ln1_b), _p(x0), _p(h1),
+                                       _p(m1), _p(r1), N, Cc, _stream()), "r3d_bn_blend_fwd")
+
+
+def bn_blend_bwd(d_h1, x0, m1, r1, ln1_g, add1, drop, drop_scale, rgb, dep, mean, rstd, g_r, b_r, g_d, b_d, alpha, m_rgb, m_dep,
+                 t0, t1, t2, t3, t4, ws_n1):
+    N, Cc = rgb.shape
+    assert ws_n1.numel() >= 2 * N * Cc
+    check(_lib.load().r3d_bn_blend_bwd(_p(d_h1), _p(x0), _p(m1), _p(r1), _p(ln1_g), _p(add1), _p(drop), drop_scale, _p(rgb),
+                                       _p(dep), _p(mean), _p(rstd), _p(g_r), _p(b_r), _p(g_d), _p(b_d), _p(alpha), _p(m_rgb),
+                                       _p(m_dep), _p(t0), _p(t1), _p(t2), _p(t3), _p(t4), _p(ws_n1), N, Cc, _stream()),
+          "r3d_bn_blend_bwd")
+
+
+def bn_bwd_apply(rgb, dep, mean, rstd, g_r, g_d, t_drb, t_ddb, dg_r, db_r, dg_d, db_d, d_rgb_pre, d_dep, training):
+    N, Cc = rgb.shape
+    check(_lib.load().r3d_bn_bwd_apply(_p(rgb), _p(dep), _p(mean), _p(rstd), _p(g_r), _p(g_d), _p(t_drb), _p(t_ddb), _p(dg_r),
+                                       _p(db_r), _p(dg_d), _p(db_d), _p(d_rgb_pre), _p(d_dep), N, Cc, 1 if training else 0,
+                                       _stream()), "r3d_bn_bwd_apply")
+
+
 def decoder_tail_fwd(x, g3, b3, gF, bF, w_head, b_head, t3, m3, r3, tgtF, mF, rF, out):
     rows, H = x.shape
     assert x.is_contiguous() and t3.is_contiguous() and tgtF.is_contiguous()
