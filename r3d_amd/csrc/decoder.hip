@@ -177,7 +177,6 @@ struct DecFwdArgs {
     const float *fin_g, *fin_b; float *tgtF, *mF, *rF;
     const float *head_w, *head_b; float* actdur; int n_head_out;
     int B, S, Q, H, heads;
-    int dbg_stop;      // diagnostic only (env R3D_DEC_STOP): return after phase N
 };
 
 __device__ __forceinline__ float keepf(const uint8_t* m, size_t idx, float scale) { return m ? scale * (float)m[idx] : 1.f; }
@@ -224,7 +223,6 @@ __global__ __launch_bounds__(DEC_THREADS) void decoder_layer_fwd_kernel(const De
     for (int j = tid; j < S; j += DEC_THREADS)
         KMASK[j] = (a.key_label && a.key_label[rowS + j] == (int64_t)a.pad_idx) ? 1.f : 0.f;
     __syncthreads();
-    if (a.dbg_stop == 1) return;
     // ---- self attention in_proj: WIDE[16][3H] = XA . Win^T + b
     mm16_nt(XA, LD, H, a.p.sa_in_w, H, 3 * H, RED, [&](int r, int c, float v) {
         v += a.p.sa_in_b[c];
@@ -232,7 +230,6 @@ __global__ __launch_bounds__(DEC_THREADS) void decoder_layer_fwd_kernel(const De
         if (r < Q) a.sa_qkv[(rowQ + r) * 3 * H + c] = v;
     });
     __syncthreads();
-    if (a.dbg_stop == 2) return;
     // ---- 8x8 attention per head: PR[h][i][j]
     const float scale = 1.0f / sqrtf((float)dh);
     for (int e = tid; e < heads * Q * Q; e += DEC_THREADS) {
@@ -265,7 +262,6 @@ __global__ __launch_bounds__(DEC_THREADS) void decoder_layer_fwd_kernel(const De
         a.sa_o[(rowQ + i) * H + c] = s;
     }
     __syncthreads();
-    if (a.dbg_stop == 3) return;
     // ---- out_proj + dropout1 + residual -> t1_pre (in XB)
     mm16_nt(XA, LD, H, a.p.sa_out_w, H, H, RED, [&](int r, int c, float v) {
         if (r < Q) {
@@ -275,7 +271,6 @@ __global__ __launch_bounds__(DEC_THREADS) void decoder_layer_fwd_kernel(const De
         }
     });
     __syncthreads();
-    if (a.dbg_stop == 4) return;
     // ---- LN1 -> t1 in XB (residual for the next sub-layer), XA = t1 + query_pos
     ln_rows(XB, LD, Q, H, a.p.n1_g, a.p.n1_b, a.m1 + rowQ, a.r1 + rowQ, [&](int r, int c, float v) {
         XB[r * LD + c] = v;
@@ -283,7 +278,6 @@ __global__ __launch_bounds__(DEC_THREADS) void decoder_layer_fwd_kernel(const De
         a.t1[(rowQ + r) * H + c] = v;
     });
     __syncthreads();
-    if (a.dbg_stop == 5) return;
     // ---- cross attention: q = XA . Wq^T + bq -> WIDE[:, 0:H];  k|v rows = KIN . Wkv^T + bkv -> KV
     mm16_nt(XA, LD, H, a.p.ca_in_w, H, H, RED, [&](int r, int c, float v) {
         v += a.p.ca_in_b[c];
@@ -298,7 +292,6 @@ __global__ __launch_bounds__(DEC_THREADS) void decoder_layer_fwd_kernel(const De
         });
     }
     __syncthreads();
-    if (a.dbg_stop == 6) return;
     for (int e = tid; e < heads * Q * S; e += DEC_THREADS) {
         const int h = e / (Q * S), i = (e / S) % Q, j = e % S;
         float s = 0.f;
@@ -328,7 +321,6 @@ __global__ __launch_bounds__(DEC_THREADS) void decoder_layer_fwd_kernel(const De
         a.ca_o[(rowQ + i) * H + c] = s;
     }
     __syncthreads();
-    if (a.dbg_stop == 7) return;
     mm16_nt(XA, LD, H, a.p.ca_out_w, H, H, RED, [&](int r, int c, float v) {
         if (r < Q) {
             v = (v + a.p.ca_out_b[c]) * keepf(a.drop_d2, (rowQ + r) * H + c, dsc) + XB[r * LD + c];
@@ -343,7 +335,6 @@ __global__ __launch_bounds__(DEC_THREADS) void decoder_layer_fwd_kernel(const De
         a.t2[(rowQ + r) * H + c] = v;
     });
     __syncthreads();
-    if (a.dbg_stop == 8) return;
     // ---- FFN: ff1 = drop(relu(t2 . W1^T + b1)) -> WIDE[16][4H];  t3_pre = t2 + drop3(ff1 . W2^T + b2)
     mm16_nt(XA, LD, H, a.p.l1_w, H, 4 * H, RED, [&](int r, int c, float v) {
         v = fmaxf(v + a.p.l1_b[c], 0.f);
@@ -356,7 +347,6 @@ __global__ __launch_bounds__(DEC_THREADS) void decoder_layer_fwd_kernel(const De
         WIDE[r * LDW + c] = v;
     });
     __syncthreads();
-    if (a.dbg_stop == 9) return;
     mm16_nt(WIDE, LDW, 4 * H, a.p.l2_w, 4 * H, H, RED, [&](int r, int c, float v) {
         if (r < Q) {
             v = (v + a.p.l2_b[c]) * keepf(a.drop_d3, (rowQ + r) * H + c, dsc) + XB[r * LD + c];
@@ -365,7 +355,6 @@ __global__ __launch_bounds__(DEC_THREADS) void decoder_layer_fwd_kernel(const De
         }
     });
     __syncthreads();
-    if (a.dbg_stop == 10) return;
     ln_rows(XB, LD, Q, H, a.p.n3_g, a.p.n3_b, a.m3 + rowQ, a.r3 + rowQ, [&](int r, int c, float v) {
         XB[r * LD + c] = v;
         a.t3[(rowQ + r) * H + c] = v;
@@ -426,7 +415,6 @@ R3D_EXPORT int r3d_decoder_layer_fwd(const void* const* ptrs, int nptrs, int B, 
     if (a.fin_g) R3D_REQUIRE(a.fin_b && a.tgtF && a.mF && a.rF && a.head_w && a.head_b && a.actdur && n_head_out > 0);
     a.pad_idx = pad_idx; a.drop_scale = drop_scale; a.n_head_out = n_head_out;
     a.B = B; a.S = S; a.Q = Q; a.H = H; a.heads = heads;
-    { const char* e = getenv("R3D_DEC_STOP"); a.dbg_stop = e ? atoi(e) : 0; }
     const size_t lds = dec_fwd_lds_bytes(S, Q, H, heads);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)decoder_layer_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
