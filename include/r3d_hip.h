@@ -327,7 +327,10 @@ int r3d_erank_jacobi(const float* x, int ld, int64_t batch_stride, int batch, in
 int r3d_erank_blocked_sizes(int R, int C, int max_sweeps, int64_t* out);
 int r3d_erank_blocked(const float* x, int ld, int R, int C, float* sigma, float* af_t, int* ctrl, float* stats,
                       int max_sweeps, void* stream);
-int r3d_erank_bwd_coef(const float* sigma, const float* stats, const float* gout, float* coef, int C, void* stream);
+/* coef[k] = gout * d erank / d sigma_k / sigma_k^3; zero for negligible sigma and, with max_rank = min(R, C) > 0, for
+ * everything but the max_rank largest (a rank-deficient X has no defined singular vectors beyond its rank). */
+int r3d_erank_bwd_coef(const float* sigma, const float* stats, const float* gout, float* coef, int C, int max_rank,
+                       void* stream);
 int r3d_scale_rows(float* x, int ld, int rows, int cols, const float* coef, void* stream);
 
 #ifdef __cplusplus

@@ -124,7 +124,7 @@ _SIGNATURES = {
     "r3d_erank_jacobi": ([_P, _I, _L, _I, _I, _I, _I, _P, _P, _P, _I, _P], C.c_int),
     "r3d_erank_blocked_sizes": ([_I, _I, _I, _P], C.c_int),
     "r3d_erank_blocked": ([_P, _I, _I, _I, _P, _P, _P, _P, _I, _P], C.c_int),
-    "r3d_erank_bwd_coef": ([_P, _P, _P, _P, _I, _P], C.c_int),
+    "r3d_erank_bwd_coef": ([_P, _P, _P, _P, _I, _I, _P], C.c_int),
     "r3d_scale_rows": ([_P, _I, _I, _I, _P, _P], C.c_int),
 }
 

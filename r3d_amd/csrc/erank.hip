@@ -291,15 +291,19 @@ __global__ __launch_bounds__(64 * kJacWaves) void erank_blk_finish_kernel(ErankB
 // coef[k] = gout * d erank / d sigma_k / sigma_k^3, zero where sigma_k is negligible (rank-deficient directions
 // carry no defined singular vectors; p log p -> 0 there: SURVEY.md Appendix A.11)
 __global__ __launch_bounds__(256) void erank_coef_kernel(const float* sigma, const float* stats, const float* gout,
-                                                         float* coef, int C) {
+                                                         float* coef, int C, int max_rank) {
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= C) return;
     const float er = stats[0], H = stats[1], total = stats[2];
     const float s = sigma[k];
     float smax = 0.f;
-    for (int j = 0; j < C; ++j) smax = fmaxf(smax, sigma[j]);
+    int larger = 0;                      // singular values above this one: only the min(R, C) largest are real
+    for (int j = 0; j < C; ++j) {
+        smax = fmaxf(smax, sigma[j]);
+        larger += (sigma[j] > s || (sigma[j] == s && j < k)) ? 1 : 0;
+    }
     float c = 0.f;
-    if (s > 1e-6f * smax && s > 0.f) {
+    if (s > 1e-6f * smax && s > 0.f && (max_rank <= 0 || larger < max_rank)) {
         const float p = s / total;
         const float g = -er * (logf(p) + H) / total;
         c = (gout ? *gout : 1.f) * g / (s * s * s);
@@ -397,10 +401,10 @@ R3D_EXPORT int r3d_erank_blocked(const float* x, int ld, int R, int C, float* si
 
 /* coef[k] = (*gout) * (d erank / d sigma_k) / sigma_k^3  for the backward  dX = Af diag(coef) (Af^T X). */
 R3D_EXPORT int r3d_erank_bwd_coef(const float* sigma, const float* stats, const float* gout, float* coef, int C,
-                                  void* stream) {
+                                  int max_rank, void* stream) {
     R3D_REQUIRE(sigma && stats && coef && C > 0);
     hipLaunchKernelGGL(erank_coef_kernel, dim3(r3d_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, sigma, stats, gout,
-                       coef, C);
+                       coef, C, max_rank);
     R3D_LAUNCH_CHECK();
     return R3D_OK;
 }

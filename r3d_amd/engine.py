@@ -198,6 +198,8 @@ class FusionEngine:
         self.use_fused_tail = True              # last norm3 + decoder.norm + heads (and their adjoints): one launch each
         self.use_paired_launches = not self.bn   # one-layer decoder: independent GEMMs of the two chains share launches
         self.use_fused_embed = not self.bn       # train mode: projections' slab sums + LN + exchange + norm1 in one launch
+        self.erank_weight = 0.0           # > 0: total loss -= erank_weight * effective_rank(fused token matrix) (build-side
+                                          # rank-enhancing penalty; the reference only describes it, README.md:8-14)
         self.shapes = {}
         self.train_mask = None            # cached train-mode selection (data independent)
         self.drop_seed = 0x5EED
@@ -432,9 +434,36 @@ class FusionEngine:
             self._decoder_fused(w, key_labels, drop, dsc)
         else:
             self._decoder_unfused(w, key_labels, dm, dsc, multi, main, s2, sa_block, paired)
-        self.last = dict(w=w, x_rgb=x_rgb, x_dep=x_dep, mask=mask, idx=idx, drop=drop, mode=mode, tp=tp, seam=seam,
+        er = self.erank_weight != 0.0 and hasattr(w, "glayers")
+        if er:
+            self._erank_forward(w)
+        self.last = dict(w=w, x_rgb=x_rgb, x_dep=x_dep, mask=mask, idx=idx, drop=drop, mode=mode, tp=tp, seam=seam, erank=er,
                          paired=paired, bn_training=bool(fw.get("bn_training", False)))
         return dict(seg=w.seg.view(B, S, K), action=w.actdur[:, :K].view(B, Q, K), duration=w.actdur[:, K].view(B, Q))
+
+    # ---- effective-rank penalty on the fused token matrix [N, H] (erank.hip; Appendix A.11) ------------------------------
+    def _erank_forward(self, w):
+        N, H = w.N, self.H
+        if not hasattr(w, "er_sigma"):
+            f = lambda *s: torch.empty(*s, dtype=torch.float32, device=self.device)     # noqa: E731
+            if not ops.erank_fits(N, H):
+                raise NotImplementedError("erank_weight: the fused [N, H] matrix must fit one CU's LDS "
+                                          f"({N}x{H}); use r3d_amd.erank.effective_rank for measurement at this size")
+            w.er_sigma, w.er_stats, w.er_af = f(1, H), f(1, 4), f(1, H, N)
+            w.er_coef, w.er_t1, w.er_gout = f(H), f(H, H), f(1)
+        ops.erank_jacobi(w.fused, w.er_sigma, w.er_stats, af_t=w.er_af)
+
+    def _erank_backward(self, w, ws):
+        """d_fused2 += d(-erank_weight * erank)/d(fused) = Af diag(coef) (Af^T X): two GEMMs and a row scale."""
+        w.er_gout.fill_(-float(self.erank_weight))
+        ops.erank_bwd_coef(w.er_sigma[0], w.er_stats[0], w.er_gout, w.er_coef, max_rank=min(w.N, self.H))
+        ops.gemm(GEMM_NN, w.er_af[0], w.fused, w.er_t1, ws=ws)
+        ops.scale_rows(w.er_t1, w.er_coef)
+        ops.gemm(GEMM_TN, w.er_af[0], w.er_t1, w.d_fused2, accumulate=True, ws=ws)
+
+    def erank_value(self):
+        """Effective rank of the last forward's fused tokens (device scalar; valid when erank_weight != 0)."""
+        return self.last["w"].er_stats[0, 0]
 
     def _forward_paired(self, w, fw, dm, dsc, drop, wv, pre, qpos, pos):
         """Fuser block (transformerblock.py:118-135, :86-94) interleaved with the layer-0 query self-attention sub-layer
@@ -819,6 +848,8 @@ class FusionEngine:
                                             dict(a=w.d_u, b=a.p(pre + "mlp.mlp.0.weight"), c=w.d_h2)], tile=t))
             gb1, gb2, gb3 = w.tables[key]
             gb1.launch()
+            if st.get("erank"):
+                self._erank_backward(w, ws)
             def lnj(site, dy, x, mean, rstd, gname, bname, dx, **kw):
                 return dict(dy=dy, x=x, mean=mean, rstd=rstd, gamma=a.p(gname), beta=a.p(bname), dx=dx, dgamma=a.g(gname),
                             dbeta=a.g(bname), partial=w.lnp[site], **kw)
@@ -833,6 +864,8 @@ class FusionEngine:
                              drop_mask=dmf("sa_p0"), drop_scale=dsc)
             gb3.launch()
         else:
+            if st.get("erank"):
+                self._erank_backward(w, ws)
             ln_bwd("nf", w.d_fused, w.x3, w.mf, w.rf, "fuser.norm.weight", "fuser.norm.bias", w.d_x3, pair_in=True,
                    dy2=w.d_fused2)
             ops.gemm(GEMM_NN, w.d_x3, a.p(pre + "mlp.mlp.2.weight"), w.d_u, aux=w.u, mul=2, ws=ws)

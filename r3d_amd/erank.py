@@ -29,7 +29,7 @@ class _ERank(torch.autograd.Function):
         x, sigma, stats, af_t = ctx.saved_tensors
         R, C = x.shape
         coef = torch.empty(C, dtype=torch.float32, device=x.device)
-        ops.erank_bwd_coef(sigma[0], stats[0], gout.contiguous().reshape(1).float(), coef)
+        ops.erank_bwd_coef(sigma[0], stats[0], gout.contiguous().reshape(1).float(), coef, max_rank=min(R, C))
         ws = ops.GemmWorkspace(x.device)
         t1 = torch.empty(C, C, dtype=torch.float32, device=x.device)
         ops.gemm(GEMM_NN, af_t[0], x, t1, ws=ws)            # Af^T X = Sigma^2 V^T
@@ -58,7 +58,7 @@ class _ERankBlocked(torch.autograd.Function):
         R, C = xx.shape
         af = af_t[:C]
         coef = torch.empty(C, dtype=torch.float32, device=xx.device)
-        ops.erank_bwd_coef(sigma, stats, gout.contiguous().reshape(1).float(), coef)
+        ops.erank_bwd_coef(sigma, stats, gout.contiguous().reshape(1).float(), coef, max_rank=min(R, C))
         ws = ops.GemmWorkspace(xx.device)
         t1 = torch.empty(C, C, dtype=torch.float32, device=xx.device)
         ops.gemm(GEMM_NN, af, xx, t1, ws=ws)

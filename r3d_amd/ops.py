@@ -572,9 +572,11 @@ def erank_blocked(x, max_sweeps=30):
     return sigma, stats, af_t
 
 
-def erank_bwd_coef(sigma, stats, gout, coef):
+def erank_bwd_coef(sigma, stats, gout, coef, max_rank=0):
+    """max_rank = min(R, C) of the decomposed matrix: singular values beyond it are rounding noise."""
     lib = _lib.load()
-    check(lib.r3d_erank_bwd_coef(_p(sigma), _p(stats), _p(gout), _p(coef), sigma.numel(), _stream()), "r3d_erank_bwd_coef")
+    check(lib.r3d_erank_bwd_coef(_p(sigma), _p(stats), _p(gout), _p(coef), sigma.numel(), max_rank, _stream()),
+          "r3d_erank_bwd_coef")
 
 
 def scale_rows(x, coef):

@@ -101,6 +101,7 @@ def train(args, model, train_loader, optimizer, scheduler, criterion, model_save
     is_main = dp is None or dp.rank == 0
     min_batch = getattr(args, "min_batch", 8)
     erank_every = getattr(args, "erank_every", 0)
+    eng.erank_weight = float(getattr(args, "erank_weight", 0.0))
     print("Training Start")
     best_val_loss = float("inf")
     best_val_acc = 0

@@ -353,3 +353,31 @@ def test_dropout_prefill_in_adamw_launch_gives_the_same_masks():
         torch.cuda.synchronize()
         outs.append((eng.arena.params.clone(), eng.last["w"].drop_pool.clone(), eng.last["w"].loss.clone()))
     assert torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][0], outs[1][0])
+
+
+@pytest.mark.parametrize("tag,paired", [("step_cfg2", True), ("step_cfg2", False), ("step_tiny", True)])
+def test_effective_rank_penalty_gradients(tag, paired, oracle_lib):
+    """erank_weight: total loss = L - w * erank(fused tokens).  Every gradient against autograd through
+    torch.linalg.svdvals on the oracle (the reference has no such term: SURVEY F1, build-side definition)."""
+    lam = 0.05
+    fx = load_fixture(tag)
+    m = fx["meta"]
+    batch = fixture_batch(fx)
+    tr = O.CpuTrainer(fixture_params(fx), m["pad_idx"], m["n_head"], m["n_dec"])
+    out, aux = O.forward(tr.p, (batch[0], batch[2]), batch[1], "train", m["pad_idx"], m["n_head"], m["n_dec"])
+    res = O.losses(out, batch[2], batch[3], batch[4], m["pad_idx"])
+    er = O.effective_rank_torch(aux["fused"].reshape(-1, m["H"]).double())
+    (res["loss"] - lam * er.float()).backward()
+    model = build_model(fx).eval()
+    eng = model.engine()
+    eng.erank_weight = lam
+    eng.use_paired_launches = paired
+    d = [t.cuda() for t in batch]
+    eng.forward(d[0], d[1], d[2], "train", training=False)
+    eng.losses(d[2], d[4], d[3])
+    eng.backward()
+    torch.cuda.synchronize()
+    assert abs(float(eng.erank_value()) - float(er)) < 5e-3 * max(1.0, float(er) / 50)
+    for n, p in tr.p.items():
+        if p.grad is not None:
+            close_rel(eng.arena.g(n), p.grad, f"{tag}/erank-penalised grad {n}", rtol=3e-3)
