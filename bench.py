@@ -41,12 +41,15 @@ def make_inputs(c, device, seed):
     return [t.to(device) for t in (feats, depth, lab, dur, tgt)]
 
 
-def build_model(c, device):
-    from r3d_amd.model.futr_safuser_tokenfusion import FUTR
+def build_model(c, device, variant="tokenfusion"):
+    if variant == "bn":               # the BN-blend fuser (futr_safuser_batchnormalization), same workload shape
+        from r3d_amd.model.futr_safuser_batchnormalization import FUTR
+    else:
+        from r3d_amd.model.futr_safuser_tokenfusion import FUTR
     args = argparse.Namespace(input_dim=c["D"], seg=True, anticipate=True, max_pos_len=2000, input_type="i3d_transcript")
     torch.manual_seed(1)
     m = FUTR(c["K"], c["H"], c["K"] + 1, device, args, n_query=c["Q"], n_head=c["heads"], num_encoder_layers=c["n_enc"],
-             num_decoder_layers=c["n_dec"]).to(device)
+             num_decoder_layers=c["n_dec"], depth_pixels=c["P"]).to(device)
     return m.train()
 
 
@@ -153,6 +156,8 @@ def main():
     ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"],
                     help="cfg2 = the headline workload; the others (per-GPU shapes of BASELINE.json configs[2..4]) are "
                          "for profiling")
+    ap.add_argument("--variant", default="tokenfusion", choices=["tokenfusion", "bn"],
+                    help="tokenfusion = the headline model (BASELINE.json); bn = the BN-blend fuser variant, profiling only")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the "
                                                       "multi-rank control flow on one GPU)")
     a = ap.parse_args()
@@ -172,7 +177,7 @@ def main():
         else:
             dist.init_process_group(a.backend)
     c = dict(CFG, **OTHER.get(a.config, {}))
-    model = build_model(c, device)
+    model = build_model(c, device, a.variant)
     if a.eval_dropout_off:
         model.eval()
     eng = model.engine()
@@ -374,7 +379,9 @@ def main():
                    kernels={k: dict(us=v["seconds"] * 1e6, GBps=v["bytes"] / v["seconds"] / 1e9,
                                     TFLOPs=v["flops"] / v["seconds"] / 1e12) for k, v in kr.items()},
                    final_losses=loss_now)
-        if world == 1 and not a.no_cpu_baseline and a.config == "cfg2":
+        if a.variant != "tokenfusion":
+            out["config"]["workload"] += f" [{a.variant} fuser variant: profiling only, not the headline model]"
+        if world == 1 and not a.no_cpu_baseline and a.config == "cfg2" and a.variant == "tokenfusion":
             out["cpu_baseline"] = cpu_baseline(c)
         print(json.dumps(out), flush=True)
     if world > 1:
