@@ -225,7 +225,7 @@ def main():
                 ok.zero_()
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if float(ok.item()) < 1.0:
-                model = build_model(c, device)
+                model = build_model(c, device, a.variant)
                 if a.eval_dropout_off:
                     model.eval()
                 eng = model.engine()
