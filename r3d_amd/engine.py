@@ -196,7 +196,7 @@ class FusionEngine:
         self.use_fused_decoder = False          # decoder.hip (one workgroup per clip and layer): measured 2 % slower than
                                                 # the composed launches at the bench shape since the GEMM epilogue rework
         self.use_fused_tail = True              # last norm3 + decoder.norm + heads (and their adjoints): one launch each
-        self.use_paired_launches = not self.bn   # one-layer decoder: independent GEMMs of the two chains share launches
+        self.use_paired_launches = True          # one-layer decoder: independent GEMMs of the two chains share launches
         self.use_fused_embed = not self.bn       # train mode: projections' slab sums + LN + exchange + norm1 in one launch
         self.erank_weight = 0.0           # > 0: total loss -= erank_weight * effective_rank(fused token matrix) (build-side
                                           # rank-enhancing penalty; the reference only describes it, README.md:8-14)
@@ -497,7 +497,7 @@ class FusionEngine:
         ops.layernorm_fwd(w.x1, a.p(pre + "norm2.weight"), a.p(pre + "norm2.bias"), w.h2, w.m2, w.r2)
         g2.launch()
         ops.gemm(GEMM_NT, w.f1, a.p(pre + "mlp.mlp.2.weight"), w.x3, bias=a.p(pre + "mlp.mlp.2.bias"), res1=w.x1,
-                 res2=w.x0, ws=self.ws)
+                 res2=None if self.bn else w.x0, ws=self.ws)          # (no x_res in the BN-blend variant)
         ops.layernorm_fwd_multi([                      # decoder norm1 and the fuser's final norm + token mean: one launch
             dict(x=c["t1_pre"], gamma=a.p(pl + "norm1.weight"), beta=a.p(pl + "norm1.bias"), y=c["t1"], mean=c["m1"],
                  rstd=c["r1"]),
