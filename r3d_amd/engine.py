@@ -198,6 +198,9 @@ class FusionEngine:
         self.use_fused_tail = True              # last norm3 + decoder.norm + heads (and their adjoints): one launch each
         self.use_paired_launches = True          # one-layer decoder: independent GEMMs of the two chains share launches
         self.use_fused_embed = not self.bn       # train mode: projections' slab sums + LN + exchange + norm1 in one launch
+        # False: train()-state steps without dropout (parity runs against a reference whose dropout probabilities were
+        # set to 0; RNG streams cannot match).  Read from the module so that it survives model.to() re-creating the engine.
+        self.dropout_enabled = bool(getattr(module, "r3d_dropout_enabled", True))
         self.erank_weight = 0.0           # > 0: total loss -= erank_weight * effective_rank(fused token matrix) (build-side
                                           # rank-enhancing penalty; the reference only describes it, README.md:8-14)
         self.shapes = {}
@@ -267,7 +270,7 @@ class FusionEngine:
         assert x_rgb.shape[1] == self.D and x_dep.shape[1] == self.P, (x_rgb.shape, x_dep.shape, self.D, self.P)
         assert x_rgb.is_contiguous() and x_dep.is_contiguous()
         w = self._shape(B, S, need_grad)
-        drop = training and need_grad
+        drop = training and need_grad and self.dropout_enabled
         if drop:
             if self._drop_ready is w:     # the previous step's AdamW launch already filled the pool for this offset
                 self._drop_ready = None

@@ -52,3 +52,41 @@ def test_input_prefetcher_feeds_the_same_training(tmp_path):
         torch.cuda.synchronize()
         finals.append(model.engine().arena.params.clone())
     assert torch.equal(finals[0], finals[1])
+
+
+def test_train_harness_matches_reference_capture(tmp_path, capsys):
+    """r3d_amd.train_proposed_depth.train() -- loop, epoch prints, validate(), checkpoint-on-improve -- against the capture
+    of the reference's own train() on the same batches (tests/golden/train_loop.npz: its stdout, validate() result and
+    checkpoint files; dropout probabilities 0 on both sides, AdamW lr 1e-3 / wd 5e-3, no-op scheduler)."""
+    import json
+    import os
+    import re
+    from r3d_amd.train_proposed_depth import train
+    from r3d_amd.optim import FlatAdamW
+    fx = load_fixture("train_loop")
+    m = fx["meta"]
+    batches = [fixture_batch(fx, seed=m["seed"] + i) for i in range(m["n_steps"])]
+    from oracle import synth
+    val = [[torch.from_numpy(x) for x in synth.make_batch(1, m["val_S"], m["n_class"], m["pad_idx"], m["seed"] + 100,
+                                                          pad_tail=False)]]
+    model = build_model(fx)
+    model.r3d_dropout_enabled = False
+    args = argparse.Namespace(epochs=1, input_type="i3d_transcript", seg=True, anticipate=True, task="long")
+
+    class NoSched:
+        def step(self):
+            pass
+    opt = FlatAdamW(model.parameters(), 1e-3, weight_decay=5e-3)
+    train(args, model, batches, opt, NoSched(), None, str(tmp_path), m["pad_idx"], torch.device("cuda"), val, seed=1)
+    out = capsys.readouterr().out
+    ref = json.loads(str(fx["stdout"]))
+    nums = lambda s: [float(x) for x in re.findall(r"-?[0-9]+[.][0-9]+", s)]          # noqa: E731
+    ref_lines, got_lines = ref.strip().splitlines(), out.strip().splitlines()
+    assert len(ref_lines) == len(got_lines), (ref, out)
+    for rl, gl in zip(ref_lines, got_lines):
+        assert re.sub(r"-?[0-9]+[.][0-9]+", "#", rl) == re.sub(r"-?[0-9]+[.][0-9]+", "#", gl), (rl, gl)     # same text
+        for a, b in zip(nums(rl), nums(gl)):
+            assert abs(a - b) <= 2e-3 * max(1.0, abs(a)) + 1.5e-3, (rl, gl)                      # 3-decimal prints
+    assert sorted(os.listdir(tmp_path)) == fx["ckpt_files"]
+    sd = torch.load(os.path.join(tmp_path, "seed_1_best.ckpt"), weights_only=True)
+    assert list(sd.keys()) == fx["ckpt_keys"]
