@@ -60,6 +60,8 @@ class PixelShardedDepth:
         self.equal = equal_batches
         self.native_a2a = dist.get_backend(process_group) == "nccl"
         self.gemm = ops.gemm              # (tests substitute a CPU stand-in to rehearse the exchange logic)
+        self.native_gather = self.native_a2a          # all_gather_into_tensor (RCCL); falls back to the all-reduce form
+        self.in_stream = torch.cuda.Stream(engine.device) if engine.device.type == "cuda" else None
         self.bufs = {}
         self.ready = {}                   # data_ptr of a depth batch -> its exchanged shard (prefetched)
         engine.tp = self
@@ -89,12 +91,19 @@ class PixelShardedDepth:
         work = None
         if self.native_a2a:
             send = self._buf(("send", N, slot), (W, N, Pr))
-            send.copy_(x_dep.view(N, W, Pr).transpose(0, 1))
-            if all(r == N for r in rows):
-                work = dist.all_to_all_single(recv, send.view(W * N, Pr), group=self.pg_in, async_op=async_op)
-            else:
-                work = dist.all_to_all_single(recv, send.view(W * N, Pr), output_split_sizes=rows,
-                                              input_split_sizes=[N] * W, group=self.pg_in, async_op=async_op)
+            # a prefetch (async_op) does its 25.7 MB re-layout copy on a side stream too: nothing of it sits on the step's
+            # critical path
+            side = self.in_stream if (async_op and self.in_stream is not None) else None
+            cur = torch.cuda.current_stream() if side is not None else None
+            if side is not None:
+                side.wait_stream(cur)
+            with torch.cuda.stream(side) if side is not None else _null():
+                send.copy_(x_dep.view(N, W, Pr).transpose(0, 1))
+                if all(r == N for r in rows):
+                    work = dist.all_to_all_single(recv, send.view(W * N, Pr), group=self.pg_in, async_op=async_op)
+                else:
+                    work = dist.all_to_all_single(recv, send.view(W * N, Pr), output_split_sizes=rows,
+                                                  input_split_sizes=[N] * W, group=self.pg_in, async_op=async_op)
         else:                             # backends without all-to-all (gloo rehearsal): W broadcasts
             off = 0
             for j in range(W):
@@ -140,6 +149,13 @@ class PixelShardedDepth:
         sh = w.tp_in
         tot = sh["x"].shape[0]
         g = self._buf(("dpre", tot), (tot, self.eng.H))
+        if self.native_gather and all(r == sh["n"] for r in sh["rows"]):
+            try:                                             # one collective, no staging kernels on the critical path
+                dist.all_gather_into_tensor(g, w.d_dep_pre, group=self.pg)
+                w.tp_dpre_all = g
+                return
+            except (RuntimeError, NotImplementedError):
+                self.native_gather = False
         g.zero_()
         g[sh["off"]:sh["off"] + sh["n"]].copy_(w.d_dep_pre)
         dist.all_reduce(g, group=self.pg)                    # a gather: every other rank contributed zeros here
@@ -160,6 +176,14 @@ class PixelShardedDepth:
         tmp[:, self.p0:self.p0 + self.Pr] = self.w
         dist.all_reduce(tmp, group=self.pg)
         W.copy_(tmp)
+
+
+class _null:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
 
 
 class DataParallelStep:
@@ -221,16 +245,25 @@ class DataParallelStep:
         joins it with wait_duration_denominator() before the loss kernel is enqueued."""
         if self.world == 1:
             return
-        torch.mul((target_dur != pad_idx).sum().to(torch.float32).reshape(1), 1.0 / self.world, out=self._den)
-        if async_group is None:
+        if async_group is None or dist.get_backend(async_group) != "nccl":     # (stream-ordered async work is RCCL's)
+            torch.mul((target_dur != pad_idx).sum().to(torch.float32).reshape(1), 1.0 / self.world, out=self._den)
             dist.all_reduce(self._den, op=dist.ReduceOp.SUM, group=self.pg)
-        else:
+            return
+        # the count (4 tiny kernels) and its all-reduce run on a side stream: off the step's critical path
+        if getattr(self, "_den_stream", None) is None:
+            self._den_stream = torch.cuda.Stream(self._den.device)
+        cur = torch.cuda.current_stream()
+        self._den_stream.wait_stream(cur)
+        with torch.cuda.stream(self._den_stream):
+            torch.mul((target_dur != pad_idx).sum().to(torch.float32).reshape(1), 1.0 / self.world, out=self._den)
             self._den_work = dist.all_reduce(self._den, op=dist.ReduceOp.SUM, group=async_group, async_op=True)
 
     def wait_duration_denominator(self):
         w, self._den_work = getattr(self, "_den_work", None), None
         if w is not None:
-            w.wait()
+            with torch.cuda.stream(self._den_stream):
+                w.wait()
+            torch.cuda.current_stream().wait_stream(self._den_stream)
 
     # -- 3. eval-mode selection scores ------------------------------------------------------------------------
     def _scores(self, sums, n_local):
