@@ -52,6 +52,8 @@ parser.add_argument("--erank_every", type=int, default=0,
 parser.add_argument("--erank_weight", type=float, default=0.0,
                     help="rank-enhancing penalty: total loss -= erank_weight * effective_rank(fused tokens) "
                          "(0 = the reference's loss; the reference describes the quantity, README.md:8-14, but never computes it)")
+parser.add_argument("--no_graph_steps", dest="graph_steps", action="store_false", default=True,
+                    help="enqueue every training step launch by launch instead of replaying it as a hipGraph (one GPU)")
 parser.add_argument("--restore_train_mode", action="store_true", default=False,
                     help="call model.train() after validate(); the reference does not (train_proposed_depth.py:53,235)")
 parser.add_argument("--min_batch", type=int, default=8,

@@ -53,6 +53,56 @@ def _to_dev(data, device):
             trans_future_target.to(device).long().contiguous())
 
 
+class _GraphedSteps:
+    """Replays the fused training step (forward + losses + backward + AdamW + epoch accumulators) as ONE hipGraph per
+    batch shape.  Enqueued launch by launch from Python the 36-launch step is bound by the host (measured 1.68 ms/step
+    against 0.29 ms replayed), so the loop keeps static device buffers per (B, S) shape, copies each batch into them
+    (device-to-device, or straight from the loader when it is given these buffers) and replays.  The first step of a
+    shape runs eagerly (allocations, planner), the second one is captured; lr lives in device memory and may change
+    between replays, the other AdamW hyper-parameters are part of the capture (a change re-captures)."""
+
+    def __init__(self, eng, acc_loss, acc_cnt):
+        self.eng, self.acc_loss, self.acc_cnt = eng, acc_loss, acc_cnt
+        self.shapes = {}
+
+    def step(self, batch, lr, hyper, training):
+        eng = self.eng
+        key = tuple(tuple(t.shape) for t in batch) + (bool(training), float(eng.erank_weight))
+        st = self.shapes.get(key)
+        if st is None:
+            st = self.shapes[key] = dict(buf=[torch.empty_like(t) for t in batch], seen=0, graph=None, hyper=None)
+        for dst, src in zip(st["buf"], batch):
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src, non_blocking=True)
+        eng.set_lr(lr)
+        if st["graph"] is not None and st["hyper"] == hyper:
+            st["graph"].replay()
+            return
+        eng._drop_ready = None
+        run = lambda: self._enqueue(st["buf"], lr, hyper, training)         # noqa: E731
+        if st["seen"] == 0 or st["hyper"] not in (None, hyper):
+            run()                                                           # eager: sizes every workspace
+            st["seen"], st["hyper"], st["graph"] = 1, hyper, None
+            return
+        g = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g):
+            run()
+        st["graph"], st["hyper"] = g, hyper
+        g.replay()
+
+    def _enqueue(self, buf, lr, hyper, training):
+        eng = self.eng
+        feats, depth, lab, dur, tgt = buf
+        wd, betas, eps = hyper
+        eng.forward(feats, depth, lab, "train", training=training)
+        loss, counts = eng.losses(lab, tgt, dur, tick=True)
+        eng.backward()
+        eng.adamw(lr, wd, betas=betas, eps=eps, ticked=True)     # (no dropout prefill: every captured step generates its
+        self.acc_loss += loss                                     #  own masks, so graphs of different shapes can interleave)
+        self.acc_cnt += counts
+
+
 def validate(model, val_loader, criterion, pad_idx, device):
     core = _unwrap(model)
     model.eval()
@@ -108,6 +158,10 @@ def train(args, model, train_loader, optimizer, scheduler, criterion, model_save
     best_weight_acc = 0
     acc_loss = torch.zeros(4, dtype=torch.float64, device=eng.device)
     acc_cnt = torch.zeros(4, dtype=torch.int64, device=eng.device)
+    # one-GPU steps with the fused optimiser replay as hipGraphs (--no_graph_steps / args.graph_steps=False: eager)
+    graphed = None
+    if dp is None and getattr(args, "graph_steps", True):
+        graphed = _GraphedSteps(eng, acc_loss, acc_cnt)
     for epoch in range(args.epochs):
         acc_loss.zero_()
         acc_cnt.zero_()
@@ -119,6 +173,15 @@ def train(args, model, train_loader, optimizer, scheduler, criterion, model_save
             if len(features) < min_batch:
                 continue
             g = optimizer.param_groups[0]
+            if graphed is not None and isinstance(optimizer, FlatAdamW):
+                graphed.step([features.contiguous(), depth_features.contiguous(), past_label.contiguous(),
+                              trans_dur_future.contiguous(), trans_future_target.contiguous()], g["lr"],
+                             (g["weight_decay"], tuple(g["betas"]), g["eps"]), model.training)
+                n_steps += 1
+                if erank_every and n_steps % erank_every == 0:
+                    from .erank import effective_rank
+                    print("effective rank of fused tokens: %.3f" % float(effective_rank(eng.last["w"].fused)))
+                continue
             if dp is not None:
                 dp.prepare_duration_denominator(trans_dur_future, pad_idx)
             eng.forward(features, depth_features, past_label, "train", training=model.training)
