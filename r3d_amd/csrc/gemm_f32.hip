@@ -142,12 +142,16 @@ __device__ __forceinline__ void gemm_epilogue_tile(const r3d_gemm_desc& d, const
             if (ok[r]) d.partial[((size_t)split * d.M + (m[r] ^ d.c_row_xor)) * d.N + n] = acc[r];
         return;
     }
-    EpiOps<16> e;
-    e.load(d, ml, n);
-    float a[16];
+    // two halves of 8 rows: the operand arrays of a 16-row pass pushed the 128x128 tiles over 256 VGPRs (spills)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) a[r] = acc[r];
-    e.apply(d, a, m, ok, n);
+    for (int h = 0; h < 2; ++h) {
+        EpiOps<8> e;
+        e.load(d, ml + 8 * h, n);
+        float a[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) a[r] = acc[8 * h + r];
+        e.apply(d, a, m + 8 * h, ok + 8 * h, n);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -839,9 +843,8 @@ R3D_EXPORT int r3d_gemm_plan(r3d_gemm_desc* d) {
     for (int t = 1; t <= 5; ++t) {
         const long tiles = (long)r3d_cdiv(d->M, kTileSz[t]) * r3d_cdiv(d->N, kTileSz[t]);
         double lt = 1.0;
-        // (TN on the 128x128 tile with 2 k-split wave groups exceeds 256 VGPRs and spills: measured 463 us where the 64x64
-        //  k-split tile takes 274 -- priced out until its epilogue is slimmed)
-        if (d->layout == R3D_GEMM_TN) lt = (t == 5) ? 1.7 : (t == 3) ? 1.3 : 0.996;     // (t == 3: 340 us measured where the fit said 300)
+        // (TN: the sweep puts the 64x64 k-split tile ahead of both 128x128 tiles at every measured shape)
+        if (d->layout == R3D_GEMM_TN) lt = (t == 5) ? 1.15 : (t == 3) ? 1.3 : 0.996;
         else if (d->layout == R3D_GEMM_NN) lt = 1.074;
         int last_ns = 0;
         for (int sk : cand) {
