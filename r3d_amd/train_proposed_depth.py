@@ -61,8 +61,12 @@ class _GraphedSteps:
     shape runs eagerly (allocations, planner), the second one is captured; lr lives in device memory and may change
     between replays, the other AdamW hyper-parameters are part of the capture (a change re-captures)."""
 
-    def __init__(self, eng, acc_loss, acc_cnt):
+    def __init__(self, eng, acc_loss, acc_cnt, dp=None, pad_idx=None):
+        """dp (replicated data parallel): the step becomes three graphs around the two gradient all-reduces, exactly
+        bench.py's N > 1 flow: [forward, losses, backward] -> small bucket (async, under the next graph) ->
+        [depth weight gradient] -> big bucket -> [AdamW]."""
         self.eng, self.acc_loss, self.acc_cnt = eng, acc_loss, acc_cnt
+        self.dp, self.pad_idx = dp, pad_idx
         self.shapes = {}
 
     def step(self, batch, lr, hyper, training):
@@ -75,6 +79,8 @@ class _GraphedSteps:
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
         eng.set_lr(lr)
+        if self.dp is not None:
+            return self._step_dp(st, lr, hyper, training)
         if st["graph"] is not None and st["hyper"] == hyper:
             st["graph"].replay()
             return
@@ -90,6 +96,49 @@ class _GraphedSteps:
             run()
         st["graph"], st["hyper"] = g, hyper
         g.replay()
+
+    def _step_dp(self, st, lr, hyper, training):
+        eng, dp = self.eng, self.dp
+        feats, depth, lab, dur, tgt = st["buf"]
+        wd, betas, eps = hyper
+        dp.prepare_duration_denominator(dur, self.pad_idx)
+
+        def part1():
+            eng.forward(feats, depth, lab, "train", training=training)
+            loss, counts = eng.losses(lab, tgt, dur, tick=True)
+            eng.backward_main()
+            self.acc_loss += loss
+            self.acc_cnt += counts
+
+        def part3():
+            eng.adamw(lr, wd, betas=betas, eps=eps, grad_scale=dp.grad_scale, ticked=True)
+        eng._drop_ready = None
+        hook, eng.grad_hook = eng.grad_hook, None            # the exchanges are issued here, between the graphs
+        try:
+            if st["graph"] is None or st["hyper"] != hyper:
+                if st["seen"] == 0 or st["hyper"] not in (None, hyper):
+                    g1 = g2 = g3 = None                          # first step of this shape: eager
+                    st["seen"], st["hyper"], st["graph"] = 1, hyper, None
+                else:
+                    torch.cuda.synchronize()
+                    g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g1):
+                        part1()
+                    with torch.cuda.graph(g2):
+                        eng.backward_depth_wgrad()
+                    with torch.cuda.graph(g3):
+                        part3()
+                    st["graph"], st["hyper"] = (g1, g2, g3), hyper
+            else:
+                g1, g2, g3 = st["graph"]
+            (g1.replay if g1 is not None else part1)()
+            dp._on_stage("small_ready")
+            (g2.replay if g2 is not None else eng.backward_depth_wgrad)()
+            dp._on_stage("big_ready")
+            dp.wait_grads()
+            (g3.replay if g3 is not None else part3)()
+        finally:
+            eng.grad_hook = hook
 
     def _enqueue(self, buf, lr, hyper, training):
         eng = self.eng
@@ -160,8 +209,8 @@ def train(args, model, train_loader, optimizer, scheduler, criterion, model_save
     acc_cnt = torch.zeros(4, dtype=torch.int64, device=eng.device)
     # one-GPU steps with the fused optimiser replay as hipGraphs (--no_graph_steps / args.graph_steps=False: eager)
     graphed = None
-    if dp is None and getattr(args, "graph_steps", True):
-        graphed = _GraphedSteps(eng, acc_loss, acc_cnt)
+    if getattr(args, "graph_steps", True) and (dp is None or dp.tp is None):
+        graphed = _GraphedSteps(eng, acc_loss, acc_cnt, dp, pad_idx)
     for epoch in range(args.epochs):
         acc_loss.zero_()
         acc_cnt.zero_()

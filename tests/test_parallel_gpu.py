@@ -128,3 +128,58 @@ def test_pixel_sharded_depth_matches_replicated_two_ranks():
         p.join(timeout=60)
     for rank, status, info in res:
         assert status == "ok", f"rank {rank}: {info}"
+
+
+def _train_worker(rank, world, port, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        import tempfile
+        from r3d_amd.train_proposed_depth import train
+        from r3d_amd.optim import FlatAdamW
+        fx = load_fixture("step_tiny")
+        m = fx["meta"]
+        batches = [fixture_batch(fx, seed=300 + 10 * s + rank) for s in range(4)]
+        val = [[t[:1] for t in fixture_batch(fx, seed=999)]]
+        finals = []
+        for graph_steps in (False, True):
+            model = _model(fx)
+            args = argparse.Namespace(epochs=1, input_type="i3d_transcript", seg=True, anticipate=True, task="long",
+                                      min_batch=1, graph_steps=graph_steps)
+
+            class NoSched:
+                def step(self):
+                    pass
+            opt = FlatAdamW(model.parameters(), 1e-3, weight_decay=5e-3)
+            with tempfile.TemporaryDirectory() as d:
+                train(args, model, batches, opt, NoSched(), None, d, m["pad_idx"], torch.device("cuda"), val, seed=rank)
+            torch.cuda.synchronize()
+            finals.append(model.engine().arena.params.clone())
+        assert torch.equal(finals[0], finals[1]), float((finals[0] - finals[1]).abs().max())
+        t = finals[1].clone()
+        dist.broadcast(t, src=0)
+        assert torch.equal(t, finals[1])                       # the ranks stayed in lock-step
+        q.put((rank, "ok", ""))
+    except Exception as e:          # noqa: BLE001
+        import traceback
+        q.put((rank, "fail", traceback.format_exc() + repr(e)))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_train_loop_graphed_data_parallel_equals_eager_two_ranks():
+    """train() under replicated data parallelism (2 ranks, gloo): replaying each step as three hipGraphs around the two
+    gradient all-reduces gives bit-identical parameters to enqueueing it launch by launch."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, status, info in res:
+        assert status == "ok", f"rank {rank}: {info}"
