@@ -160,6 +160,12 @@ def main():
                     help="tokenfusion = the headline model (BASELINE.json); bn = the BN-blend fuser variant, profiling only")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the "
                                                       "multi-rank control flow on one GPU)")
+    ap.add_argument("--torch-collectives", action="store_true",
+                    help="multi-GPU: exchanges through torch.distributed (ProcessGroupNCCL's stream + event joins, several "
+                         "graphs per step) instead of RCCL enqueued on the launch stream")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal: run the multi-rank flow (process group, exchanges, graphs around them) with however "
+                         "many ranks there are, even one")
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -170,8 +176,14 @@ def main():
     local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    dist_on = world > 1 or a.force_dist
+    if a.force_dist:
+        os.environ["R3D_REHEARSE_DIST"] = "1"
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if a.backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
@@ -208,35 +220,60 @@ def main():
         eng.adamw(c["lr"], c["wd"], grad_scale=gscale, ticked=True, skip_depth=fuse, prefill_dropout=True)
 
     mode = "replicated"
-    if world > 1:
+    rs = None                               # RcclStep: exchanges on the launch stream, one hipGraph per step
+    pad = c["K"] + 1
+    if dist_on:
         want_tp = not a.replicated_depth and c["P"] % (4 * world) == 0
         pg_in = dist.new_group(backend=a.backend) if want_tp else None
-        dp = DataParallelStep(eng, pixel_shard=want_tp, input_group=pg_in)
-        dp.broadcast_parameters()
-        tp = dp.tp
-        gscale = dp.grad_scale
-        if tp is not None:                  # one trial step; every rank must agree that it worked
+
+        def agreed(fn):
+            """Run fn on every rank; True only if it succeeded everywhere."""
             ok = torch.ones(1, device=device)
             try:
-                step_eager()
+                fn()
                 torch.cuda.synchronize()
             except Exception as e:          # noqa: BLE001
-                print(f"[rank {rank}] pixel-sharded step failed ({type(e).__name__}: {e}); falling back", flush=True)
+                print(f"[rank {rank}] {fn.__name__} failed ({type(e).__name__}: {e}); falling back", flush=True)
                 ok.zero_()
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if float(ok.item()) < 1.0:
-                model = build_model(c, device, a.variant)
-                if a.eval_dropout_off:
-                    model.eval()
-                eng = model.engine()
-                eng.use_side_stream = a.side_stream
-                dp = DataParallelStep(eng)
-                dp.broadcast_parameters()
-                tp = None
-            else:
-                mode = "pixel-sharded depth_projection"
+            return float(ok.item()) >= 1.0
+
+        def rebuild(pixel_shard):
+            nonlocal model, eng, dp, tp, gscale
+            model = build_model(c, device, a.variant)
+            if a.eval_dropout_off:
+                model.eval()
+            eng = model.engine()
+            eng.use_side_stream = a.side_stream
+            dp = DataParallelStep(eng, pixel_shard=pixel_shard, input_group=pg_in if pixel_shard else None)
+            dp.broadcast_parameters()
+            tp, gscale = dp.tp, dp.grad_scale
+
+        rebuild(want_tp)
+        if a.backend == "nccl" and not a.torch_collectives:
+            def rccl_trial():
+                nonlocal rs
+                from r3d_amd.parallel import RcclStep
+                from r3d_amd.rccl import RcclComm
+                rs = RcclStep(dp, RcclComm(), RcclComm(), c["lr"], c["wd"], fuse_adam)
+                rs.prime(x_dep2d, dur, pad, 0)
+                for s in (0, 1):
+                    rs.run(feats, depth, lab, dur, tgt, pad, training, slot=s if tp is not None else 0,
+                           next_inputs=(x_dep2d, dur) if tp is not None else None)
+            if not agreed(rccl_trial):
+                rs = None
+                rebuild(want_tp)
+        if rs is None and tp is not None and not agreed(step_eager):     # torch.distributed form of the sharded step
+            rebuild(False)
+        if tp is not None:
+            mode = "pixel-sharded depth_projection"
     else:
         gscale = 1.0
+    if rs is not None:
+        def step_eager():                   # noqa: F811  (same step, exchanges enqueued by RCCL on this stream)
+            s = slot[0] if tp is not None else 0
+            rs.run(feats, depth, lab, dur, tgt, pad, training, slot=s, next_inputs=(x_dep2d, dur) if tp is not None else None)
+            slot[0] ^= 1
     for _ in range(3):
         step_eager()
     torch.cuda.synchronize()
@@ -249,6 +286,21 @@ def main():
                 with torch.cuda.graph(g):
                     step_eager()
                 run_step, launch = g.replay, "hipGraph (1 graph/step)"
+            elif rs is not None:
+                G = {}
+                for s_ in ((0, 1) if tp is not None else (0,)):
+                    eng._drop_ready = eng.last["w"] if training else None             # masks come from the AdamW launch
+                    G[s_] = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(G[s_]):
+                        rs.run(feats, depth, lab, dur, tgt, pad, training, slot=s_,
+                               next_inputs=(x_dep2d, dur) if tp is not None else None)
+                eng._drop_ready = None
+
+                def run_step():
+                    s_ = slot[0] if tp is not None else 0
+                    G[s_].replay()
+                    slot[0] ^= 1
+                launch = "hipGraph (1 graph/step, RCCL exchanges captured on the launch stream)"
             elif tp is not None:
                 hook = eng.grad_hook
                 eng.grad_hook = None
@@ -336,18 +388,18 @@ def main():
     for _ in range(a.warmup):
         run_step()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         run_step()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         tt = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -373,7 +425,7 @@ def main():
                    config=dict(workload=NAMES.get(a.config, f"{a.config} per-GPU shape B={c['B']} S={c['S']} H={c['H']} "
                                                                   "(profiling only, not the headline workload)"),
                                global_batch=world * c["B"], clip_frames=c["S"], hidden=c["H"],
-                               parallelism=f"dp{world}" + (f" ({mode})" if world > 1 else ""),
+                               parallelism=f"dp{world}" + (f" ({mode})" if dist_on else ""),
                                launch=launch, dropout="on" if training else "off"),
                    roofline=roof,
                    kernels={k: dict(us=v["seconds"] * 1e6, GBps=v["bytes"] / v["seconds"] / 1e9,
@@ -384,7 +436,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline and a.config == "cfg2" and a.variant == "tokenfusion":
             out["cpu_baseline"] = cpu_baseline(c)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -929,8 +929,10 @@ class FusionEngine:
             self._lr_host = float(lr)
 
     def adamw(self, lr, weight_decay, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0, tick_dropout=False, ticked=False,
-              skip_depth=False, prefill_dropout=False):
+              skip_depth=False, prefill_dropout=False, before_flat=None):
         """One fused launch over the live prefix of the arena (main_darai.py:135; train_proposed_depth.py:215).
+        before_flat: callable run between the pixel-sharded weight's update (which needs no exchanged gradient, so it goes
+        first) and the flat launch over the replicated parameters (which does) -- the place to join their all-reduce.
         ticked: losses(tick=True) already advanced the counters in this step.
         skip_depth: backward(fused_adamw=...) already updated depth_projection.weight.
         prefill_dropout: the same launch also fills the dropout pool of the step's workspace with the NEXT step's masks
@@ -941,6 +943,13 @@ class FusionEngine:
             ops.tick(self.step_t, self.drop_offset if tick_dropout else None)
         n = a.n_live if (self.tp is None and not skip_depth) else a.bucket_small[1]
         st = self.last
+        depth_cols_first = before_flat is not None and self.tp is not None and not skip_depth
+        if depth_cols_first:
+            t = self.tp
+            ops.adamw_2d(t.w, t.g, t.m, t.v, self.lr_t, self.step_t, beta1=betas[0], beta2=betas[1], eps=eps,
+                         weight_decay=weight_decay, grad_scale=grad_scale)
+        if before_flat is not None:
+            before_flat()
         if prefill_dropout and st is not None and st["drop"] and (ticked or tick_dropout):
             ops.adamw_flat_dropout(a.params[:n], a.grads[:n], a.exp_avg[:n], a.exp_avg_sq[:n], self.lr_t, self.step_t,
                                    st["w"].drop_pool, DROP_P, self.drop_seed, self.drop_offset, beta1=betas[0], beta2=betas[1],
@@ -949,8 +958,8 @@ class FusionEngine:
         else:
             ops.adamw_flat(a.params[:n], a.grads[:n], a.exp_avg[:n], a.exp_avg_sq[:n], self.lr_t, self.step_t,
                            beta1=betas[0], beta2=betas[1], eps=eps, weight_decay=weight_decay, grad_scale=grad_scale)
-        if self.tp is not None and not skip_depth:  # depth_projection.weight: only this rank's pixel columns are live
-            t = self.tp
+        if self.tp is not None and not skip_depth and not depth_cols_first:
+            t = self.tp                             # depth_projection.weight: only this rank's pixel columns are live
             ops.adamw_2d(t.w, t.g, t.m, t.v, self.lr_t, self.step_t, beta1=betas[0], beta2=betas[1], eps=eps,
                          weight_decay=weight_decay, grad_scale=grad_scale)
 

@@ -22,6 +22,8 @@ weight, of its gradient and of both AdamW moments; what crosses xGMI instead of 
   * two [sum_r N_r, H] activations (512 KB at 8 GPUs): the partial products forward, d(depth_pre) backward.
 The mathematics is unchanged (the sum over pixels is split across ranks instead of across split-K workgroups).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -192,6 +194,8 @@ class DataParallelStep:
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        # R3D_REHEARSE_DIST=1: run every exchange even with one rank (exercises the RCCL calls on a one-GPU box)
+        self.active = self.world > 1 or (dist.is_initialized() and os.environ.get("R3D_REHEARSE_DIST") == "1")
         self.works = []
         a = engine.arena
         self.small = a.grads[a.bucket_small[0]:a.bucket_small[1]]
@@ -199,15 +203,15 @@ class DataParallelStep:
         self._den = torch.zeros(1, dtype=torch.float32, device=a.grads.device)
         engine.grad_hook = self._on_stage
         engine.score_allreduce = self._scores
-        if self.world > 1:
+        if self.active:
             engine.dur_den = self._den
         self.tp = None
-        if pixel_shard and self.world > 1:
+        if pixel_shard and self.active:
             self.tp = PixelShardedDepth(engine, process_group, equal_batches, input_group)
 
     # -- 1. gradients ------------------------------------------------------------------------------------------
     def _on_stage(self, stage):
-        if self.world == 1:
+        if not self.active:
             return
         if stage == "big_ready" and self.tp is not None:
             return                        # that gradient is already complete on the rank that owns the columns
@@ -243,7 +247,7 @@ class DataParallelStep:
         """Call before the step's loss kernel: den = (global count of non-pad duration targets) / world.
         async_group: run the all-reduce asynchronously on that communicator (under the input projections); the caller
         joins it with wait_duration_denominator() before the loss kernel is enqueued."""
-        if self.world == 1:
+        if not self.active:
             return
         if async_group is None or dist.get_backend(async_group) != "nccl":     # (stream-ordered async work is RCCL's)
             torch.mul((target_dur != pad_idx).sum().to(torch.float32).reshape(1), 1.0 / self.world, out=self._den)
@@ -267,7 +271,7 @@ class DataParallelStep:
 
     # -- 3. eval-mode selection scores ------------------------------------------------------------------------
     def _scores(self, sums, n_local):
-        if self.world == 1:
+        if not self.active:
             return float(n_local)
         cnt = torch.tensor([float(n_local)], dtype=torch.float64, device=sums.device)
         dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.pg)
@@ -276,5 +280,106 @@ class DataParallelStep:
 
     def broadcast_parameters(self, src=0):
         """Same initial weights on every rank (nn.DataParallel replicates from device 0 each step)."""
-        if self.world > 1:
+        if self.active:
             dist.broadcast(self.eng.arena.params, src=src, group=self.pg)
+
+
+class RcclStep:
+    """The multi-GPU training step with its exchanges enqueued by RCCL on the step's own stream (r3d_amd/rccl.py), so that
+    the whole step -- kernels and collectives -- is captured into ONE hipGraph per input slot.
+
+    Two communicators: `comm` for the exchanges that sit on the critical path (they run in stream order between the
+    kernels that produce and consume their operands) and `comm_side` for the ones that do not -- the next step's depth
+    input (pixel-sharded mode), the duration-loss denominator and the replicated parameters' gradient bucket (which
+    travels under the depth weight-gradient GEMM and the sharded weight's AdamW).  The side work runs on a second stream
+    that forks from and re-joins the launch stream inside the graph.
+
+    Pixel-sharded mode, per step (W ranks, N frame rows per rank, H hidden, P pixels):
+        side:  [N, P] -> all-to-all -> [W N, P/W] for the NEXT step (slot s^1);  its denominator all-reduce (1 float)
+        main:  partial GEMM -> reduce-scatter [W N, H] (each rank keeps the sum of its own rows) -> ... -> losses ->
+               backward -> all-gather d(depth_pre) [N, H] -> [W N, H] -> fork(side: all-reduce of the replicated bucket)
+               -> weight-gradient GEMM on the owned columns -> AdamW on the owned columns -> join -> AdamW on the rest
+    Replicated mode: denominator and small bucket on the side stream, the depth_projection gradient all-reduced in stream
+    order after its GEMM.
+    """
+
+    def __init__(self, dp, comm, comm_side, lr, weight_decay, fuse_adam=False):
+        self.dp, self.eng, self.tp = dp, dp.eng, dp.tp
+        self.comm, self.side_comm = comm, comm_side
+        self.lr, self.wd, self.fuse_adam = lr, weight_decay, fuse_adam and dp.tp is not None
+        dev = self.eng.device
+        self.side = torch.cuda.Stream(dev)
+        self.den = [torch.zeros(1, dtype=torch.float32, device=dev) for _ in range(2)]
+        self.shards = {}
+
+    # -- what does not sit on the critical path --------------------------------------------------------------
+    def _stage_inputs(self, x_dep2d, dur, pad_idx, slot):
+        """(on the current stream) the exchanged depth shard and the duration denominator for a step that will run from
+        `slot`."""
+        W = self.dp.world
+        torch.mul((dur != pad_idx).sum().to(torch.float32).reshape(1), 1.0 / W, out=self.den[slot])
+        self.side_comm.all_reduce(self.den[slot])
+        if self.tp is not None:
+            tp, N = self.tp, x_dep2d.shape[0]
+            send = tp._buf(("send", N, slot), (W, N, tp.Pr))
+            recv = tp._buf(("recv", W * N, slot), (W * N, tp.Pr))
+            if W > 1:
+                send.copy_(x_dep2d.view(N, W, tp.Pr).transpose(0, 1))
+                self.side_comm.all_to_all(recv, send)
+            else:       # (one-rank rehearsal: the same two passes as kernels -- hipGraph instantiation crashes on the
+                        #  25.7 MB memcpy nodes that a contiguous copy_ and a self-addressed all-to-all turn into)
+                torch.mul(x_dep2d.view(W, N, tp.Pr), 1.0, out=send)
+                torch.mul(send.view(W * N, tp.Pr), 1.0, out=recv)
+            self.shards[slot] = dict(x=recv, rows=[N] * W, off=tp.rank * N, n=N, work=None)
+
+    def prime(self, x_dep2d, dur, pad_idx, slot=0):
+        """Before the first step: its own inputs (every later step finds them prefetched by its predecessor)."""
+        self._stage_inputs(x_dep2d, dur, pad_idx, slot)
+
+    # -- one step ------------------------------------------------------------------------------------------------
+    def run(self, feats, depth, lab, dur, tgt, pad_idx, training, slot=0, next_inputs=None):
+        """Enqueue (or capture) one step that consumes slot `slot`.  next_inputs = (x_dep2d, dur) of the step after it,
+        staged into slot^1 on the side stream; None = nothing to prefetch (replicated mode stages its own denominator)."""
+        eng, dp, tp = self.eng, self.dp, self.tp
+        cur = torch.cuda.current_stream()
+        skip = os.environ.get("R3D_RS_SKIP", "").split(",") if torch.cuda.is_current_stream_capturing() else []
+        hook, eng.grad_hook = eng.grad_hook, None
+        try:
+            self.side.wait_stream(cur)
+            with torch.cuda.stream(self.side):
+                if tp is None:
+                    self._stage_inputs(None, dur, pad_idx, slot)
+                elif next_inputs is not None and "stage" not in skip:
+                    self._stage_inputs(next_inputs[0], next_inputs[1], pad_idx, slot ^ 1)
+            eng.dur_den = self.den[slot]
+            if tp is not None:
+                tp.ready[depth.reshape(depth.shape[0] * depth.shape[1], -1).data_ptr()] = self.shards[slot]
+                eng.forward_begin(feats, depth, lab, "train", training)
+                if "rs" not in skip:
+                    self.comm.reduce_scatter_inplace(eng._fw["w"].tp_part)
+                eng.forward_finish()
+            else:
+                eng.forward(feats, depth, lab, "train", training)
+                cur.wait_stream(self.side)                      # the denominator
+            eng.losses(lab, tgt, dur, tick=True)
+            adam = dict(lr=self.lr, weight_decay=self.wd, grad_scale=dp.grad_scale) if self.fuse_adam else None
+            eng.prepare_fused_adamw(adam)
+            eng.backward_main()
+            w = eng.last["w"]
+            if tp is not None:
+                g = tp._buf(("dpre", w.tp_part.shape[0]), tuple(w.tp_part.shape))
+                if "ag" not in skip:
+                    self.comm.all_gather(g, w.d_dep_pre)
+                w.tp_dpre_all = g
+            self.side.wait_stream(cur)
+            with torch.cuda.stream(self.side):
+                small = dp.small[:dp._small_live()]
+                if small.numel() and "small" not in skip:
+                    self.side_comm.all_reduce(small)
+            eng.backward_depth_wgrad()
+            if tp is None:
+                self.comm.all_reduce(dp.big)
+            eng.adamw(self.lr, self.wd, grad_scale=dp.grad_scale, ticked=True, skip_depth=self.fuse_adam,
+                      prefill_dropout=True, before_flat=lambda: cur.wait_stream(self.side))
+        finally:
+            eng.grad_hook = hook

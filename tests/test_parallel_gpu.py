@@ -183,3 +183,106 @@ def test_train_loop_graphed_data_parallel_equals_eager_two_ranks():
         p.join(timeout=60)
     for rank, status, info in res:
         assert status == "ok", f"rank {rank}: {info}"
+
+
+class _DistAsRccl:
+    """Test double with r3d_amd.rccl.RcclComm's interface over a torch.distributed group (gloo): rehearses RcclStep's
+    exchange logic with two ranks on one GPU, where RCCL itself cannot form a communicator."""
+
+    def __init__(self):
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+
+    def all_reduce(self, t, stream=None):
+        dist.all_reduce(t)
+
+    def reduce_scatter_inplace(self, full, stream=None):
+        n = full.numel() // self.world
+        tmp = full.clone()
+        dist.all_reduce(tmp)
+        mine = full.view(-1)[self.rank * n:(self.rank + 1) * n]
+        mine.copy_(tmp.view(-1)[self.rank * n:(self.rank + 1) * n])       # the other blocks stay partial, as with RCCL
+        return mine
+
+    def all_gather(self, out, inp, stream=None):
+        parts = [torch.empty_like(inp) for _ in range(self.world)]
+        dist.all_gather(parts, inp)
+        out.view(self.world, -1).copy_(torch.stack([p.reshape(-1) for p in parts]))
+
+    def all_to_all(self, recv, send, stream=None):
+        parts = [torch.empty_like(send) for _ in range(self.world)]
+        dist.all_gather(parts, send)
+        blk = send.numel() // self.world
+        for j in range(self.world):
+            recv.view(-1)[j * blk:(j + 1) * blk].copy_(parts[j].view(-1)[self.rank * blk:(self.rank + 1) * blk])
+
+
+def _run_rccl_step(fx, rank, pixel_shard, steps):
+    from r3d_amd.parallel import DataParallelStep, RcclStep
+    m = fx["meta"]
+    model = _model(fx)
+    eng = model.engine()
+    dp = DataParallelStep(eng, pixel_shard=pixel_shard)
+    dp.broadcast_parameters()
+    rs = RcclStep(dp, _DistAsRccl(), _DistAsRccl(), m["lr"], m["wd"])
+    batches = [[t.cuda() for t in fixture_batch(fx, seed=100 + 10 * s + rank)] for s in range(steps)]
+    x2d = [b[1].reshape(m["B"] * m["S"], -1) for b in batches]
+    rs.prime(x2d[0], batches[0][3], m["pad_idx"], 0)
+    losses = []
+    for s, (feats, depth, lab, dur, tgt) in enumerate(batches):
+        nxt = (x2d[s + 1], batches[s + 1][3]) if (dp.tp is not None and s + 1 < steps) else None
+        rs.run(feats, depth, lab, dur, tgt, m["pad_idx"], False, slot=s % 2 if dp.tp is not None else 0, next_inputs=nxt)
+        torch.cuda.synchronize()
+        losses.append(eng.last["w"].loss.clone())
+    if dp.tp is not None:
+        dp.tp.sync_full_weight()
+    torch.cuda.synchronize()
+    return eng, losses
+
+
+def _rccl_step_worker(rank, world, port, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        fx = load_fixture("step_tiny")
+        lr = fx["meta"]["lr"]
+        engA, _, recA = _run(fx, rank, False, 3, False)                # torch.distributed, replicated: the yardstick
+        for pixel_shard in (False, True):
+            engB, lossB = _run_rccl_step(fx, rank, pixel_shard, 3)
+            for s in range(3):
+                tol = 1e-5 if s == 0 else 2e-2
+                assert torch.allclose(recA[s]["loss"], lossB[s], rtol=tol, atol=1e-6), (pixel_shard, s, recA[s]["loss"],
+                                                                                       lossB[s])
+            a, b = engA.arena, engB.arena
+            pa, pb = a.params[:a.n_live], b.params[:b.n_live]
+            d = (pa - pb).abs()
+            assert float(d.max()) <= 3 * 2.1 * lr, float(d.max())
+            frac = float((d <= 1e-5 * (1 + pa.abs())).double().mean())
+            assert frac > 0.95, (pixel_shard, frac)
+            t = pb.clone()
+            dist.broadcast(t, src=0)
+            assert torch.equal(t, pb)
+        q.put((rank, "ok", ""))
+    except Exception as e:          # noqa: BLE001
+        import traceback
+        q.put((rank, "fail", traceback.format_exc() + repr(e)))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_rccl_step_flow_matches_replicated_two_ranks():
+    """RcclStep (exchanges in stream order: reduce-scatter of the partial products, all-gather of d(depth_pre), the
+    prefetched all-to-all, side-stream bucket) with a gloo stand-in for the communicator == the torch.distributed
+    replicated step, over three steps with different batches (so a wrong slot or a stale prefetch shows)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rccl_step_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, status, info in res:
+        assert status == "ok", f"rank {rank}: {info}"
