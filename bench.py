@@ -136,6 +136,36 @@ def cpu_baseline(c, budget_s=15.0):
                        f"H={c['H']} workload in {dt:.1f}s, torch {torch.__version__} CPU, {cores} threads")
 
 
+def rccl_probe_child(a, timeout_s=300):
+    """Multi-GPU only, before this process touches the GPU: run the RCCL-on-the-launch-stream step (own communicators,
+    collectives captured into the step's hipGraph) for a few steps in a CHILD process per rank.  A crash or hang there --
+    which no try/except in this process could survive -- costs the child, and the bench falls back to the
+    torch.distributed exchanges.  Returns True if the child finished cleanly."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC")}
+    port = int(env.get("MASTER_PORT", "29533"))
+    env["MASTER_PORT"] = str(20000 + (port + 7919) % 40000)      # the children rendezvous among themselves
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    cmd = [sys.executable, os.path.abspath(__file__), "--probe-child", "--gpus", str(a.gpus), "--steps", "10", "--warmup",
+           "2", "--no-cpu-baseline", "--config", a.config, "--variant", a.variant]
+    for flag, on in (("--force-dist", a.force_dist), ("--replicated-depth", a.replicated_depth),
+                     ("--fused-adamw", a.fused_adamw), ("--eval-dropout-off", a.eval_dropout_off)):
+        if on:
+            cmd.append(flag)
+    try:
+        p = subprocess.Popen(cmd, env=env, stdout=sys.stderr, stderr=sys.stderr)
+    except OSError as e:
+        print(f"[bench] probe child could not start: {e}", file=sys.stderr, flush=True)
+        return False
+    try:
+        return p.wait(timeout=timeout_s) == 0
+    except subprocess.TimeoutExpired:
+        p.kill()
+        p.wait()
+        print("[bench] probe child timed out; using torch.distributed exchanges", file=sys.stderr, flush=True)
+        return False
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -163,20 +193,30 @@ def main():
     ap.add_argument("--torch-collectives", action="store_true",
                     help="multi-GPU: exchanges through torch.distributed (ProcessGroupNCCL's stream + event joins, several "
                          "graphs per step) instead of RCCL enqueued on the launch stream")
+    ap.add_argument("--probe-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-probe", action="store_true",
+                    help="multi-GPU: skip the child-process rehearsal of the RCCL step (needed under a profiler)")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal: run the multi-rank flow (process group, exchanges, graphs around them) with however "
                          "many ranks there are, even one")
     a = ap.parse_args()
+    # libraries write to fd 1 (RCCL prints a version banner there): stdout is kept for the one JSON line
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world:
         if world == 1 and a.gpus > 1:
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    dist_on = world > 1 or a.force_dist
+    probe_ok = True
+    if dist_on and a.backend == "nccl" and not a.torch_collectives and not a.probe_child and not a.no_probe:
+        probe_ok = rccl_probe_child(a)       # BEFORE anything here initialises the GPU
     local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    dist_on = world > 1 or a.force_dist
     if a.force_dist:
         os.environ["R3D_REHEARSE_DIST"] = "1"
     if dist_on:
@@ -188,6 +228,10 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(a.backend)
+        t_ok = torch.tensor([1.0 if probe_ok else 0.0], device=device)
+        dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
+        if float(t_ok.item()) < 1.0:            # some rank's rehearsal failed: every rank takes the torch.distributed path
+            a.torch_collectives = True
     c = dict(CFG, **OTHER.get(a.config, {}))
     model = build_model(c, device, a.variant)
     if a.eval_dropout_off:
@@ -256,10 +300,10 @@ def main():
                 from r3d_amd.parallel import RcclStep
                 from r3d_amd.rccl import RcclComm
                 rs = RcclStep(dp, RcclComm(), RcclComm(), c["lr"], c["wd"], fuse_adam)
-                rs.prime(x_dep2d, dur, pad, 0)
+                rs.stage(x_dep2d, dur, pad, 0)
                 for s in (0, 1):
-                    rs.run(feats, depth, lab, dur, tgt, pad, training, slot=s if tp is not None else 0,
-                           next_inputs=(x_dep2d, dur) if tp is not None else None)
+                    rs.stage(x_dep2d, dur, pad, s ^ 1)
+                    rs.run(feats, depth, lab, dur, tgt, pad, training, slot=s)
             if not agreed(rccl_trial):
                 rs = None
                 rebuild(want_tp)
@@ -271,8 +315,8 @@ def main():
         gscale = 1.0
     if rs is not None:
         def step_eager():                   # noqa: F811  (same step, exchanges enqueued by RCCL on this stream)
-            s = slot[0] if tp is not None else 0
-            rs.run(feats, depth, lab, dur, tgt, pad, training, slot=s, next_inputs=(x_dep2d, dur) if tp is not None else None)
+            rs.stage(x_dep2d, dur, pad, slot[0] ^ 1)            # the next step's inputs
+            rs.run(feats, depth, lab, dur, tgt, pad, training, slot=slot[0])
             slot[0] ^= 1
     for _ in range(3):
         step_eager()
@@ -287,20 +331,43 @@ def main():
                     step_eager()
                 run_step, launch = g.replay, "hipGraph (1 graph/step)"
             elif rs is not None:
-                G = {}
-                for s_ in ((0, 1) if tp is not None else (0,)):
+                G, S = {}, {}
+                side = torch.cuda.Stream(device)
+                side.wait_stream(torch.cuda.current_stream())
+                for s_ in (0, 1):
+                    S[s_] = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(S[s_], stream=side):                        # next-step inputs: their own graph
+                        rs.stage(x_dep2d, dur, pad, s_)
                     eng._drop_ready = eng.last["w"] if training else None             # masks come from the AdamW launch
                     G[s_] = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(G[s_]):
-                        rs.run(feats, depth, lab, dur, tgt, pad, training, slot=s_,
-                               next_inputs=(x_dep2d, dur) if tp is not None else None)
+                        rs.run(feats, depth, lab, dur, tgt, pad, training, slot=s_)
                 eng._drop_ready = None
+                ev_side = [torch.cuda.Event(), torch.cuda.Event()]
+                evs = [torch.cuda.Event() for _ in range(4)]
+                nstep = [0]
+                for e in ev_side + evs:
+                    e.record()
 
+                # Ordering between the two streams.  step -> needs its staged inputs: a stream-level wait on the side
+                # graph's event (long complete by then: ~4 us).  side graph for step t+1 -> must not overwrite the slot
+                # step t-1 still reads: measured, a stream-level dependency FROM the busy launch stream costs ~50 us per
+                # step on this runtime (in-graph fork or event alike), so this one is kept on the host instead: the host
+                # launches step t, then waits for step t-1's event before it launches the side graph.  Step t is already
+                # queued behind step t-1, so the GPU never idles while the host waits.
                 def run_step():
-                    s_ = slot[0] if tp is not None else 0
+                    s_, cur = slot[0], torch.cuda.current_stream()
+                    t = nstep[0]
+                    cur.wait_event(ev_side[s_])
                     G[s_].replay()
+                    evs[t % 4].record(cur)
+                    evs[(t - 1) % 4].synchronize()
+                    with torch.cuda.stream(side):
+                        S[s_ ^ 1].replay()
+                        ev_side[s_ ^ 1].record(side)
+                    nstep[0] = t + 1
                     slot[0] ^= 1
-                launch = "hipGraph (1 graph/step, RCCL exchanges captured on the launch stream)"
+                launch = "hipGraph (1 graph/step, RCCL exchanges captured on the launch stream; next inputs staged by a side graph)"
             elif tp is not None:
                 hook = eng.grad_hook
                 eng.grad_hook = None
@@ -405,6 +472,12 @@ def main():
         dt = float(tt.item())
     w = eng.last["w"]
     loss_now = [float(x) for x in w.loss.cpu()]
+    if a.probe_child:                       # the rehearsal: success = the one-graph RCCL step ran and stayed finite
+        good = rs is not None and launch.startswith("hipGraph (1 graph") and all(x == x and abs(x) < 1e30 for x in loss_now)
+        print(f"[bench probe child rank {rank}] {'ok' if good else 'NOT ok'}: {launch}; {dt / a.steps * 1e3:.3f} ms/step",
+              file=sys.stderr, flush=True)
+        dist.destroy_process_group()
+        sys.exit(0 if good else 3)
     if rank == 0:
         kr = kernel_rooflines(eng, c)
         name, dom = max(kr.items(), key=lambda kv: kv[1]["seconds"])
@@ -435,6 +508,8 @@ def main():
             out["config"]["workload"] += f" [{a.variant} fuser variant: profiling only, not the headline model]"
         if world == 1 and not a.no_cpu_baseline and a.config == "cfg2" and a.variant == "tokenfusion":
             out["cpu_baseline"] = cpu_baseline(c)
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
     if dist_on:
         dist.destroy_process_group()

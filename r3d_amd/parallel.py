@@ -286,21 +286,20 @@ class DataParallelStep:
 
 class RcclStep:
     """The multi-GPU training step with its exchanges enqueued by RCCL on the step's own stream (r3d_amd/rccl.py), so that
-    the whole step -- kernels and collectives -- is captured into ONE hipGraph per input slot.
+    the whole step -- kernels and collectives -- is ONE linear hipGraph: no stream forks, no event joins inside it.
 
-    Two communicators: `comm` for the exchanges that sit on the critical path (they run in stream order between the
-    kernels that produce and consume their operands) and `comm_side` for the ones that do not -- the next step's depth
-    input (pixel-sharded mode), the duration-loss denominator and the replicated parameters' gradient bucket (which
-    travels under the depth weight-gradient GEMM and the sharded weight's AdamW).  The side work runs on a second stream
-    that forks from and re-joins the launch stream inside the graph.
+    What a step needs from the other ranks BEFORE it starts is staged one step ahead by stage(): the depth input's
+    all-to-all (pixel-sharded mode) and the duration-loss denominator (1 float all-reduced).  stage() runs on its own
+    stream / communicator (its own small graph), ordered against the step graphs only at graph boundaries, by events
+    that are long complete when they are waited on -- so nothing of it sits on the critical path.
 
     Pixel-sharded mode, per step (W ranks, N frame rows per rank, H hidden, P pixels):
-        side:  [N, P] -> all-to-all -> [W N, P/W] for the NEXT step (slot s^1);  its denominator all-reduce (1 float)
-        main:  partial GEMM -> reduce-scatter [W N, H] (each rank keeps the sum of its own rows) -> ... -> losses ->
-               backward -> all-gather d(depth_pre) [N, H] -> [W N, H] -> fork(side: all-reduce of the replicated bucket)
-               -> weight-gradient GEMM on the owned columns -> AdamW on the owned columns -> join -> AdamW on the rest
-    Replicated mode: denominator and small bucket on the side stream, the depth_projection gradient all-reduced in stream
-    order after its GEMM.
+        stage: [N, P] -> all-to-all -> [W N, P/W] for the NEXT step (slot s^1);  its denominator
+        run:   partial GEMM -> reduce-scatter [W N, H] (each rank keeps the sum of its own rows) -> ... -> losses ->
+               backward -> all-gather d(depth_pre) [N, H] -> [W N, H] -> all-reduce of the replicated parameters' bucket
+               -> weight-gradient GEMM on the owned columns -> AdamW (owned columns + replicated parameters)
+    Replicated mode: both gradient buckets all-reduced in stream order (the small one before the depth weight-gradient
+    GEMM, the large one after it).
     """
 
     def __init__(self, dp, comm, comm_side, lr, weight_decay, fuse_adam=False):
@@ -308,14 +307,11 @@ class RcclStep:
         self.comm, self.side_comm = comm, comm_side
         self.lr, self.wd, self.fuse_adam = lr, weight_decay, fuse_adam and dp.tp is not None
         dev = self.eng.device
-        self.side = torch.cuda.Stream(dev)
         self.den = [torch.zeros(1, dtype=torch.float32, device=dev) for _ in range(2)]
         self.shards = {}
 
-    # -- what does not sit on the critical path --------------------------------------------------------------
-    def _stage_inputs(self, x_dep2d, dur, pad_idx, slot):
-        """(on the current stream) the exchanged depth shard and the duration denominator for a step that will run from
-        `slot`."""
+    def stage(self, x_dep2d, dur, pad_idx, slot):
+        """(on the current stream) everything a step that will run from `slot` needs from the other ranks beforehand."""
         W = self.dp.world
         torch.mul((dur != pad_idx).sum().to(torch.float32).reshape(1), 1.0 / W, out=self.den[slot])
         self.side_comm.all_reduce(self.den[slot])
@@ -332,35 +328,19 @@ class RcclStep:
                 torch.mul(send.view(W * N, tp.Pr), 1.0, out=recv)
             self.shards[slot] = dict(x=recv, rows=[N] * W, off=tp.rank * N, n=N, work=None)
 
-    def prime(self, x_dep2d, dur, pad_idx, slot=0):
-        """Before the first step: its own inputs (every later step finds them prefetched by its predecessor)."""
-        self._stage_inputs(x_dep2d, dur, pad_idx, slot)
-
-    # -- one step ------------------------------------------------------------------------------------------------
-    def run(self, feats, depth, lab, dur, tgt, pad_idx, training, slot=0, next_inputs=None):
-        """Enqueue (or capture) one step that consumes slot `slot`.  next_inputs = (x_dep2d, dur) of the step after it,
-        staged into slot^1 on the side stream; None = nothing to prefetch (replicated mode stages its own denominator)."""
+    def run(self, feats, depth, lab, dur, tgt, pad_idx, training, slot=0):
+        """Enqueue (or capture) one step whose staged inputs are in `slot`."""
         eng, dp, tp = self.eng, self.dp, self.tp
-        cur = torch.cuda.current_stream()
-        skip = os.environ.get("R3D_RS_SKIP", "").split(",") if torch.cuda.is_current_stream_capturing() else []
         hook, eng.grad_hook = eng.grad_hook, None
         try:
-            self.side.wait_stream(cur)
-            with torch.cuda.stream(self.side):
-                if tp is None:
-                    self._stage_inputs(None, dur, pad_idx, slot)
-                elif next_inputs is not None and "stage" not in skip:
-                    self._stage_inputs(next_inputs[0], next_inputs[1], pad_idx, slot ^ 1)
             eng.dur_den = self.den[slot]
             if tp is not None:
                 tp.ready[depth.reshape(depth.shape[0] * depth.shape[1], -1).data_ptr()] = self.shards[slot]
                 eng.forward_begin(feats, depth, lab, "train", training)
-                if "rs" not in skip:
-                    self.comm.reduce_scatter_inplace(eng._fw["w"].tp_part)
+                self.comm.reduce_scatter_inplace(eng._fw["w"].tp_part)
                 eng.forward_finish()
             else:
                 eng.forward(feats, depth, lab, "train", training)
-                cur.wait_stream(self.side)                      # the denominator
             eng.losses(lab, tgt, dur, tick=True)
             adam = dict(lr=self.lr, weight_decay=self.wd, grad_scale=dp.grad_scale) if self.fuse_adam else None
             eng.prepare_fused_adamw(adam)
@@ -368,18 +348,15 @@ class RcclStep:
             w = eng.last["w"]
             if tp is not None:
                 g = tp._buf(("dpre", w.tp_part.shape[0]), tuple(w.tp_part.shape))
-                if "ag" not in skip:
-                    self.comm.all_gather(g, w.d_dep_pre)
+                self.comm.all_gather(g, w.d_dep_pre)
                 w.tp_dpre_all = g
-            self.side.wait_stream(cur)
-            with torch.cuda.stream(self.side):
-                small = dp.small[:dp._small_live()]
-                if small.numel() and "small" not in skip:
-                    self.side_comm.all_reduce(small)
+            small = dp.small[:dp._small_live()]
+            if small.numel():
+                self.comm.all_reduce(small)
             eng.backward_depth_wgrad()
             if tp is None:
                 self.comm.all_reduce(dp.big)
             eng.adamw(self.lr, self.wd, grad_scale=dp.grad_scale, ticked=True, skip_depth=self.fuse_adam,
-                      prefill_dropout=True, before_flat=lambda: cur.wait_stream(self.side))
+                      prefill_dropout=True)
         finally:
             eng.grad_hook = hook

@@ -226,11 +226,12 @@ def _run_rccl_step(fx, rank, pixel_shard, steps):
     rs = RcclStep(dp, _DistAsRccl(), _DistAsRccl(), m["lr"], m["wd"])
     batches = [[t.cuda() for t in fixture_batch(fx, seed=100 + 10 * s + rank)] for s in range(steps)]
     x2d = [b[1].reshape(m["B"] * m["S"], -1) for b in batches]
-    rs.prime(x2d[0], batches[0][3], m["pad_idx"], 0)
+    rs.stage(x2d[0], batches[0][3], m["pad_idx"], 0)
     losses = []
     for s, (feats, depth, lab, dur, tgt) in enumerate(batches):
-        nxt = (x2d[s + 1], batches[s + 1][3]) if (dp.tp is not None and s + 1 < steps) else None
-        rs.run(feats, depth, lab, dur, tgt, m["pad_idx"], False, slot=s % 2 if dp.tp is not None else 0, next_inputs=nxt)
+        if s + 1 < steps:                                             # the next step's inputs, one step ahead
+            rs.stage(x2d[s + 1], batches[s + 1][3], m["pad_idx"], (s + 1) % 2)
+        rs.run(feats, depth, lab, dur, tgt, m["pad_idx"], False, slot=s % 2)
         torch.cuda.synchronize()
         losses.append(eng.last["w"].loss.clone())
     if dp.tp is not None:

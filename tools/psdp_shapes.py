@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Times the pixel-sharded depth projection's two GEMMs at the per-rank shapes of W = 1, 2, 4, 8 ranks (same FLOPs at
+every W): forward [W*128, P/W] x [128, P/W]^T and weight gradient [W*128, 128]^T x [W*128, P/W]; planner's choice vs a
+sweep of (tile, splitk)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from r3d_amd import ops
+from tools.gemm_sweep import time_graph
+
+ws = ops.GemmWorkspace("cuda")
+ws.get(64 * 1024 * 1024)
+P, H, N = 50176, 128, 128
+for W in (1, 2, 4, 8):
+    for name, layout, M, Nn, K in (("fwd", 0, W * N, H, P // W), ("wgrad", 2, H, P // W, W * N)):
+        sa = (M, K) if layout == 0 else (K, M)
+        sb = (Nn, K) if layout == 0 else (K, Nn)
+        A = torch.randn(*sa, device="cuda"); B = torch.randn(*sb, device="cuda"); C = torch.empty(M, Nn, device="cuda")
+        d = ops.gemm(layout, A, B, C, ws=ws)
+        auto = time_graph(lambda: ops.gemm(layout, A, B, C, ws=ws))
+        best = []
+        for tile in (1, 2, 3, 4, 5, 6):
+            for sk in (1, 2, 4, 7, 8, 14, 16, 28, 32, 49, 64, 98, 128, 196):
+                if sk > 1 and K // sk < 128:
+                    continue
+                try:
+                    t = time_graph(lambda: ops.gemm(layout, A, B, C, ws=ws, tile=tile, splitk=sk))
+                except Exception:
+                    continue
+                best.append((round(t, 1), tile, sk))
+        best.sort()
+        print(f"W={W} {name} M={M} N={Nn} K={K}: auto tile={d.tile} sk={d.splitk} {auto:.1f} us | best {best[:4]}", flush=True)
