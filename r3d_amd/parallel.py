@@ -346,13 +346,14 @@ class RcclStep:
             eng.prepare_fused_adamw(adam)
             eng.backward_main()
             w = eng.last["w"]
-            if tp is not None:
-                g = tp._buf(("dpre", w.tp_part.shape[0]), tuple(w.tp_part.shape))
-                self.comm.all_gather(g, w.d_dep_pre)
-                w.tp_dpre_all = g
             small = dp.small[:dp._small_live()]
-            if small.numel():
-                self.comm.all_reduce(small)
+            with self.comm.group():                 # one submission: the gather the weight-gradient GEMM waits for and
+                if tp is not None:                  # the replicated parameters' gradient bucket
+                    g = tp._buf(("dpre", w.tp_part.shape[0]), tuple(w.tp_part.shape))
+                    self.comm.all_gather(g, w.d_dep_pre)
+                    w.tp_dpre_all = g
+                if small.numel():
+                    self.comm.all_reduce(small)
             eng.backward_depth_wgrad()
             if tp is None:
                 self.comm.all_reduce(dp.big)

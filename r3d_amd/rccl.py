@@ -65,6 +65,16 @@ def _stream(stream):
     return ctypes.c_void_p((stream if stream is not None else torch.cuda.current_stream()).cuda_stream)
 
 
+class _Group:
+    def __enter__(self):
+        _check(_load().ncclGroupStart(), "ncclGroupStart")
+        return self
+
+    def __exit__(self, *exc):
+        _check(_load().ncclGroupEnd(), "ncclGroupEnd")
+        return False
+
+
 class RcclComm:
     """One RCCL communicator over the ranks of a torch.distributed group.  Every method enqueues on the current (or
     given) torch stream and returns at once; nothing here synchronises the device or allocates."""
@@ -92,6 +102,11 @@ class RcclComm:
         if getattr(self, "_comm", None):
             _load().ncclCommDestroy(self._comm)
             self._comm = None
+
+    def group(self):
+        """with comm.group(): ...  -- the collectives enqueued inside are submitted together (ncclGroupStart/End), so
+        RCCL can launch them as one kernel instead of one per call."""
+        return _Group()
 
     @staticmethod
     def _ok(*tensors):

@@ -27,8 +27,15 @@ o = torch.zeros(1024, dtype=torch.float32, device=dev)
 c.all_gather(o, x); torch.cuda.synchronize(); print("all_gather", float(o.sum()), flush=True)
 r = torch.zeros(1024, dtype=torch.float32, device=dev)
 c.all_to_all(r, x); torch.cuda.synchronize(); print("all_to_all", float(r.sum()), flush=True)
+with c.group():
+    c.all_gather(o, x)
+    c.all_reduce(x)
+torch.cuda.synchronize(); print("group ok", flush=True)
 g = torch.cuda.CUDAGraph()
 with torch.cuda.graph(g):
+    with c.group():
+        c.all_gather(o, x)
+        c.all_reduce(y)
     c.all_reduce(x)
     c.reduce_scatter_inplace(y)
     c.all_gather(o, x)
