@@ -58,6 +58,9 @@ parser.add_argument("--restore_train_mode", action="store_true", default=False,
                     help="call model.train() after validate(); the reference does not (train_proposed_depth.py:53,235)")
 parser.add_argument("--min_batch", type=int, default=8,
                     help="batches smaller than this are skipped, as in the reference (train_proposed_depth.py:148)")
+parser.add_argument("--torch_collectives", action="store_true", default=False,
+                    help="multi-GPU only: gradient exchanges through torch.distributed (three graphs per step) instead of RCCL "
+                         "enqueued on the launch stream inside the step's one graph (r3d_amd/rccl.py)")
 parser.add_argument("--pixel_shard", action="store_true", default=False,
                     help="multi-GPU only: shard depth_projection.weight (and its AdamW state) over pixels across ranks "
                          "instead of all-reducing its gradient (r3d_amd/parallel.py); same mathematics")

@@ -328,11 +328,20 @@ class RcclStep:
                 torch.mul(send.view(W * N, tp.Pr), 1.0, out=recv)
             self.shards[slot] = dict(x=recv, rows=[N] * W, off=tp.rank * N, n=N, work=None)
 
-    def run(self, feats, depth, lab, dur, tgt, pad_idx, training, slot=0):
-        """Enqueue (or capture) one step whose staged inputs are in `slot`."""
+    def run(self, feats, depth, lab, dur, tgt, pad_idx, training, slot=0, lr=None, hyper=None, after_losses=None,
+            stage_den=False, prefill_dropout=True):
+        """Enqueue (or capture) one step whose staged inputs are in `slot`.
+        stage_den: compute and all-reduce the loss denominator inside the step (a loop that only sees a batch when its
+        step starts cannot stage it a step ahead); lr / hyper = (weight_decay, betas, eps): override the constructor's;
+        after_losses(loss, counts): called where the loss kernel's outputs exist (epoch accumulators)."""
         eng, dp, tp = self.eng, self.dp, self.tp
         hook, eng.grad_hook = eng.grad_hook, None
+        wd, betas, eps = hyper if hyper is not None else (self.wd, (0.9, 0.999), 1e-8)
+        lr = self.lr if lr is None else lr
         try:
+            if stage_den:
+                torch.mul((dur != pad_idx).sum().to(torch.float32).reshape(1), 1.0 / dp.world, out=self.den[slot])
+                self.comm.all_reduce(self.den[slot])
             eng.dur_den = self.den[slot]
             if tp is not None:
                 tp.ready[depth.reshape(depth.shape[0] * depth.shape[1], -1).data_ptr()] = self.shards[slot]
@@ -341,8 +350,10 @@ class RcclStep:
                 eng.forward_finish()
             else:
                 eng.forward(feats, depth, lab, "train", training)
-            eng.losses(lab, tgt, dur, tick=True)
-            adam = dict(lr=self.lr, weight_decay=self.wd, grad_scale=dp.grad_scale) if self.fuse_adam else None
+            loss, counts = eng.losses(lab, tgt, dur, tick=True)
+            if after_losses is not None:
+                after_losses(loss, counts)
+            adam = dict(lr=lr, weight_decay=wd, betas=betas, eps=eps, grad_scale=dp.grad_scale) if self.fuse_adam else None
             eng.prepare_fused_adamw(adam)
             eng.backward_main()
             w = eng.last["w"]
@@ -357,7 +368,7 @@ class RcclStep:
             eng.backward_depth_wgrad()
             if tp is None:
                 self.comm.all_reduce(dp.big)
-            eng.adamw(self.lr, self.wd, grad_scale=dp.grad_scale, ticked=True, skip_depth=self.fuse_adam,
-                      prefill_dropout=True)
+            eng.adamw(lr, wd, betas=betas, eps=eps, grad_scale=dp.grad_scale, ticked=True, skip_depth=self.fuse_adam,
+                      prefill_dropout=prefill_dropout)
         finally:
             eng.grad_hook = hook

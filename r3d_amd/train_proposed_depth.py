@@ -61,12 +61,13 @@ class _GraphedSteps:
     shape runs eagerly (allocations, planner), the second one is captured; lr lives in device memory and may change
     between replays, the other AdamW hyper-parameters are part of the capture (a change re-captures)."""
 
-    def __init__(self, eng, acc_loss, acc_cnt, dp=None, pad_idx=None):
-        """dp (replicated data parallel): the step becomes three graphs around the two gradient all-reduces, exactly
-        bench.py's N > 1 flow: [forward, losses, backward] -> small bucket (async, under the next graph) ->
-        [depth weight gradient] -> big bucket -> [AdamW]."""
+    def __init__(self, eng, acc_loss, acc_cnt, dp=None, pad_idx=None, rs=None):
+        """dp (replicated data parallel): with rs (parallel.RcclStep: RCCL enqueued on the launch stream) the step stays
+        ONE graph, exchanges included; otherwise it becomes three graphs around the two torch.distributed all-reduces:
+        [forward, losses, backward] -> small bucket (async, under the next graph) -> [depth weight gradient] -> big bucket
+        -> [AdamW]."""
         self.eng, self.acc_loss, self.acc_cnt = eng, acc_loss, acc_cnt
-        self.dp, self.pad_idx = dp, pad_idx
+        self.dp, self.pad_idx, self.rs = dp, pad_idx, rs
         self.shapes = {}
 
     def step(self, batch, lr, hyper, training):
@@ -79,13 +80,17 @@ class _GraphedSteps:
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
         eng.set_lr(lr)
-        if self.dp is not None:
+        if self.dp is not None and self.rs is None:
             return self._step_dp(st, lr, hyper, training)
         if st["graph"] is not None and st["hyper"] == hyper:
             st["graph"].replay()
             return
         eng._drop_ready = None
-        run = lambda: self._enqueue(st["buf"], lr, hyper, training)         # noqa: E731
+        if self.rs is not None:
+            run = lambda: self.rs.run(*st["buf"], self.pad_idx, training, slot=0, lr=lr, hyper=hyper,     # noqa: E731
+                                      after_losses=self._accumulate, stage_den=True, prefill_dropout=False)
+        else:
+            run = lambda: self._enqueue(st["buf"], lr, hyper, training)     # noqa: E731
         if st["seen"] == 0 or st["hyper"] not in (None, hyper):
             run()                                                           # eager: sizes every workspace
             st["seen"], st["hyper"], st["graph"] = 1, hyper, None
@@ -96,6 +101,10 @@ class _GraphedSteps:
             run()
         st["graph"], st["hyper"] = g, hyper
         g.replay()
+
+    def _accumulate(self, loss, counts):
+        self.acc_loss += loss
+        self.acc_cnt += counts
 
     def _step_dp(self, st, lr, hyper, training):
         eng, dp = self.eng, self.dp
@@ -191,7 +200,8 @@ def train(args, model, train_loader, optimizer, scheduler, criterion, model_save
     model.train()
     eng = core.engine()
     dp = None
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1
+                                                          or os.environ.get("R3D_REHEARSE_DIST") == "1"):
         # --pixel_shard: depth_projection tensor-parallel over pixels (parallel.PixelShardedDepth); per-rank batch sizes may
         # differ at the end of an epoch, so the row counts are exchanged every step
         dp = DataParallelStep(eng, pixel_shard=getattr(args, "pixel_shard", False), equal_batches=False)
@@ -210,7 +220,19 @@ def train(args, model, train_loader, optimizer, scheduler, criterion, model_save
     # one-GPU steps with the fused optimiser replay as hipGraphs (--no_graph_steps / args.graph_steps=False: eager)
     graphed = None
     if getattr(args, "graph_steps", True) and (dp is None or dp.tp is None):
-        graphed = _GraphedSteps(eng, acc_loss, acc_cnt, dp, pad_idx)
+        rs = None
+        if dp is not None and dp.active and dist.get_backend() == "nccl" and not getattr(args, "torch_collectives", False):
+            try:                                    # RCCL on the launch stream: the data-parallel step stays one graph
+                from .parallel import RcclStep
+                from .rccl import RcclComm
+                g0 = optimizer.param_groups[0]
+                rs = RcclStep(dp, RcclComm(), RcclComm(), g0["lr"], g0["weight_decay"])
+                if dp.rank == 0:
+                    print("Data-parallel step: RCCL on the launch stream, one hipGraph per step")
+            except Exception as e:                  # noqa: BLE001  (no librccl beside torch, communicator refused, ...)
+                print(f"RCCL step unavailable ({type(e).__name__}: {e}); using torch.distributed all-reduces")
+                rs = None
+        graphed = _GraphedSteps(eng, acc_loss, acc_cnt, dp, pad_idx, rs)
     for epoch in range(args.epochs):
         acc_loss.zero_()
         acc_cnt.zero_()

@@ -291,3 +291,59 @@ def test_rccl_step_flow_matches_replicated_two_ranks():
         p.join(timeout=60)
     for rank, status, info in res:
         assert status == "ok", f"rank {rank}: {info}"
+
+
+def _train_rccl_worker(port, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+        torch.cuda.set_device(0)
+        import tempfile
+        from r3d_amd.train_proposed_depth import train
+        from r3d_amd.optim import FlatAdamW
+        fx = load_fixture("step_tiny")
+        m = fx["meta"]
+        batches = [fixture_batch(fx, seed=300 + 10 * s) for s in range(4)]
+        val = [[t[:1] for t in fixture_batch(fx, seed=999)]]
+        finals = []
+        for rehearse in (False, True):
+            if rehearse:                     # one-rank RCCL group: train() takes the data-parallel RcclStep path
+                dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+                os.environ["R3D_REHEARSE_DIST"] = "1"
+            model = _model(fx)
+            args = argparse.Namespace(epochs=1, input_type="i3d_transcript", seg=True, anticipate=True, task="long",
+                                      min_batch=1, graph_steps=True)
+
+            class NoSched:
+                def step(self):
+                    pass
+            opt = FlatAdamW(model.parameters(), 1e-3, weight_decay=5e-3)
+            import contextlib
+            import io
+            out = io.StringIO()
+            with tempfile.TemporaryDirectory() as d, contextlib.redirect_stdout(out):
+                train(args, model, batches, opt, NoSched(), None, d, m["pad_idx"], torch.device("cuda"), val, seed=0)
+            torch.cuda.synchronize()
+            assert ("RCCL on the launch stream" in out.getvalue()) == rehearse, out.getvalue()
+            finals.append(model.engine().arena.params.clone())
+        os.environ.pop("R3D_REHEARSE_DIST", None)
+        d = float((finals[0] - finals[1]).abs().max())
+        assert d <= 1e-6, d
+        q.put((0, "ok", d))
+    except Exception as e:          # noqa: BLE001
+        import traceback
+        q.put((0, "fail", traceback.format_exc() + repr(e)))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_train_loop_rccl_step_one_rank_equals_single_gpu():
+    """train() on its data-parallel RcclStep path (RCCL calls captured inside the step's one hipGraph), rehearsed with a
+    one-rank RCCL communicator, ends with the parameters of the plain one-GPU loop."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_train_rccl_worker, args=(_free_port(), q))
+    p.start()
+    rank, status, info = q.get(timeout=600)
+    p.join(timeout=60)
+    assert status == "ok", info
