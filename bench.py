@@ -158,7 +158,10 @@ def rccl_probe_child(a, timeout_s=300):
         print(f"[bench] probe child could not start: {e}", file=sys.stderr, flush=True)
         return False
     try:
-        return p.wait(timeout=timeout_s) == 0
+        rc = p.wait(timeout=timeout_s)
+        if rc != 0:
+            print(f"[bench] probe child exited with {rc}; using torch.distributed exchanges", file=sys.stderr, flush=True)
+        return rc == 0
     except subprocess.TimeoutExpired:
         p.kill()
         p.wait()
@@ -200,6 +203,8 @@ def main():
                     help="rehearsal: run the multi-rank flow (process group, exchanges, graphs around them) with however "
                          "many ranks there are, even one")
     a = ap.parse_args()
+    if a.probe_child and os.environ.get("R3D_PROBE_FAIL") == "1":      # (test hook: a failing rehearsal)
+        sys.exit(3)
     # libraries write to fd 1 (RCCL prints a version banner there): stdout is kept for the one JSON line
     sys.stdout.flush()
     real_stdout = os.dup(1)
