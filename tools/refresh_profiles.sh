@@ -1,0 +1,21 @@
+#!/bin/bash
+# Runs ON the GPU box (gpurun): the round's judged artefacts into gpurun_out/final/ -- GPU test log, smoke, the default
+# bench line (with cpu_baseline), rocprofv3 kernel stats of the same command, and the two PMC passes (separate runs, no
+# trace domains besides kernel-trace) that tools/pmc_summary.py turns into the HBM-traffic table.
+set -o pipefail
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/final
+mkdir -p $O
+cd $R
+timeout -k 10 900 python -m pytest tests -q -m gpu -x > $O/tests_gpu.log 2>&1; echo "tests rc=$?"; tail -2 $O/tests_gpu.log
+timeout -k 10 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $O/smoke.log
+timeout -k 10 300 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; cut -c1-400 $O/bench.json
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o k -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline > $O/stats.log 2>&1; echo "stats rc=$?"
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o f -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/pmc_fetch.log 2>&1; echo "fetch rc=$?"
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o w -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/pmc_write.log 2>&1; echo "write rc=$?"
+F=$(find $O/pmc_fetch -name "*counter_collection.csv" | head -1); W=$(find $O/pmc_write -name "*counter_collection.csv" | head -1)
+python3 $R/tools/pmc_summary.py "$F" "$W" $O/pmc_hbm.json $O/pmc_hbm.csv && echo "pmc ok"
+cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
+find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -size +20M -delete
+ls -la $O | head -30
