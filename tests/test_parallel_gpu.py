@@ -276,14 +276,16 @@ def _rccl_step_worker(rank, world, port, q):
             dist.destroy_process_group()
 
 
-def test_rccl_step_flow_matches_replicated_two_ranks():
+@pytest.mark.parametrize("world", [2, 4])
+def test_rccl_step_flow_matches_replicated(world):
     """RcclStep (exchanges in stream order: reduce-scatter of the partial products, all-gather of d(depth_pre), the
-    prefetched all-to-all, side-stream bucket) with a gloo stand-in for the communicator == the torch.distributed
-    replicated step, over three steps with different batches (so a wrong slot or a stale prefetch shows)."""
+    staged all-to-all and denominator, grouped bucket all-reduce) with a gloo stand-in for the communicator == the
+    torch.distributed replicated step, over three steps with different batches (so a wrong slot or a stale prefetch
+    shows); 2 and 4 ranks sharing the GPU."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_rccl_step_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_rccl_step_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in procs]

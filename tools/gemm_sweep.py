@@ -25,6 +25,8 @@ def main():
     shapes = {"depth_fwd_cfg2": (0, 128, 128, 50176), "depth_wgrad_cfg2": (2, 128, 50176, 128),
               "rgb_fwd_cfg2": (0, 128, 128, 2048), "fuser_fc1_cfg2": (0, 256, 512, 128), "fuser_fc2_cfg2": (0, 256, 128, 512),
               "dec_64x128x128": (0, 64, 128, 128), "depth_fwd_cfg4": (0, 512, 512, 50176), "depth_wgrad_cfg4": (2, 512, 50176, 512)}
+    shapes["sq4096"] = (0, 4096, 4096, 4096)
+    shapes["sq2048_k8192"] = (0, 2048, 2048, 8192)
     for H in (128, 512, 1024):
         for N in (128, 512, 1024):
             shapes[f"dfwd_N{N}_H{H}"] = (0, N, H, 50176)
