@@ -481,8 +481,8 @@ def main():
         good = rs is not None and launch.startswith("hipGraph (1 graph") and all(x == x and abs(x) < 1e30 for x in loss_now)
         print(f"[bench probe child rank {rank}] {'ok' if good else 'NOT ok'}: {launch}; {dt / a.steps * 1e3:.3f} ms/step",
               file=sys.stderr, flush=True)
-        dist.destroy_process_group()
-        sys.exit(0 if good else 3)
+        sys.stderr.flush()
+        os._exit(0 if good else 3)          # no teardown: nothing of RCCL / HIP / graphs can hang the exit
     if rank == 0:
         kr = kernel_rooflines(eng, c)
         name, dom = max(kr.items(), key=lambda kv: kv[1]["seconds"])
@@ -517,7 +517,12 @@ def main():
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
     if dist_on:
-        dist.destroy_process_group()
+        # every rank is past its last collective (the barrier after the timed loop); leave without the interpreter's
+        # teardown of communicators, captured graphs and HIP state, so nothing can hang after the result is out
+        sys.stdout.flush()
+        sys.stderr.flush()
+        dist.barrier()
+        os._exit(0)
 
 
 if __name__ == "__main__":
