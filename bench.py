@@ -149,6 +149,7 @@ def rccl_probe_child(a, timeout_s=300):
     cmd = [sys.executable, os.path.abspath(__file__), "--probe-child", "--gpus", str(a.gpus), "--steps", "10", "--warmup",
            "2", "--no-cpu-baseline", "--config", a.config, "--variant", a.variant]
     for flag, on in (("--force-dist", a.force_dist), ("--replicated-depth", a.replicated_depth),
+                     ("--frame-major-input", a.frame_major_input),
                      ("--fused-adamw", a.fused_adamw), ("--eval-dropout-off", a.eval_dropout_off)):
         if on:
             cmd.append(flag)
@@ -196,6 +197,9 @@ def main():
     ap.add_argument("--torch-collectives", action="store_true",
                     help="multi-GPU: exchanges through torch.distributed (ProcessGroupNCCL's stream + event joins, several "
                          "graphs per step) instead of RCCL enqueued on the launch stream")
+    ap.add_argument("--frame-major-input", action="store_true",
+                    help="multi-GPU, sharded: keep the resident depth input [N, P] and re-lay it out every step instead of "
+                         "holding it pixel-block-major")
     ap.add_argument("--probe-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-probe", action="store_true",
                     help="multi-GPU: skip the child-process rehearsal of the RCCL step (needed under a profiler)")
@@ -247,6 +251,7 @@ def main():
     from r3d_amd.parallel import DataParallelStep
     feats, depth, lab, dur, tgt = make_inputs(c, device, seed=1 + rank)
     x_dep2d = depth.reshape(c["B"] * c["S"], -1)
+    x_stage = x_dep2d
     training = model.training
     dp = tp = None
     slot = [0]
@@ -301,13 +306,17 @@ def main():
         rebuild(want_tp)
         if a.backend == "nccl" and not a.torch_collectives:
             def rccl_trial():
-                nonlocal rs
+                nonlocal rs, x_stage
                 from r3d_amd.parallel import RcclStep
                 from r3d_amd.rccl import RcclComm
                 rs = RcclStep(dp, RcclComm(), RcclComm(), c["lr"], c["wd"], fuse_adam)
-                rs.stage(x_dep2d, dur, pad, 0)
+                if tp is not None and not a.frame_major_input:
+                    # the resident depth input in the layout the sharded projection sends: [W, N, P/W] pixel-block-major
+                    # (what a loader writes at host-to-device time); saves the 25.7 MB re-layout pass per step
+                    x_stage = x_dep2d.view(x_dep2d.shape[0], world, -1).transpose(0, 1).contiguous()
+                rs.stage(x_stage, dur, pad, 0)
                 for s in (0, 1):
-                    rs.stage(x_dep2d, dur, pad, s ^ 1)
+                    rs.stage(x_stage, dur, pad, s ^ 1)
                     rs.run(feats, depth, lab, dur, tgt, pad, training, slot=s)
             if not agreed(rccl_trial):
                 rs = None
@@ -320,7 +329,7 @@ def main():
         gscale = 1.0
     if rs is not None:
         def step_eager():                   # noqa: F811  (same step, exchanges enqueued by RCCL on this stream)
-            rs.stage(x_dep2d, dur, pad, slot[0] ^ 1)            # the next step's inputs
+            rs.stage(x_stage, dur, pad, slot[0] ^ 1)            # the next step's inputs
             rs.run(feats, depth, lab, dur, tgt, pad, training, slot=slot[0])
             slot[0] ^= 1
     for _ in range(3):
@@ -342,7 +351,7 @@ def main():
                 for s_ in (0, 1):
                     S[s_] = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(S[s_], stream=side):                        # next-step inputs: their own graph
-                        rs.stage(x_dep2d, dur, pad, s_)
+                        rs.stage(x_stage, dur, pad, s_)
                     eng._drop_ready = eng.last["w"] if training else None             # masks come from the AdamW launch
                     G[s_] = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(G[s_]):

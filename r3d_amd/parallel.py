@@ -316,15 +316,21 @@ class RcclStep:
         torch.mul((dur != pad_idx).sum().to(torch.float32).reshape(1), 1.0 / W, out=self.den[slot])
         self.side_comm.all_reduce(self.den[slot])
         if self.tp is not None:
-            tp, N = self.tp, x_dep2d.shape[0]
-            send = tp._buf(("send", N, slot), (W, N, tp.Pr))
+            tp = self.tp
+            # x_dep2d: [N, P] frame rows (re-laid out here, one 25.7 MB pass), or already [W, N, P/W] pixel-block-major --
+            # the layout the input pipeline can produce for free at host-to-device time -- which is sent as it is
+            blocked = x_dep2d.dim() == 3
+            N = x_dep2d.shape[1] if blocked else x_dep2d.shape[0]
             recv = tp._buf(("recv", W * N, slot), (W * N, tp.Pr))
+            send = x_dep2d if blocked else tp._buf(("send", N, slot), (W, N, tp.Pr))
             if W > 1:
-                send.copy_(x_dep2d.view(N, W, tp.Pr).transpose(0, 1))
+                if not blocked:
+                    send.copy_(x_dep2d.view(N, W, tp.Pr).transpose(0, 1))
                 self.side_comm.all_to_all(recv, send)
-            else:       # (one-rank rehearsal: the same two passes as kernels -- hipGraph instantiation crashes on the
+            else:       # (one-rank rehearsal: the same passes as kernels -- hipGraph instantiation crashes on the
                         #  25.7 MB memcpy nodes that a contiguous copy_ and a self-addressed all-to-all turn into)
-                torch.mul(x_dep2d.view(W, N, tp.Pr), 1.0, out=send)
+                if not blocked:
+                    torch.mul(x_dep2d.view(W, N, tp.Pr), 1.0, out=send)
                 torch.mul(send.view(W * N, tp.Pr), 1.0, out=recv)
             self.shards[slot] = dict(x=recv, rows=[N] * W, off=tp.rank * N, n=N, work=None)
 

@@ -220,7 +220,7 @@ class _DistAsRccl:
             recv.view(-1)[j * blk:(j + 1) * blk].copy_(parts[j].view(-1)[self.rank * blk:(self.rank + 1) * blk])
 
 
-def _run_rccl_step(fx, rank, pixel_shard, steps):
+def _run_rccl_step(fx, rank, pixel_shard, steps, blocked=False):
     from r3d_amd.parallel import DataParallelStep, RcclStep
     m = fx["meta"]
     model = _model(fx)
@@ -230,6 +230,9 @@ def _run_rccl_step(fx, rank, pixel_shard, steps):
     rs = RcclStep(dp, _DistAsRccl(), _DistAsRccl(), m["lr"], m["wd"])
     batches = [[t.cuda() for t in fixture_batch(fx, seed=100 + 10 * s + rank)] for s in range(steps)]
     x2d = [b[1].reshape(m["B"] * m["S"], -1) for b in batches]
+    if blocked:                              # resident input already pixel-block-major [W, N, P/W]
+        W = dist.get_world_size()
+        x2d = [x.view(x.shape[0], W, -1).transpose(0, 1).contiguous() for x in x2d]
     rs.stage(x2d[0], batches[0][3], m["pad_idx"], 0)
     losses = []
     for s, (feats, depth, lab, dur, tgt) in enumerate(batches):
@@ -252,8 +255,8 @@ def _rccl_step_worker(rank, world, port, q):
         fx = load_fixture("step_tiny")
         lr = fx["meta"]["lr"]
         engA, _, recA = _run(fx, rank, False, 3, False)                # torch.distributed, replicated: the yardstick
-        for pixel_shard in (False, True):
-            engB, lossB = _run_rccl_step(fx, rank, pixel_shard, 3)
+        for pixel_shard, blocked in ((False, False), (True, False), (True, True)):
+            engB, lossB = _run_rccl_step(fx, rank, pixel_shard, 3, blocked)
             for s in range(3):
                 tol = 1e-5 if s == 0 else 2e-2
                 assert torch.allclose(recA[s]["loss"], lossB[s], rtol=tol, atol=1e-6), (pixel_shard, s, recA[s]["loss"],
