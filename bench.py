@@ -309,7 +309,10 @@ def main():
                 nonlocal rs, x_stage
                 from r3d_amd.parallel import RcclStep
                 from r3d_amd.rccl import RcclComm
-                rs = RcclStep(dp, RcclComm(), RcclComm(), c["lr"], c["wd"], fuse_adam)
+                # AdamW of the owned columns inside the weight-gradient GEMM's epilogue: measured on the per-rank shapes
+                # (tools/psdp_shapes.py) 8 / 5 us faster than GEMM + adamw_2d at 2 / 4 ranks, neutral at 8
+                rs = RcclStep(dp, RcclComm(), RcclComm(), c["lr"], c["wd"],
+                              fuse_adam or (tp is not None and world in (2, 4) and c["H"] <= 128))
                 if tp is not None and not a.frame_major_input:
                     # the resident depth input in the layout the sharded projection sends: [W, N, P/W] pixel-block-major
                     # (what a loader writes at host-to-device time); saves the 25.7 MB re-layout pass per step

@@ -220,14 +220,14 @@ class _DistAsRccl:
             recv.view(-1)[j * blk:(j + 1) * blk].copy_(parts[j].view(-1)[self.rank * blk:(self.rank + 1) * blk])
 
 
-def _run_rccl_step(fx, rank, pixel_shard, steps, blocked=False):
+def _run_rccl_step(fx, rank, pixel_shard, steps, blocked=False, fuse_adam=False):
     from r3d_amd.parallel import DataParallelStep, RcclStep
     m = fx["meta"]
     model = _model(fx)
     eng = model.engine()
     dp = DataParallelStep(eng, pixel_shard=pixel_shard)
     dp.broadcast_parameters()
-    rs = RcclStep(dp, _DistAsRccl(), _DistAsRccl(), m["lr"], m["wd"])
+    rs = RcclStep(dp, _DistAsRccl(), _DistAsRccl(), m["lr"], m["wd"], fuse_adam=fuse_adam)
     batches = [[t.cuda() for t in fixture_batch(fx, seed=100 + 10 * s + rank)] for s in range(steps)]
     x2d = [b[1].reshape(m["B"] * m["S"], -1) for b in batches]
     if blocked:                              # resident input already pixel-block-major [W, N, P/W]
@@ -255,8 +255,9 @@ def _rccl_step_worker(rank, world, port, q):
         fx = load_fixture("step_tiny")
         lr = fx["meta"]["lr"]
         engA, _, recA = _run(fx, rank, False, 3, False)                # torch.distributed, replicated: the yardstick
-        for pixel_shard, blocked in ((False, False), (True, False), (True, True)):
-            engB, lossB = _run_rccl_step(fx, rank, pixel_shard, 3, blocked)
+        # (sharded?, resident input already pixel-block-major?, AdamW of the owned columns inside the GEMM epilogue?)
+        for pixel_shard, blocked, fuse_adam in ((False, False, False), (True, False, False), (True, True, True)):
+            engB, lossB = _run_rccl_step(fx, rank, pixel_shard, 3, blocked, fuse_adam)
             for s in range(3):
                 tol = 1e-5 if s == 0 else 2e-2
                 assert torch.allclose(recA[s]["loss"], lossB[s], rtol=tol, atol=1e-6), (pixel_shard, s, recA[s]["loss"],

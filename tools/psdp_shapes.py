@@ -32,3 +32,21 @@ for W in (1, 2, 4, 8):
                 best.append((round(t, 1), tile, sk))
         best.sort()
         print(f"W={W} {name} M={M} N={Nn} K={K}: auto tile={d.tile} sk={d.splitk} {auto:.1f} us | best {best[:4]}", flush=True)
+
+# weight gradient + AdamW on the owned columns: separate launches vs AdamW inside the GEMM's epilogue
+lr_t = torch.full((1,), 1e-3, device="cuda"); step_t = torch.ones(1, dtype=torch.int64, device="cuda")
+for W in (1, 2, 4, 8):
+    M, Nn, K = H, P // W, W * N
+    A = torch.randn(K, M, device="cuda"); B = torch.randn(K, Nn, device="cuda")
+    Wt = torch.randn(M, Nn, device="cuda"); G = torch.empty(M, Nn, device="cuda")
+    m = torch.zeros(M, Nn, device="cuda"); v = torch.zeros(M, Nn, device="cuda")
+    adam = dict(lr_t=lr_t, step_t=step_t, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=5e-3, grad_scale=1.0 / W, m=m, v=v)
+
+    def separate():
+        ops.gemm(2, A, B, G, ws=ws)
+        ops.adamw_2d(Wt, G, m, v, lr_t, step_t, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=5e-3, grad_scale=1.0 / W)
+
+    def fused():
+        ops.gemm(2, A, B, Wt, ws=ws, adam=adam)
+    print(f"W={W} wgrad+AdamW on [{M} x {Nn}], K={K}: separate {time_graph(separate):.1f} us | fused epilogue {time_graph(fused):.1f} us",
+          flush=True)
