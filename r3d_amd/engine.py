@@ -212,6 +212,7 @@ class FusionEngine:
         self._lr_host = None
         self.dur_den = None               # device scalar set by the data-parallel wrapper
         self.score_allreduce = None       # callable(sums fp64 [2,H]) -> global row count, set by the DP wrapper
+        self.bn_sync = None               # parallel.SyncBatchNorm, set by the DP wrapper for the BN-blend variant
         self.grad_hook = None             # callable(stage) set by the DP wrapper: "small_ready" / "big_ready"
         self.tp = None                    # parallel.PixelShardedDepth: depth_projection tensor-parallel over pixels
         self._fw = None
@@ -394,7 +395,10 @@ class FusionEngine:
             # + norm1 (futr_safuser_batchnormalization.py:45-75,95; transformerblock.py:122)
             mod = self.module.fuser
             bt = bool(fw.get("bn_training", False))
-            ops.bn_stats(w.rgb, w.dep, mod.bn_rgb, mod.bn_depth, w.bn_mean, w.bn_rstd, w.bn_absg, bt)
+            if bt and self.bn_sync is not None:     # data parallel: statistics over the global batch (parallel.SyncBatchNorm)
+                self.bn_sync.forward(self, w, mod)
+            else:
+                ops.bn_stats(w.rgb, w.dep, mod.bn_rgb, mod.bn_depth, w.bn_mean, w.bn_rstd, w.bn_absg, bt)
             ops.token_select(w.bn_idx.shape[1], w.bn_idx, w.mask, score_f=w.bn_absg)
             idx, mask = w.bn_idx, w.mask
             ops.bn_blend_fwd(w.rgb, w.dep, w.bn_mean, w.bn_rstd, a.p("fuser.bn_rgb.weight"), a.p("fuser.bn_rgb.bias"),
@@ -891,9 +895,14 @@ class FusionEngine:
                              a.p("fuser.bn_depth.weight"), a.p("fuser.bn_depth.bias"), a.p("fuser.alpha").view(-1), mask[0],
                              mask[1], t[0], t[1], t[2], t[3], t[4], w.lnp_seam["n1"])
             w.bn_sums.launch()                 # column sums -> d gamma / d beta of both BatchNorms, d alpha
+            if st["bn_training"] and self.bn_sync is not None:
+                s4 = self.bn_sync.backward_sums(self, w)       # the sums over the global batch
+                sums = (s4[0], s4[1], s4[2], s4[3])
+            else:
+                sums = (a.g("fuser.bn_rgb.weight"), a.g("fuser.bn_rgb.bias"), a.g("fuser.bn_depth.weight"),
+                        a.g("fuser.bn_depth.bias"))
             ops.bn_bwd_apply(w.rgb, w.dep, w.bn_mean, w.bn_rstd, a.p("fuser.bn_rgb.weight"), a.p("fuser.bn_depth.weight"),
-                             t[0], t[2], a.g("fuser.bn_rgb.weight"), a.g("fuser.bn_rgb.bias"), a.g("fuser.bn_depth.weight"),
-                             a.g("fuser.bn_depth.bias"), w.d_rgb_pre, w.d_dep, st["bn_training"])
+                             t[0], t[2], sums[0], sums[1], sums[2], sums[3], w.d_rgb_pre, w.d_dep, st["bn_training"])
             ln_bwd("dep", w.d_dep, w.dep_pre, w.mean_d, w.rstd_d, "depth_layernorm.weight", "depth_layernorm.bias",
                    w.d_dep_pre, relu=True)
         else:

@@ -188,8 +188,76 @@ class _null:
         return False
 
 
+class _BnScratch:
+    """Stand-in for an nn.BatchNorm1d holder: the real weight, throw-away running buffers."""
+
+    def __init__(self, bn):
+        self.weight = bn.weight
+        self.running_mean = torch.zeros_like(bn.running_mean)
+        self.running_var = torch.ones_like(bn.running_var)
+        self.num_batches_tracked = None
+
+
+class SyncBatchNorm:
+    """BatchNorm statistics of the BN-blend fuser (futr_safuser_batchnormalization.py:45-46) over the global batch.
+
+    forward : every rank computes its local mean and M2 = sum (x - mean_local)^2 per channel with the same kernel as the
+              one-GPU path (two-pass, so no E[x^2] - mean^2 cancellation), one all-gather of [2 modalities x 2 x C (+ row
+              count)] floats, then Chan's parallel-variance combination in rank order (deterministic):
+              mean = sum n_r mean_r / n,  M2 = sum M2_r + sum n_r (mean_r - mean)^2.  The running statistics are updated
+              from the global moments (unbiased with the global count), as one process would.
+    backward: dx = gamma rstd (dy - sum(dy)/n - xhat sum(dy xhat)/n) needs the two sums over the global batch: the local
+              BatchNorm parameter gradients (which ARE those sums) are all-reduced as a 4 x C copy -- the arena keeps the
+              local values for the ordinary gradient bucket -- and pre-scaled by n_local / n so that the kernel's own 1/n_local
+              gives 1/n.
+    All of it is enqueued (tiny device tensors, no host read), so it is captured with the step."""
+
+    def __init__(self, dp):
+        self.dp = dp
+        self.scratch = None
+        self.eps = 1e-5
+        self.momentum = 0.1
+
+    def forward(self, eng, w, mod):
+        dp = self.dp
+        if self.scratch is None:
+            self.scratch = (_BnScratch(mod.bn_rgb), _BnScratch(mod.bn_depth))
+        N, C = w.rgb.shape
+        ops.bn_stats(w.rgb, w.dep, self.scratch[0], self.scratch[1], w.bn_mean, w.bn_rstd, w.bn_absg, True)
+        var_l = (1.0 / (w.bn_rstd * w.bn_rstd) - self.eps).clamp_min_(0.0)
+        pack = torch.cat([w.bn_mean.reshape(-1), (var_l * float(N)).reshape(-1),
+                          torch.full((1,), float(N), dtype=torch.float32, device=w.rgb.device)])
+        allp = torch.empty(dp.world, pack.numel(), dtype=torch.float32, device=pack.device)
+        dp.all_gather_(allp, pack)
+        n_r = allp[:, -1:]                                          # [W, 1]
+        mean_r, m2_r = allp[:, :2 * C], allp[:, 2 * C:4 * C]
+        n = n_r.sum()
+        mean = (n_r * mean_r).sum(0) / n
+        m2 = m2_r.sum(0) + (n_r * (mean_r - mean) ** 2).sum(0)
+        var = m2 / n
+        w.bn_mean.copy_(mean.view(2, C))
+        w.bn_rstd.copy_(torch.rsqrt(var + self.eps).view(2, C))
+        w.bn_nfrac = float(N) / n                                    # device scalar: n_local / n
+        unb = (var * (n / (n - 1.0))).view(2, C)
+        for t, bn in enumerate((mod.bn_rgb, mod.bn_depth)):
+            bn.running_mean.mul_(1.0 - self.momentum).add_(mean.view(2, C)[t], alpha=self.momentum)
+            bn.running_var.mul_(1.0 - self.momentum).add_(unb[t], alpha=self.momentum)
+            bn.num_batches_tracked.add_(1)
+
+    def backward_sums(self, eng, w):
+        """-> [4, C]: global (d gamma_rgb, d beta_rgb, d gamma_depth, d beta_depth), scaled by n_local / n."""
+        a = eng.arena
+        t = torch.stack([a.g("fuser.bn_rgb.weight"), a.g("fuser.bn_rgb.bias"), a.g("fuser.bn_depth.weight"),
+                         a.g("fuser.bn_depth.bias")])
+        self.dp.all_reduce_(t)
+        return t * w.bn_nfrac
+
+
 class DataParallelStep:
-    def __init__(self, engine, process_group=None, pixel_shard=False, equal_batches=True, input_group=None):
+    def __init__(self, engine, process_group=None, pixel_shard=False, equal_batches=True, input_group=None,
+                 sync_bn=True):
+        """sync_bn (BN-blend variant only): batch statistics over the GLOBAL batch, as the single-process reference sees it
+        (False = per-rank statistics, what nn.DataParallel gives the reference)."""
         self.eng = engine
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -203,11 +271,32 @@ class DataParallelStep:
         self._den = torch.zeros(1, dtype=torch.float32, device=a.grads.device)
         engine.grad_hook = self._on_stage
         engine.score_allreduce = self._scores
+        self.comm_override = None         # RcclStep: exchanges issued from inside the step go through its communicator
+        if getattr(engine, "bn", False) and sync_bn and self.active:
+            engine.bn_sync = SyncBatchNorm(self)
         if self.active:
             engine.dur_den = self._den
         self.tp = None
         if pixel_shard and self.active:
             self.tp = PixelShardedDepth(engine, process_group, equal_batches, input_group)
+
+    # -- exchanges issued from inside a step (scores, BatchNorm sums) --------------------------------------------
+    def all_reduce_(self, t):
+        if self.comm_override is not None:
+            self.comm_override.all_reduce(t)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
+
+    def all_gather_(self, out, inp):
+        """out [world, ...inp.shape] <- every rank's inp."""
+        if self.comm_override is not None:
+            self.comm_override.all_gather(out, inp)
+        elif dist.get_backend(self.pg) == "nccl":
+            dist.all_gather_into_tensor(out, inp, group=self.pg)
+        else:
+            parts = [torch.empty_like(inp) for _ in range(self.world)]
+            dist.all_gather(parts, inp, group=self.pg)
+            out.copy_(torch.stack(parts))
 
     # -- 1. gradients ------------------------------------------------------------------------------------------
     def _on_stage(self, stage):
@@ -342,6 +431,7 @@ class RcclStep:
         after_losses(loss, counts): called where the loss kernel's outputs exist (epoch accumulators)."""
         eng, dp, tp = self.eng, self.dp, self.tp
         hook, eng.grad_hook = eng.grad_hook, None
+        dp.comm_override = self.comm
         wd, betas, eps = hyper if hyper is not None else (self.wd, (0.9, 0.999), 1e-8)
         lr = self.lr if lr is None else lr
         try:
@@ -378,3 +468,4 @@ class RcclStep:
                       prefill_dropout=prefill_dropout)
         finally:
             eng.grad_hook = hook
+            dp.comm_override = None

@@ -91,3 +91,71 @@ def test_bn_variant_trains(oracle_lib):
     assert float(loss[3]) < first and torch.isfinite(loss).all()
     assert float((eng.arena.p("fuser.alpha") - a0).abs().max()) > 0
     assert int(model.fuser.bn_rgb.num_batches_tracked) == 8
+
+
+def _sync_bn_worker(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        from r3d_amd.parallel import DataParallelStep
+        fx = load_fixture("bn_tiny")
+        m = fx["meta"]
+        B, C = m["B"], m["H"]
+        gb = [torch.from_numpy(x) for x in synth.make_batch(world * B, m["S"], m["n_class"], m["pad_idx"], m["seed"] + 3,
+                                                            depth_hw=tuple(m["depth_hw"]))]
+        st0 = {}
+        for pre in ("fuser.bn_rgb.", "fuser.bn_depth."):
+            st0[pre + "running_mean"], st0[pre + "running_var"] = torch.zeros(C), torch.ones(C)
+            st0[pre + "num_batches_tracked"] = torch.zeros((), dtype=torch.long)
+        tr = O.CpuTrainer(fixture_params(fx), m["pad_idx"], 8, m["n_dec"], bn_state=st0, bn_training=True)
+        tr.step(gb, apply=False)                          # the single-process reference view: one batch of world*B clips
+        model = _model(fx).eval()
+        eng = model.engine()
+        dp = DataParallelStep(eng)
+        assert eng.bn_sync is not None
+        mine = [t[rank * B:(rank + 1) * B].cuda() for t in gb]
+        dp.prepare_duration_denominator(mine[3], m["pad_idx"])
+        eng.forward(mine[0], mine[1], mine[2], "train", training=False, bn_training=True)
+        eng.losses(mine[2], mine[4], mine[3])
+        eng.backward()
+        dp.wait_grads()
+        torch.cuda.synchronize()
+        live = json.loads(str(fx["live_names"])) if not isinstance(fx["live_names"], list) else fx["live_names"]
+        for n in live:
+            close_rel(eng.arena.g(n) * dp.grad_scale, tr.p[n].grad, f"sync-bn grad {n}", rtol=2e-3)
+        sd = model.state_dict()
+        for pre in ("fuser.bn_rgb.", "fuser.bn_depth."):
+            assert_close(sd[pre + "running_mean"].float().cpu(), tr.bn_state[pre + "running_mean"], 1e-4, 1e-6, pre + "mean")
+            assert_close(sd[pre + "running_var"].float().cpu(), tr.bn_state[pre + "running_var"], 1e-4, 1e-6, pre + "var")
+            assert int(sd[pre + "num_batches_tracked"]) == 1
+        q.put((rank, "ok", ""))
+    except Exception as e:          # noqa: BLE001
+        import traceback
+        q.put((rank, "fail", traceback.format_exc() + repr(e)))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_bn_variant_sync_statistics_two_ranks(oracle_lib):
+    """Data parallel BN-blend variant (2 ranks on one GPU, gloo): with the global-batch BatchNorm statistics of
+    parallel.SyncBatchNorm the averaged rank gradients and the running statistics equal the oracle's on the whole batch."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sync_bn_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, status, info in res:
+        assert status == "ok", f"rank {rank}: {info}"
