@@ -276,6 +276,16 @@ int r3d_bn_bwd_apply(const float* rgb, const float* dep, const float* mean, cons
                      const float* gamma_dep, const float* t_drb, const float* t_ddb, const float* dgamma_rgb,
                      const float* dbeta_rgb, const float* dgamma_dep, const float* dbeta_dep, float* d_rgb_pre, float* d_dep,
                      int N, int C, int training, void* stream);
+/* Data-parallel BatchNorm for that fuser (the statistics of the GLOBAL batch, as one process running the reference sees
+ * them; replaces what torch.nn.SyncBatchNorm would do for futr_safuser_batchnormalization.py:45-46):
+ * r3d_bn_sync_pack     : the local moments left by r3d_bn_stats -> out [4C + 1] = (mean [2][C], M2 = N var [2][C], N);
+ * r3d_bn_sync_finalize : all [world][4C + 1] (every rank's pack, rank order) -> global mean / rstd [2][C] by Chan's
+ *                        parallel-variance combination, running-statistics update from the global moments, nfrac[0] =
+ *                        n_local / n_global. */
+int r3d_bn_sync_pack(const float* mean, const float* rstd, int N, int C, float* out, void* stream);
+int r3d_bn_sync_finalize(const float* all, int world, int n_local, int C, float* mean, float* rstd, float* run_mean_rgb,
+                         float* run_var_rgb, int64_t* nbt_rgb, float* run_mean_dep, float* run_var_dep, int64_t* nbt_dep,
+                         float* nfrac, float momentum, void* stream);
 
 /* ---- the decoder's tail, one launch per direction (row-local on the B*Q query rows) ------------------------------
  * forward : last layer's norm3 (transformer.py:329) -> decoder.norm (:182-183) -> heads fc | fc_len as one [n_head, H]

@@ -110,6 +110,8 @@ _SIGNATURES = {
     "r3d_bn_blend_fwd": ([_P] * 12 + [_F] + [_P] * 6 + [_I, _I, _P], C.c_int),
     "r3d_bn_blend_bwd": ([_P] * 7 + [_F] + [_P] * 17 + [_I, _I, _P], C.c_int),
     "r3d_bn_bwd_apply": ([_P] * 14 + [_I, _I, _I, _P], C.c_int),
+    "r3d_bn_sync_pack": ([_P, _P, _I, _I, _P, _P], C.c_int),
+    "r3d_bn_sync_finalize": ([_P, _I, _I, _I] + [_P] * 9 + [_F, _P], C.c_int),
     "r3d_decoder_tail_fwd": ([_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P], C.c_int),
     "r3d_decoder_tail_bwd": ([_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I,
                               _P], C.c_int),

@@ -211,6 +211,55 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnApplyArgs a) 
     }
 }
 
+// ---- data-parallel BatchNorm (parallel.SyncBatchNorm): moments of the global batch from per-rank moments -------------
+// pack    : out [4C + 1] = (local mean [2][C], local M2 = N * var [2][C], N)   (var recovered from rstd: 1/rstd^2 - eps)
+// finalize: all [W][4C + 1] (rank order) -> Chan's combination  mean = sum n_r mean_r / n,  M2 = sum M2_r + sum n_r
+//           (mean_r - mean)^2  in rank order (deterministic); writes mean / rstd [2][C], the nn.BatchNorm1d running-statistics
+//           update from the global moments (unbiased with the global count), num_batches_tracked += 1, and
+//           nfrac = n_local / n (the factor that turns bn_bwd_apply's 1 / n_local into 1 / n).
+__global__ __launch_bounds__(256) void bn_sync_pack_kernel(const float* mean, const float* rstd, int N, int C, float* out) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < 2 * C; i += gridDim.x * 256) {
+        const float r = rstd[i];
+        out[i] = mean[i];
+        out[2 * C + i] = fmaxf(1.0f / (r * r) - kEpsBN, 0.f) * (float)N;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[4 * C] = (float)N;
+}
+
+struct BnSyncArgs {
+    const float* all; int W, n_local, C; float* mean; float* rstd; float* run_mean[2]; float* run_var[2]; int64_t* nbt[2];
+    float* nfrac; float momentum;
+};
+
+__global__ __launch_bounds__(256) void bn_sync_finalize_kernel(const BnSyncArgs a) {
+    const int C = a.C, L = 4 * C + 1;
+    float n = 0.f;
+    for (int r = 0; r < a.W; ++r) n += a.all[(size_t)r * L + 4 * C];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < 2 * C; i += gridDim.x * 256) {
+        float sm = 0.f;
+        for (int r = 0; r < a.W; ++r) sm += a.all[(size_t)r * L + 4 * C] * a.all[(size_t)r * L + i];
+        const float mean = sm / n;
+        float m2 = 0.f, between = 0.f;
+        for (int r = 0; r < a.W; ++r) {
+            const float d = a.all[(size_t)r * L + i] - mean;
+            m2 += a.all[(size_t)r * L + 2 * C + i];
+            between += a.all[(size_t)r * L + 4 * C] * d * d;
+        }
+        const float var = (m2 + between) / n;
+        a.mean[i] = mean;
+        a.rstd[i] = 1.0f / sqrtf(var + kEpsBN);
+        const int t = i / C, c = i - t * C;
+        const float unb = n > 1.f ? var * (n / (n - 1.f)) : var;
+        a.run_mean[t][c] = (1.f - a.momentum) * a.run_mean[t][c] + a.momentum * mean;
+        a.run_var[t][c] = (1.f - a.momentum) * a.run_var[t][c] + a.momentum * unb;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        a.nfrac[0] = (float)a.n_local / n;
+        if (a.nbt[0]) *a.nbt[0] += 1;
+        if (a.nbt[1]) *a.nbt[1] += 1;
+    }
+}
+
 }  // namespace r3d
 
 using namespace r3d;
@@ -295,6 +344,29 @@ R3D_EXPORT int r3d_bn_bwd_apply(const float* rgb, const float* dep, const float*
     const size_t total = (size_t)N * C;
     const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    R3D_LAUNCH_CHECK();
+    return R3D_OK;
+}
+
+/* Data-parallel BatchNorm, step 1: the local moments r3d_bn_stats left in mean / rstd [2][C] (N rows) packed for the
+ * exchange: out [4C + 1] = (mean, M2 = N * var, N). */
+R3D_EXPORT int r3d_bn_sync_pack(const float* mean, const float* rstd, int N, int C, float* out, void* stream) {
+    R3D_REQUIRE(mean && rstd && out && N > 0 && C > 0);
+    hipLaunchKernelGGL(bn_sync_pack_kernel, dim3(r3d_cdiv(2 * C, 256)), dim3(256), 0, (hipStream_t)stream, mean, rstd, N, C, out);
+    R3D_LAUNCH_CHECK();
+    return R3D_OK;
+}
+
+/* Data-parallel BatchNorm, step 2: all [world][4C + 1] = every rank's pack in rank order -> global mean / rstd [2][C],
+ * running-statistics update from the global moments, nfrac[0] = n_local / n_global. */
+R3D_EXPORT int r3d_bn_sync_finalize(const float* all, int world, int n_local, int C, float* mean, float* rstd,
+                                    float* run_mean_rgb, float* run_var_rgb, int64_t* nbt_rgb, float* run_mean_dep,
+                                    float* run_var_dep, int64_t* nbt_dep, float* nfrac, float momentum, void* stream) {
+    R3D_REQUIRE(all && mean && rstd && run_mean_rgb && run_var_rgb && run_mean_dep && run_var_dep && nfrac);
+    R3D_REQUIRE(world > 0 && n_local > 0 && C > 0);
+    BnSyncArgs a{all, world, n_local, C, mean, rstd, {run_mean_rgb, run_mean_dep}, {run_var_rgb, run_var_dep},
+                 {nbt_rgb, nbt_dep}, nfrac, momentum};
+    hipLaunchKernelGGL(bn_sync_finalize_kernel, dim3(r3d_cdiv(2 * C, 256)), dim3(256), 0, (hipStream_t)stream, a);
     R3D_LAUNCH_CHECK();
     return R3D_OK;
 }

@@ -441,6 +441,21 @@ def bn_bwd_apply(rgb, dep, mean, rstd, g_r, g_d, t_drb, t_ddb, dg_r, db_r, dg_d,
                                        _stream()), "r3d_bn_bwd_apply")
 
 
+def bn_sync_pack(mean, rstd, N, out):
+    Cc = mean.shape[-1]
+    assert out.numel() == 4 * Cc + 1 and out.is_contiguous()
+    check(_lib.load().r3d_bn_sync_pack(_p(mean), _p(rstd), N, Cc, _p(out), _stream()), "r3d_bn_sync_pack")
+
+
+def bn_sync_finalize(allp, n_local, mean, rstd, bn_rgb, bn_dep, nfrac, momentum=0.1):
+    world, Cc = allp.shape[0], mean.shape[-1]
+    assert allp.is_contiguous() and allp.shape[1] == 4 * Cc + 1
+    check(_lib.load().r3d_bn_sync_finalize(_p(allp), world, n_local, Cc, _p(mean), _p(rstd), _p(bn_rgb.running_mean),
+                                           _p(bn_rgb.running_var), _p(bn_rgb.num_batches_tracked), _p(bn_dep.running_mean),
+                                           _p(bn_dep.running_var), _p(bn_dep.num_batches_tracked), _p(nfrac), momentum,
+                                           _stream()), "r3d_bn_sync_finalize")
+
+
 def decoder_tail_fwd(x, g3, b3, gF, bF, w_head, b_head, t3, m3, r3, tgtF, mF, rF, out):
     rows, H = x.shape
     assert x.is_contiguous() and t3.is_contiguous() and tgtF.is_contiguous()

@@ -215,7 +215,7 @@ class SyncBatchNorm:
     def __init__(self, dp):
         self.dp = dp
         self.scratch = None
-        self.eps = 1e-5
+        self.bufs = {}
         self.momentum = 0.1
 
     def forward(self, eng, w, mod):
@@ -224,25 +224,17 @@ class SyncBatchNorm:
             self.scratch = (_BnScratch(mod.bn_rgb), _BnScratch(mod.bn_depth))
         N, C = w.rgb.shape
         ops.bn_stats(w.rgb, w.dep, self.scratch[0], self.scratch[1], w.bn_mean, w.bn_rstd, w.bn_absg, True)
-        var_l = (1.0 / (w.bn_rstd * w.bn_rstd) - self.eps).clamp_min_(0.0)
-        pack = torch.cat([w.bn_mean.reshape(-1), (var_l * float(N)).reshape(-1),
-                          torch.full((1,), float(N), dtype=torch.float32, device=w.rgb.device)])
-        allp = torch.empty(dp.world, pack.numel(), dtype=torch.float32, device=pack.device)
-        dp.all_gather_(allp, pack)
-        n_r = allp[:, -1:]                                          # [W, 1]
-        mean_r, m2_r = allp[:, :2 * C], allp[:, 2 * C:4 * C]
-        n = n_r.sum()
-        mean = (n_r * mean_r).sum(0) / n
-        m2 = m2_r.sum(0) + (n_r * (mean_r - mean) ** 2).sum(0)
-        var = m2 / n
-        w.bn_mean.copy_(mean.view(2, C))
-        w.bn_rstd.copy_(torch.rsqrt(var + self.eps).view(2, C))
-        w.bn_nfrac = float(N) / n                                    # device scalar: n_local / n
-        unb = (var * (n / (n - 1.0))).view(2, C)
-        for t, bn in enumerate((mod.bn_rgb, mod.bn_depth)):
-            bn.running_mean.mul_(1.0 - self.momentum).add_(mean.view(2, C)[t], alpha=self.momentum)
-            bn.running_var.mul_(1.0 - self.momentum).add_(unb[t], alpha=self.momentum)
-            bn.num_batches_tracked.add_(1)
+        key = (C, dp.world)
+        if self.bufs.get("key") != key:
+            dev = w.rgb.device
+            self.bufs = dict(key=key, pack=torch.empty(4 * C + 1, dtype=torch.float32, device=dev),
+                             allp=torch.empty(dp.world, 4 * C + 1, dtype=torch.float32, device=dev),
+                             nfrac=torch.ones(1, dtype=torch.float32, device=dev))
+        b = self.bufs
+        ops.bn_sync_pack(w.bn_mean, w.bn_rstd, N, b["pack"])
+        dp.all_gather_(b["allp"], b["pack"])
+        ops.bn_sync_finalize(b["allp"], N, w.bn_mean, w.bn_rstd, mod.bn_rgb, mod.bn_depth, b["nfrac"], self.momentum)
+        w.bn_nfrac = b["nfrac"]
 
     def backward_sums(self, eng, w):
         """-> [4, C]: global (d gamma_rgb, d beta_rgb, d gamma_depth, d beta_depth), scaled by n_local / n."""
