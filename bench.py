@@ -149,7 +149,7 @@ def rccl_probe_child(a, timeout_s=300):
     cmd = [sys.executable, os.path.abspath(__file__), "--probe-child", "--gpus", str(a.gpus), "--steps", "10", "--warmup",
            "2", "--no-cpu-baseline", "--config", a.config, "--variant", a.variant]
     for flag, on in (("--force-dist", a.force_dist), ("--replicated-depth", a.replicated_depth),
-                     ("--frame-major-input", a.frame_major_input),
+                     ("--frame-major-input", a.frame_major_input), ("--separate-tail", a.separate_tail),
                      ("--fused-adamw", a.fused_adamw), ("--eval-dropout-off", a.eval_dropout_off)):
         if on:
             cmd.append(flag)
@@ -197,6 +197,8 @@ def main():
     ap.add_argument("--torch-collectives", action="store_true",
                     help="multi-GPU: exchanges through torch.distributed (ProcessGroupNCCL's stream + event joins, several "
                          "graphs per step) instead of RCCL enqueued on the launch stream")
+    ap.add_argument("--separate-tail", action="store_true",
+                    help="decoder tail forward, losses and tail backward as three launches instead of one")
     ap.add_argument("--frame-major-input", action="store_true",
                     help="multi-GPU, sharded: keep the resident depth input [N, P] and re-lay it out every step instead of "
                          "holding it pixel-block-major")
@@ -248,6 +250,7 @@ def main():
     eng = model.engine()
     eng.use_side_stream = a.side_stream
     eng.use_fused_decoder = a.fused_decoder
+    eng.defer_tail = not a.separate_tail      # forward -> losses -> backward run back to back: one tail/loss launch
     from r3d_amd.parallel import DataParallelStep
     feats, depth, lab, dur, tgt = make_inputs(c, device, seed=1 + rank)
     x_dep2d = depth.reshape(c["B"] * c["S"], -1)
@@ -299,6 +302,7 @@ def main():
                 model.eval()
             eng = model.engine()
             eng.use_side_stream = a.side_stream
+            eng.defer_tail = not a.separate_tail
             dp = DataParallelStep(eng, pixel_shard=pixel_shard, input_group=pg_in if pixel_shard else None)
             dp.broadcast_parameters()
             tp, gscale = dp.tp, dp.grad_scale

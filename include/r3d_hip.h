@@ -312,6 +312,25 @@ int r3d_losses_fwd_bwd(const float* seg_logits, int ld_seg, const float* act_log
  * incremented once per call (the engine's step counter and dropout offset). */
 int64_t r3d_losses_ws_floats(int B, int S, int Q);
 
+/* ---- training step only: the decoder's tail, the three losses and the tail's backward as ONE launch -------------------
+ * = r3d_decoder_tail_fwd (transformer.py:329,182-183; futr_safuser_tokenfusion.py:219-226) -> r3d_losses_fwd_bwd
+ * (train_proposed_depth.py:171-213) -> r3d_decoder_tail_bwd, same arithmetic per row.  The anticipation logits live in
+ * out [B*Q, ld_out]: K action columns + 1 duration column; d_out likewise.  wsF / ws3: LayerNorm parameter-gradient
+ * partials in r3d_layernorm_bwd's layout for B*Q rows.  ws: as for r3d_losses_fwd_bwd.
+ * r3d_decoder_tail_losses_supported: hidden <= 128, K + 1 <= 24, Q == 8, B*Q <= 1024; callers fall back to the three
+ * separate entry points otherwise. */
+typedef struct r3d_tail_losses_args {
+    const float* x; const float* g3; const float* b3; const float* gF; const float* bF;
+    const float* w_head; const float* b_head; int n_head;
+    float* t3; float* m3; float* r3; float* tgtF; float* mF; float* rF; float* out; int ld_out; int H;
+    const float* seg; int ld_seg; const int64_t* past_label; const int64_t* target; const float* target_dur;
+    int B, S, Q, K, pad_idx, exclude_idx; const float* dur_den; float grad_scale;
+    float* d_seg; int ld_dseg; float* d_out; int ld_dout; float* loss_out; int64_t* counts; int64_t* tick_a; int64_t* tick_b;
+    const uint8_t* drop; float drop_scale; float* dx; float* dx2; float* wsF; float* ws3;
+} r3d_tail_losses_args;
+int r3d_decoder_tail_losses_supported(int H, int n_head, int Q, int rows);
+int r3d_decoder_tail_losses(const r3d_tail_losses_args* a, float* ws, void* stream);
+
 /* ---- optimiser / dropout masks: main_darai.py:135, train/train_proposed_depth.py:215 -------------------------- */
 /* torch.optim.AdamW semantics over flat arenas of n floats (n % 4 == 0, 16-byte aligned); g is multiplied by
  * grad_scale first (1/world after a sum all-reduce).  lr and the 1-based step are read from device memory. */

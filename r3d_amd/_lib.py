@@ -61,6 +61,19 @@ class RowsumJob(C.Structure):
                 ("ldd", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32), ("mod", C.c_int32)]
 
 
+class TailLossesArgs(C.Structure):
+    """r3d_tail_losses_args (include/r3d_hip.h)."""
+    _fields_ = ([(n, C.c_void_p) for n in ("x", "g3", "b3", "gF", "bF", "w_head", "b_head")] + [("n_head", C.c_int32)] +
+                [(n, C.c_void_p) for n in ("t3", "m3", "r3", "tgtF", "mF", "rF", "out")] +
+                [("ld_out", C.c_int32), ("H", C.c_int32), ("seg", C.c_void_p), ("ld_seg", C.c_int32),
+                 ("past_label", C.c_void_p), ("target", C.c_void_p), ("target_dur", C.c_void_p)] +
+                [(n, C.c_int32) for n in ("B", "S", "Q", "K", "pad_idx", "exclude_idx")] +
+                [("dur_den", C.c_void_p), ("grad_scale", C.c_float), ("d_seg", C.c_void_p), ("ld_dseg", C.c_int32),
+                 ("d_out", C.c_void_p), ("ld_dout", C.c_int32), ("loss_out", C.c_void_p), ("counts", C.c_void_p),
+                 ("tick_a", C.c_void_p), ("tick_b", C.c_void_p), ("drop", C.c_void_p), ("drop_scale", C.c_float)] +
+                [(n, C.c_void_p) for n in ("dx", "dx2", "wsF", "ws3")])
+
+
 class LnFinalizeJob(C.Structure):
     """struct r3d_ln_finalize_job"""
     _fields_ = [("ws", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("rows", C.c_int32), ("H", C.c_int32)]
@@ -115,6 +128,8 @@ _SIGNATURES = {
     "r3d_decoder_tail_fwd": ([_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P], C.c_int),
     "r3d_decoder_tail_bwd": ([_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I,
                               _P], C.c_int),
+    "r3d_decoder_tail_losses_supported": ([_I, _I, _I, _I], C.c_int),
+    "r3d_decoder_tail_losses": ([_P, _P, _P], C.c_int),
     "r3d_losses_fwd_bwd": ([_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _F, _P, _I, _P, _I,
                             _P, _I, _P, _P, _P, _P, _P, _P], C.c_int),
     "r3d_losses_ws_floats": ([_I, _I, _I], C.c_int64),

@@ -195,6 +195,265 @@ __global__ __launch_bounds__(256) void losses_kernel(const LossArgs a, float* pa
     if (threadIdx.x == 0) *arrivals = 0u;             // ready for the next launch
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// The decoder's tail, the losses and the tail's backward in ONE launch (training step, hidden <= 128, <= 24 head outputs,
+// 8 queries per clip): three dependent row-local launches (r3d_decoder_tail_fwd -> r3d_losses_fwd_bwd ->
+// r3d_decoder_tail_bwd, 8.7 + 9.2 + 6.6 us) whose only cross-row coupling is inside a clip (the duration normalisation
+// over its Q queries) or a scalar every workgroup can recompute (the duration-mask count).
+//   workgroups [0, B)        : one clip each, wave q = query row b*Q + q:
+//        norm3 -> decoder.norm -> heads (logits also kept in LDS)  | barrier |  action CE + this row's duration gradient
+//        (from the clip's Q duration logits in LDS)  ->  heads' input gradient -> decoder.norm backward -> norm3 backward
+//        (+ dropout3), LayerNorm parameter partials folded per 4 rows = r3d_layernorm_bwd's layout for B*Q rows.
+//   workgroups [B, B + N/8)  : the segmentation rows, one wave each (losses_unit).
+//   the last workgroup to arrive adds the loss partials in a fixed order (as losses_kernel).
+// Same arithmetic, same order per row as the three kernels it replaces.
+// ---------------------------------------------------------------------------------------------------------
+constexpr float kLnEpsTL = 1e-5f;
+
+__device__ __forceinline__ void ln2_apply(const float (&x)[2], const float (&g)[2], const float (&b)[2], int H, int lane,
+                                          float (&y)[2], float& mean, float& rstd) {
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) s += (lane + 64 * e < H) ? x[e] : 0.f;
+    mean = wave_sum(s) / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const float dl = (lane + 64 * e < H) ? x[e] - mean : 0.f;
+        q += dl * dl;
+    }
+    rstd = 1.0f / sqrtf(wave_sum(q) / (float)H + kLnEpsTL);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) y[e] = (lane + 64 * e < H) ? (x[e] - mean) * rstd * g[e] + b[e] : 0.f;
+}
+
+// same partial sums over 8 waves instead of 4 (fixed order)
+__device__ __forceinline__ void losses_finalize8(const LossArgs& a, const float* part) {
+    __shared__ double red8[8][3][3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int N = a.B * a.S, BQ = a.B * a.Q;
+    double acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    for (int u = threadIdx.x; u < N + BQ + a.B; u += 512) {
+        const float vx = __hip_atomic_load(part + 4 * (size_t)u + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float vy = __hip_atomic_load(part + 4 * (size_t)u + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float vz = __hip_atomic_load(part + 4 * (size_t)u + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int g = u < N ? 0 : (u < N + BQ ? 1 : 2);
+        acc[g][0] += vx; acc[g][1] += vy; acc[g][2] += vz;
+    }
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double t = wave_sum_d(acc[g][k]);
+            if (lane == 0) red8[wave][g][k] = t;
+        }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t[3][3];
+        for (int g = 0; g < 3; ++g)
+            for (int k = 0; k < 3; ++k)
+                t[g][k] = ((red8[0][g][k] + red8[1][g][k]) + (red8[2][g][k] + red8[3][g][k])) +
+                          ((red8[4][g][k] + red8[5][g][k]) + (red8[6][g][k] + red8[7][g][k]));
+        const double msum = t[2][2] / (double)a.B;
+        const double dur_den = a.dur_den ? (double)*a.dur_den : msum;
+        const float ls = a.seg ? (float)(t[0][0] / (double)N) : 0.f;
+        const float la = (float)(t[1][0] / (double)BQ);
+        const float ld = (float)(t[2][0] / dur_den);
+        a.loss_out[0] = ls; a.loss_out[1] = la; a.loss_out[2] = ld; a.loss_out[3] = ls + la + ld;
+        a.counts[0] = (int64_t)(t[0][1] + 0.5); a.counts[1] = (int64_t)(t[0][2] + 0.5);
+        a.counts[2] = (int64_t)(t[1][1] + 0.5); a.counts[3] = (int64_t)(t[1][2] + 0.5);
+        if (a.tick_a) *a.tick_a += 1;
+        if (a.tick_b) *a.tick_b += 1;
+    }
+}
+
+constexpr int kTLHeads = 24;          // head outputs kept in registers / LDS per row (K + 1 <= 24)
+
+__global__ __launch_bounds__(512) void tail_losses_kernel(const r3d_tail_losses_args t, const LossArgs a, float* part,
+                                                          unsigned* arrivals) {
+    __shared__ float lg[8][kTLHeads + 8];            // logits of the clip's rows; column n_head-1 = duration
+    __shared__ float dl[8][kTLHeads + 8];            // their gradients
+    __shared__ float red[8][4][128];                 // LayerNorm parameter partials per wave
+    __shared__ int is_last;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int H = t.H, K = a.K, Q = a.Q, NH = t.n_head, N = a.B * a.S, BQ = a.B * a.Q;
+    if ((int)blockIdx.x < a.B) {
+        const int b = blockIdx.x, row = b * Q + wave;            // Q == 8 == waves (validated by the host)
+        int cc[2];
+        float x[2], g3[2], b3[2], gF[2], bF[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int c = lane + 64 * e;
+            cc[e] = c < H ? c : H - 1;
+            x[e] = t.x[(size_t)row * H + cc[e]];
+            g3[e] = t.g3[cc[e]]; b3[e] = t.b3[cc[e]]; gF[e] = t.gF[cc[e]]; bF[e] = t.bF[cc[e]];
+        }
+        float wh[kTLHeads][2];
+#pragma unroll
+        for (int k = 0; k < kTLHeads; ++k) {
+            const int kc = k < NH ? k : NH - 1;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) wh[k][e] = t.w_head[(size_t)kc * H + cc[e]];
+        }
+        // backward operands that do not depend on anything computed here: issued now, consumed after the barrier
+        float keep[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) keep[e] = t.drop ? t.drop_scale * (float)t.drop[(size_t)row * H + cc[e]] : 1.f;
+        // ---- forward tail: norm3 -> decoder.norm -> heads
+        float y3[2], yF[2], m3, r3, mF, rF;
+        ln2_apply(x, g3, b3, H, lane, y3, m3, r3);
+        ln2_apply(y3, gF, bF, H, lane, yF, mF, rF);
+        if (lane == 0) { t.m3[row] = m3; t.r3[row] = r3; t.mF[row] = mF; t.rF[row] = rF; }
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+            if (lane + 64 * e < H) {
+                t.t3[(size_t)row * H + lane + 64 * e] = y3[e];
+                t.tgtF[(size_t)row * H + lane + 64 * e] = yF[e];
+            }
+        {
+            float p[kTLHeads];
+#pragma unroll
+            for (int k = 0; k < kTLHeads; ++k) p[k] = yF[0] * wh[k][0] + yF[1] * wh[k][1];
+#pragma unroll
+            for (int k = 0; k < kTLHeads; ++k) {
+                if (k < NH) {                                     // wave-uniform
+                    const float v = wave_sum(p[k]) + t.b_head[k];
+                    if (lane == 0) { t.out[(size_t)row * t.ld_out + k] = v; lg[wave][k] = v; }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- losses of this row: anticipation CE (cal_weighted_loss) ...
+        float out_l, out_c, out_v;
+        {
+            int last = -1;
+            for (int s = lane; s < a.S; s += 64)
+                if (a.past_label[(size_t)b * a.S + s] != (int64_t)a.pad_idx) last = s;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) last = max(last, __shfl_xor(last, off, 64));
+            const int64_t ref = (last >= 0) ? a.past_label[(size_t)b * a.S + last] : (int64_t)a.pad_idx;
+            const float w = (ref == a.target[(size_t)b * Q]) ? 1.0f : 10.0f;
+            const int64_t lab = a.target[row];
+            const bool valid = (lab != (int64_t)a.pad_idx) && (lab != (int64_t)a.exclude_idx) && lab >= 0 && lab < K;
+            int am;
+            const float l = ce_row(&lg[wave][0], K, lab, valid, a.pad_idx, w * a.grad_scale / (float)BQ, &dl[wave][0], lane, &am);
+            out_l = l * w; out_v = valid ? 1.f : 0.f; out_c = (valid && (int64_t)am == lab) ? 1.f : 0.f;
+            if (lane == 0) {
+                __hip_atomic_store(part + 4 * (size_t)(N + row) + 0, out_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(part + 4 * (size_t)(N + row) + 1, out_c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(part + 4 * (size_t)(N + row) + 2, out_v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        // ... and the duration MSE (normalize_duration over the clip's Q queries; every wave redoes the clip's sums,
+        // wave 0 reports the clip's loss term)
+        {
+            float mc = 0.f;
+            for (int e = lane; e < BQ; e += 64) mc += (a.target_dur[e] != (float)a.pad_idx) ? 1.f : 0.f;
+            mc = wave_sum(mc);
+            const float dur_den = a.dur_den ? *a.dur_den : mc;
+            float ssum = 0.f;
+            for (int q = lane; q < Q; q += 64) {
+                const float td = a.target_dur[(size_t)b * Q + q];
+                const float mk = (td != (float)a.pad_idx) ? 1.f : 0.f;
+                ssum += fabsf(expf(lg[q][K]) * mk);
+            }
+            ssum = wave_sum(ssum);
+            const float den = fmaxf(ssum, 1e-12f);
+            float sq = 0.f, gp = 0.f;
+            for (int q = lane; q < Q; q += 64) {
+                const float td = a.target_dur[(size_t)b * Q + q];
+                const float mk = (td != (float)a.pad_idx) ? 1.f : 0.f;
+                const float p = expf(lg[q][K]) * mk / den;
+                const float tt = td * mk * mk;
+                const float diff = p - tt;
+                sq += diff * diff;
+                gp += (2.f * diff / dur_den) * p;
+            }
+            sq = wave_sum(sq);
+            gp = wave_sum(gp);
+            if (lane == 0) {
+                const float td = a.target_dur[(size_t)b * Q + wave];
+                const float mk = (td != (float)a.pad_idx) ? 1.f : 0.f;
+                const float p = expf(lg[wave][K]) * mk / den;
+                const float g = 2.f * (p - td * mk * mk) / dur_den;
+                dl[wave][K] = ((ssum >= 1e-12f) ? p * (g - gp) : 0.f) * a.grad_scale;
+                if (wave == 0) {
+                    const size_t u = (size_t)N + BQ + b;
+                    __hip_atomic_store(part + 4 * u + 0, sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(part + 4 * u + 1, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(part + 4 * u + 2, mc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        // the row's gradient leaves for the heads' weight gradient (a later grouped GEMM reads it from memory)
+        for (int k = lane; k < NH; k += 64) t.d_out[(size_t)row * t.ld_dout + k] = dl[wave][k];
+        // ---- backward tail: heads' input gradient -> decoder.norm backward -> norm3 backward (+ dropout3)
+        float d[2] = {0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < kTLHeads; ++k) {
+            if (k < NH) {
+                const float dk = dl[wave][k];
+                d[0] += dk * wh[k][0]; d[1] += dk * wh[k][1];
+            }
+        }
+        float agF[2], abF[2], ag3[2], ab3[2], xh[2], gg[2], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const bool in = lane + 64 * e < H;
+            xh[e] = in ? (y3[e] - mF) * rF : 0.f;
+            const float dd = in ? d[e] : 0.f;
+            agF[e] = dd * xh[e]; abF[e] = dd;
+            gg[e] = dd * gF[e];
+            s1 += gg[e]; s2 += gg[e] * xh[e];
+        }
+        s1 = wave_sum(s1) / (float)H; s2 = wave_sum(s2) / (float)H;
+        float dt[2], u1 = 0.f, u2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) dt[e] = rF * (gg[e] - s1 - xh[e] * s2);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const bool in = lane + 64 * e < H;
+            xh[e] = in ? (x[e] - m3) * r3 : 0.f;
+            const float dd = in ? dt[e] : 0.f;
+            ag3[e] = dd * xh[e]; ab3[e] = dd;
+            gg[e] = dd * g3[e];
+            u1 += gg[e]; u2 += gg[e] * xh[e];
+        }
+        u1 = wave_sum(u1) / (float)H; u2 = wave_sum(u2) / (float)H;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int c = lane + 64 * e;
+            if (c < H) {
+                const float o = r3 * (gg[e] - u1 - xh[e] * u2);
+                t.dx[(size_t)row * H + c] = o;
+                t.dx2[(size_t)row * H + c] = o * keep[e];
+                red[wave][0][c] = agF[e]; red[wave][1][c] = abF[e]; red[wave][2][c] = ag3[e]; red[wave][3][c] = ab3[e];
+            }
+        }
+        __syncthreads();
+        // partials per 4 rows (waves 0-3 -> partial block 2b, waves 4-7 -> 2b+1): r3d_layernorm_bwd's layout for B*Q rows
+        for (int i = threadIdx.x; i < 2 * 4 * H; i += 512) {
+            const int half = i / (4 * H), j = i - half * 4 * H, which = j / H, c = j - which * H;
+            const int w0 = 4 * half;
+            const float s = (red[w0][which][c] + red[w0 + 1][which][c]) + (red[w0 + 2][which][c] + red[w0 + 3][which][c]);
+            float* ws = which < 2 ? t.wsF : t.ws3;
+            ws[((size_t)(2 * b + half) * 2 + (which & 1)) * H + c] = s;
+        }
+    } else {
+        const int u = ((int)blockIdx.x - a.B) * 8 + wave;
+        if (u < N) losses_unit(a, part, u, lane);
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (threadIdx.x == 0)
+        is_last = (__hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1 : 0;
+    __syncthreads();
+    if (!is_last) return;
+    losses_finalize8(a, part);
+    if (threadIdx.x == 0) *arrivals = 0u;
+}
+
 }  // namespace r3d
 
 using namespace r3d;
@@ -228,6 +487,33 @@ R3D_EXPORT int r3d_losses_fwd_bwd(const float* seg_logits, int ld_seg, const flo
                counts, tick_a, tick_b};
     const int units = B * S + B * Q + B;
     hipLaunchKernelGGL(losses_kernel, dim3(r3d_cdiv(units, 4)), dim3(256), 0, (hipStream_t)stream, a, ws,
+                       reinterpret_cast<unsigned*>(ws + 4 * (size_t)units));
+    R3D_LAUNCH_CHECK();
+    return R3D_OK;
+}
+
+/* Training step only: r3d_decoder_tail_fwd + r3d_losses_fwd_bwd + r3d_decoder_tail_bwd as one launch (see
+ * tail_losses_kernel).  Supported when r3d_decoder_tail_losses_supported(...) != 0; ws as for r3d_losses_fwd_bwd. */
+R3D_EXPORT int r3d_decoder_tail_losses_supported(int H, int n_head, int Q, int rows) {
+    return (H > 0 && H <= 128 && n_head > 0 && n_head <= kTLHeads && Q == 8 && rows > 0 && rows <= 1024 && rows % 8 == 0) ? 1 : 0;
+}
+
+R3D_EXPORT int r3d_decoder_tail_losses(const r3d_tail_losses_args* p, float* ws, void* stream) {
+    R3D_REQUIRE(p && ws);
+    const r3d_tail_losses_args& t = *p;
+    R3D_REQUIRE(t.x && t.g3 && t.b3 && t.gF && t.bF && t.w_head && t.b_head && t.t3 && t.m3 && t.r3 && t.tgtF && t.mF && t.rF);
+    R3D_REQUIRE(t.out && t.seg && t.past_label && t.target && t.target_dur && t.d_seg && t.d_out && t.loss_out && t.counts);
+    R3D_REQUIRE(t.dx && t.dx2 && t.wsF && t.ws3);
+    R3D_REQUIRE(t.B > 0 && t.S > 0 && t.K > 0 && t.n_head == t.K + 1 && t.ld_out >= t.n_head && t.ld_dout >= t.n_head);
+    R3D_REQUIRE(t.ld_seg >= t.K && t.ld_dseg >= t.K);
+    if (!r3d_decoder_tail_losses_supported(t.H, t.n_head, t.Q, t.B * t.Q)) return R3D_EINVAL;
+    if (!r3d_aligned16(ws)) return R3D_EALIGN;
+    LossArgs a{t.seg, t.ld_seg, t.out, t.ld_out, t.out + t.K, t.ld_out, t.past_label, t.target, t.target_dur, t.B, t.S, t.Q,
+               t.K, t.pad_idx, t.exclude_idx, 0, t.dur_den, t.grad_scale, t.d_seg, t.ld_dseg, t.d_out, t.ld_dout,
+               t.d_out + t.K, t.ld_dout, t.loss_out, t.counts, t.tick_a, t.tick_b};
+    const int units = t.B * t.S + t.B * t.Q + t.B;
+    const int grid = t.B + r3d_cdiv(t.B * t.S, 8);
+    hipLaunchKernelGGL(tail_losses_kernel, dim3(grid), dim3(512), 0, (hipStream_t)stream, t, a, ws,
                        reinterpret_cast<unsigned*>(ws + 4 * (size_t)units));
     R3D_LAUNCH_CHECK();
     return R3D_OK;

@@ -196,6 +196,10 @@ class FusionEngine:
         self.use_fused_decoder = False          # decoder.hip (one workgroup per clip and layer): measured 2 % slower than
                                                 # the composed launches at the bench shape since the GEMM epilogue rework
         self.use_fused_tail = True              # last norm3 + decoder.norm + heads (and their adjoints): one launch each
+        # training flows that call forward -> losses -> backward back to back set this: the tail's forward, the losses and
+        # the tail's backward then run as ONE launch inside losses() (r3d_decoder_tail_losses); the anticipation outputs
+        # of forward() are valid only after losses() in that mode
+        self.defer_tail = False
         self.use_paired_launches = True          # one-layer decoder: independent GEMMs of the two chains share launches
         self.use_fused_embed = not self.bn       # train mode: projections' slab sums + LN + exchange + norm1 in one launch
         # False: train()-state steps without dropout (parity runs against a reference whose dropout probabilities were
@@ -542,6 +546,11 @@ class FusionEngine:
                      drop_mask=self._dm2(dm(f"d3_{l}"), BQ, H), drop_scale=dsc, res1=c["t2"], ws=self.ws)
             if l == self.L - 1 and self.use_fused_tail:
                 # last norm3 + decoder.norm (:182-183) + anticipation heads (:219-226, fc | fc_len = one [K+1, H] product)
+                w._tail_done = False
+                w._tail_deferred = bool(self.defer_tail and self._fw["mode"] == "train" and hasattr(w, "glayers")
+                                        and ops.tail_losses_supported(H, self.K + 1, Q, BQ))
+                if w._tail_deferred:
+                    return                          # runs inside losses()
                 ops.decoder_tail_fwd(c["t3_pre"], a.p(pl + "norm3.weight"), a.p(pl + "norm3.bias"),
                                      a.p("transformer.decoder.norm.weight"), a.p("transformer.decoder.norm.bias"),
                                      self.w_head, self.b_head, c["t3"], c["m3"], c["r3"], w.tgtF, w.mF, w.rF, w.actdur)
@@ -599,6 +608,28 @@ class FusionEngine:
         K = self.K
         ta = self.step_t if tick else None
         tb = self.drop_offset if (tick and self.last["drop"]) else None
+        if getattr(w, "_tail_deferred", False):
+            w._tail_deferred = False
+            a, Lm = self.arena, self.L - 1
+            c, pl = w.layers[Lm], f"transformer.decoder.layers.{Lm}."
+            tail = dict(x=c["t3_pre"], g3=a.p(pl + "norm3.weight"), b3=a.p(pl + "norm3.bias"),
+                        gF=a.p("transformer.decoder.norm.weight"), bF=a.p("transformer.decoder.norm.bias"),
+                        w_head=self.w_head, b_head=self.b_head, t3=c["t3"], m3=c["m3"], r3=c["r3"], tgtF=w.tgtF, mF=w.mF,
+                        rF=w.rF, out=w.actdur)
+            if with_grad and not val_mode:
+                # forward tail + losses + backward tail: one launch (losses.hip: tail_losses_kernel)
+                drop = self.last["drop"]
+                ops.decoder_tail_losses(**tail, seg=w.seg, past_label=past_label, target=target, target_dur=target_dur,
+                                        B=w.B, S=w.S, Q=self.Q, K=K, pad_idx=self.pad_idx, exclude_idx=EXCLUDE_CLASS_IDX,
+                                        dur_den=self.dur_den, grad_scale=1.0, d_seg=w.d_seg, d_out=w.d_actdur, loss_out=w.loss,
+                                        counts=w.counts, tick_a=ta, tick_b=tb,
+                                        drop=w.drop[f"d3_{Lm}"] if drop else None, drop_scale=1.0 / (1.0 - DROP_P),
+                                        dx=w.glayers[Lm]["t3pre"], dx2=w.glayers[Lm]["ff2"], wsF=w.lnp["final"],
+                                        ws3=w.lnp[f"d3_{Lm}"], ws=w.loss_ws)
+                w._tail_done = True
+                return w.loss, w.counts
+            ops.decoder_tail_fwd(tail["x"], tail["g3"], tail["b3"], tail["gF"], tail["bF"], tail["w_head"], tail["b_head"],
+                                 tail["t3"], tail["m3"], tail["r3"], tail["tgtF"], tail["mF"], tail["rF"], tail["out"])
         ops.losses_fwd_bwd(None if val_mode else w.seg, w.actdur[:, :K], w.actdur[:, K:], K + 1, past_label, target,
                            target_dur, w.B, w.S, self.Q, K, self.pad_idx, EXCLUDE_CLASS_IDX, w.loss, w.counts,
                            val_mode=val_mode, dur_den=self.dur_den,
@@ -739,6 +770,7 @@ class FusionEngine:
         st = self.last
         w, a, H, Q, K, heads, dh, ws = st["w"], self.arena, self.H, self.Q, self.K, self.heads, self.dh, self.ws
         B, S, N, BQ = w.B, w.S, w.N, w.BQ
+        ext_grads = d_seg is not None or d_actdur is not None       # (autograd path: gradients handed in by the caller)
         if d_seg is not None and d_seg.data_ptr() != w.d_seg.data_ptr():
             w.d_seg.copy_(d_seg)
         if d_actdur is not None and d_actdur.data_ptr() != w.d_actdur.data_ptr():
@@ -767,11 +799,15 @@ class FusionEngine:
             # ---- heads' input gradient + decoder.norm backward + the last norm3 backward: one launch.  The segmentation
             # head's input gradient (only needed at the fuser's norm) rides in a later group (paired) or goes alone.
             Lm, plm = self.L - 1, f"transformer.decoder.layers.{self.L - 1}."
-            ops.decoder_tail_bwd(w.d_actdur, self.w_head, last["t3"], w.mF, w.rF, a.p("transformer.decoder.norm.weight"),
-                                 last["t3_pre"], last["m3"], last["r3"], a.p(plm + "norm3.weight"),
-                                 None if not drop else w.drop[f"d3_{Lm}"], dsc, w.glayers[Lm]["t3pre"], w.glayers[Lm]["ff2"],
-                                 a.g("transformer.decoder.norm.weight"), a.g("transformer.decoder.norm.bias"),
-                                 a.g(plm + "norm3.weight"), a.g(plm + "norm3.bias"), w.lnp["final"], w.lnp[f"d3_{Lm}"])
+            if getattr(w, "_tail_done", False) and not ext_grads:
+                w._tail_done = False                 # losses() already ran the tail's backward (r3d_decoder_tail_losses)
+            else:
+                ops.decoder_tail_bwd(w.d_actdur, self.w_head, last["t3"], w.mF, w.rF,
+                                     a.p("transformer.decoder.norm.weight"), last["t3_pre"], last["m3"], last["r3"],
+                                     a.p(plm + "norm3.weight"), None if not drop else w.drop[f"d3_{Lm}"], dsc,
+                                     w.glayers[Lm]["t3pre"], w.glayers[Lm]["ff2"], a.g("transformer.decoder.norm.weight"),
+                                     a.g("transformer.decoder.norm.bias"), a.g(plm + "norm3.weight"),
+                                     a.g(plm + "norm3.bias"), w.lnp["final"], w.lnp[f"d3_{Lm}"])
             if not paired:
                 ops.gemm(GEMM_NN, d_seg, a.p("fc_seg.weight"), w.d_fused2, ws=ws)
         else:
@@ -974,7 +1010,11 @@ class FusionEngine:
 
     def train_step(self, feats, depth, past_label, target_dur, target, lr, weight_decay, training=True):
         """forward + losses + backward + AdamW, all enqueued, no host sync.  Returns (loss[4], counts[4]) on device."""
-        self.forward(feats, depth, past_label, "train", training)
+        keep, self.defer_tail = self.defer_tail, True       # forward -> losses -> backward back to back: one tail launch
+        try:
+            self.forward(feats, depth, past_label, "train", training)
+        finally:
+            self.defer_tail = keep
         loss, counts = self.losses(past_label, target, target_dur, tick=True)
         # (backward(fused_adamw=...) + adamw(skip_depth=True) would update depth_projection.weight inside its
         #  weight-gradient GEMM; measured neutral at the bench shape, so the plain sequence stays the default)

@@ -195,7 +195,11 @@ class _FusedForward(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, eng, src, depth, labels, mode, training, names, *params):
-        out = eng.forward(src, depth, labels, mode, training=training, need_grad=True)
+        keep, eng.defer_tail = eng.defer_tail, False        # the caller reads the outputs before any loss exists
+        try:
+            out = eng.forward(src, depth, labels, mode, training=training, need_grad=True)
+        finally:
+            eng.defer_tail = keep
         ctx.eng, ctx.names, ctx.token = eng, names, eng.last
         return out["duration"].clone(), out["action"].clone(), out["seg"].clone()
 

@@ -514,6 +514,35 @@ def losses_fwd_bwd(seg, act, dur, ld_dur, past_label, target, target_dur, B, S, 
           "r3d_losses_fwd_bwd")
 
 
+def tail_losses_supported(H, n_head, Q, rows):
+    return bool(_lib.load().r3d_decoder_tail_losses_supported(H, n_head, Q, rows))
+
+
+def decoder_tail_losses(*, x, g3, b3, gF, bF, w_head, b_head, t3, m3, r3, tgtF, mF, rF, out, seg, past_label, target,
+                        target_dur, B, S, Q, K, pad_idx, exclude_idx, dur_den, grad_scale, d_seg, d_out, loss_out, counts,
+                        tick_a, tick_b, drop, drop_scale, dx, dx2, wsF, ws3, ws):
+    """r3d_decoder_tail_fwd + r3d_losses_fwd_bwd + r3d_decoder_tail_bwd in one launch (training step)."""
+    from ._lib import TailLossesArgs
+    assert past_label.dtype == torch.int64 and target.dtype == torch.int64 and target_dur.dtype == torch.float32
+    assert past_label.is_contiguous() and target.is_contiguous() and target_dur.is_contiguous()
+    for t_ in (x, t3, tgtF, dx, dx2):
+        assert t_.is_contiguous()
+    pv = lambda t_: None if t_ is None else t_.data_ptr()        # noqa: E731
+    a = TailLossesArgs()
+    for n, v in dict(x=x, g3=g3, b3=b3, gF=gF, bF=bF, w_head=w_head, b_head=b_head, t3=t3, m3=m3, r3=r3, tgtF=tgtF, mF=mF,
+                     rF=rF, out=out, seg=seg, past_label=past_label, target=target, target_dur=target_dur, dur_den=dur_den,
+                     d_seg=d_seg, d_out=d_out, loss_out=loss_out, counts=counts, tick_a=tick_a, tick_b=tick_b, drop=drop,
+                     dx=dx, dx2=dx2, wsF=wsF, ws3=ws3).items():
+        if v is not None:
+            assert v.is_cuda
+        setattr(a, n, pv(v))
+    a.n_head, a.ld_out, a.H = w_head.shape[0], _ld(out), x.shape[1]
+    a.ld_seg, a.ld_dseg, a.ld_dout = _ld(seg), _ld(d_seg), _ld(d_out)
+    a.B, a.S, a.Q, a.K, a.pad_idx, a.exclude_idx = B, S, Q, K, pad_idx, exclude_idx
+    a.grad_scale, a.drop_scale = grad_scale, drop_scale
+    check(_lib.load().r3d_decoder_tail_losses(C.byref(a), _p(ws), _stream()), "r3d_decoder_tail_losses")
+
+
 def losses_ws_floats(B, S, Q):
     return int(_lib.load().r3d_losses_ws_floats(B, S, Q))
 

@@ -424,6 +424,7 @@ class RcclStep:
         eng, dp, tp = self.eng, self.dp, self.tp
         hook, eng.grad_hook = eng.grad_hook, None
         dp.comm_override = self.comm
+        keep_defer, eng.defer_tail = eng.defer_tail, True     # forward -> losses -> backward back to back
         wd, betas, eps = hyper if hyper is not None else (self.wd, (0.9, 0.999), 1e-8)
         lr = self.lr if lr is None else lr
         try:
@@ -461,3 +462,4 @@ class RcclStep:
         finally:
             eng.grad_hook = hook
             dp.comm_override = None
+            eng.defer_tail = keep_defer

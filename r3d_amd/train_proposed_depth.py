@@ -199,6 +199,8 @@ def train(args, model, train_loader, optimizer, scheduler, criterion, model_save
     model.to(device)
     model.train()
     eng = core.engine()
+    eng.defer_tail = True       # every step here is forward -> losses -> backward: tail forward, losses and tail backward
+                                # run as one launch (validate()'s forwards carry no gradient workspace and are unaffected)
     dp = None
     if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1
                                                           or os.environ.get("R3D_REHEARSE_DIST") == "1"):
@@ -302,4 +304,5 @@ def train(args, model, train_loader, optimizer, scheduler, criterion, model_save
                 os.remove(best_save_file)
             torch.save(model.state_dict(), best_save_file)
             print(f"Best model saved with validation loss: {best_val_loss:.3f}")
+    eng.defer_tail = False
     return model

@@ -381,3 +381,35 @@ def test_effective_rank_penalty_gradients(tag, paired, oracle_lib):
     for n, p in tr.p.items():
         if p.grad is not None:
             close_rel(eng.arena.g(n), p.grad, f"{tag}/erank-penalised grad {n}", rtol=3e-3)
+
+
+def test_deferred_tail_one_launch_equals_three(oracle_lib):
+    """engine.defer_tail: the decoder tail's forward, the losses and the tail's backward as ONE launch
+    (r3d_decoder_tail_losses) give the same outputs, losses, counters and gradients as the three separate launches,
+    with and without dropout (same Philox offset => same masks)."""
+    import bench
+    c = dict(bench.CFG)
+    for training in (False, True):
+        res = []
+        for defer in (False, True):
+            model = bench.build_model(c, torch.device("cuda"))
+            if not training:
+                model.eval()
+            eng = model.engine()
+            eng.defer_tail = defer
+            feats, depth, lab, dur, tgt = bench.make_inputs(c, torch.device("cuda"), seed=5)
+            out = eng.forward(feats, depth, lab, "train", training)
+            loss, counts = eng.losses(lab, tgt, dur, tick=True)
+            assert bool(getattr(eng.last["w"], "_tail_done", False)) == defer
+            eng.backward()
+            torch.cuda.synchronize()
+            res.append(dict(loss=loss.clone(), counts=counts.clone(), grads=eng.arena.grads.clone(),
+                            act=out["action"].clone(), dur=out["duration"].clone(), step=int(eng.step_t)))
+        a, b = res
+        # (not bitwise: the compiler contracts the two-term head dot products into differently ordered FMAs)
+        assert torch.allclose(a["act"], b["act"], rtol=1e-5, atol=1e-6), float((a["act"] - b["act"]).abs().max())
+        assert torch.allclose(a["dur"], b["dur"], rtol=1e-5, atol=1e-6), float((a["dur"] - b["dur"]).abs().max())
+        assert torch.allclose(a["loss"], b["loss"], rtol=1e-5, atol=1e-7), (a["loss"], b["loss"])
+        assert torch.equal(a["counts"], b["counts"]) and a["step"] == b["step"]
+        d = (a["grads"] - b["grads"]).abs().max()
+        assert float(d) <= 2e-5 * float(a["grads"].abs().max()), (float(d), float(a["grads"].abs().max()))
