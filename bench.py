@@ -53,16 +53,28 @@ def build_model(c, device, variant="tokenfusion"):
     return m.train()
 
 
-def time_kernel(fn, iters=30, warm=5):
+def time_kernel(fn, iters=20, warm=5, reps=5):
+    """Average launch duration of fn's kernel: `iters` launches captured into a hipGraph (no host launch gaps between
+    them), replayed `reps` times with HIP events around each replay on the launch stream; the median replay is reported
+    (single replays scatter by +-10 % with the memory clock state right after the timed region)."""
     for _ in range(warm):
         fn()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # on torch's current stream,
-    e0.record()                                                                           # where ops.* launch
-    for _ in range(iters):
-        fn()
-    e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters * 1e-3          # seconds per launch
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(iters):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
+    times = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # on torch's current stream,
+        e0.record()                                                                           # where ops.* launch
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        times.append(e0.elapsed_time(e1) / iters * 1e-3)
+    return sorted(times)[len(times) // 2]              # seconds per launch
 
 
 def kernel_rooflines(eng, c):
