@@ -99,6 +99,50 @@ def kernel_rooflines(eng, c):
     return out
 
 
+def erank_field(eng):
+    """Effective rank of the last step's fused token matrix [N, H] (the quantity the metric's "effective-rank match"
+    names): the HIP one-sided Jacobi (r3d_erank_jacobi / r3d_erank_blocked, timed with HIP events on the launch stream,
+    median of 5) against torch.linalg.svdvals (LAPACK) on the CPU copy of the same matrix.  Outside the timed region.
+    The reference has no SVD: svdvals on the same tokens IS the checker BASELINE.json's tolerance
+    (+-0.5) refers to."""
+    from r3d_amd import ops
+    x = eng.last["w"].fused
+    N, H = x.shape
+    dev = x.device
+    lds = ops.erank_fits(N, H)
+    if lds:
+        sigma, stats = torch.empty(1, H, device=dev), torch.empty(1, 4, device=dev)
+        af = torch.empty(1, H, N, device=dev)
+        run = lambda: ops.erank_jacobi(x, sigma, stats, af_t=af)             # noqa: E731
+        kernel = "erank_jacobi_kernel (columns resident in one CU's LDS)"
+    else:
+        xx = x.t().contiguous() if N < H else x
+        state = {}
+
+        def run():
+            state["r"] = ops.erank_blocked(xx)
+        kernel = "erank_blk_round_kernel (two-level block Jacobi, columns in HBM/L2)"
+    run()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        run()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    st = (stats[0] if lds else state["r"][1]).cpu()
+    sv = torch.linalg.svdvals(x.detach().cpu().double())
+    pr = sv / sv.sum()
+    pr = pr[pr > 0]
+    want = float(torch.exp(-(pr * pr.log()).sum()))
+    return dict(hip=float(st[0]), svdvals=want, abs_diff=abs(float(st[0]) - want), tolerance=0.5, sweeps=float(st[3]),
+                us=sorted(ts)[2], matrix=[N, H], kernel=kernel, in_step=False,
+                note="measured after the timed region on the last step's fused tokens; the headline step runs with "
+                     "erank_weight = 0 (the reference's loss, SURVEY.md F1)")
+
+
 def pmc_traffic(kernel_label):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE
     in separate runs, gfx950 correction applied: tools/pmc_summary.py -> profiles/r01_pmc_hbm.json).  A profiler cannot
@@ -537,6 +581,10 @@ def main():
                    kernels={k: dict(us=v["seconds"] * 1e6, GBps=v["bytes"] / v["seconds"] / 1e9,
                                     TFLOPs=v["flops"] / v["seconds"] / 1e12) for k, v in kr.items()},
                    final_losses=loss_now)
+        try:
+            out["erank"] = erank_field(eng)
+        except Exception as e:                                # noqa: BLE001  (the headline number must still print)
+            out["erank"] = dict(error=f"{type(e).__name__}: {e}")
         if a.variant != "tokenfusion":
             out["config"]["workload"] += f" [{a.variant} fuser variant: profiling only, not the headline model]"
         if world == 1 and not a.no_cpu_baseline and a.config == "cfg2" and a.variant == "tokenfusion":

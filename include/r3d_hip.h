@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define R3D_ABI_VERSION 1
+#define R3D_ABI_VERSION 2
 
 /* ---- error codes ---------------------------------------------------------------------------------------- */
 #define R3D_OK 0
@@ -351,8 +351,10 @@ int64_t r3d_erank_lds_bytes(int R, int C);
 int r3d_erank_jacobi(const float* x, int ld, int64_t batch_stride, int batch, int R, int C, int gram, float* sigma,
                      float* af_t, float* stats, int max_sweeps, void* stream);
 /* Any size: two-level (block) one-sided Jacobi with the columns in HBM; one matrix X[R, C].  r3d_erank_blocked_sizes
- * fills out[0] = floats of af_t ([Cpad][R], the rotated columns (X V)^T, zero rows past C), out[1] = ints of ctrl
- * (scratch).  sigma [C] unsorted, stats [4] = {erank, entropy, sum sigma, sweeps}.  Enqueues its launches, no sync. */
+ * fills out[0] = floats of af_t ([Cpad][Rp], the rotated columns (X V)^T; Rp = R rounded up to 4 is the row stride,
+ * rows past C and the row tails R..Rp-1 are zero), out[1] = ints of ctrl (scratch), out[2] = Rp, out[3] = columns per
+ * block.  af_t must be 16-byte aligned.  sigma [C] unsorted, stats [4] = {erank, entropy, sum sigma, sweeps}.
+ * max_sweeps <= 0 selects 20.  Enqueues its launches, no sync. */
 int r3d_erank_blocked_sizes(int R, int C, int max_sweeps, int64_t* out);
 int r3d_erank_blocked(const float* x, int ld, int R, int C, float* sigma, float* af_t, int* ctrl, float* stats,
                       int max_sweeps, void* stream);
@@ -361,6 +363,11 @@ int r3d_erank_blocked(const float* x, int ld, int R, int C, float* sigma, float*
 int r3d_erank_bwd_coef(const float* sigma, const float* stats, const float* gout, float* coef, int C, int max_rank,
                        void* stream);
 int r3d_scale_rows(float* x, int ld, int rows, int cols, const float* coef, void* stream);
+/* Warm start of the next decomposition of a nearby matrix: after a sweep X V = Af, so t1 = Af^T X = Sigma^2 V^T and
+ * vt [C][C] <- diag(1 / sigma^2) t1 (the identity when min sigma <= rel_thresh * max sigma); r3d_erank_vt_polish is one
+ * Newton-Schulz step vt <- 1.5 vt_raw - 0.5 gv with gv = (vt_raw vt_raw^T) vt_raw.  The caller then decomposes X vt^T. */
+int r3d_erank_vt_update(const float* t1, int ld, const float* sigma, float* vt, int C, float rel_thresh, void* stream);
+int r3d_erank_vt_polish(const float* vt_raw, const float* gv, float* vt, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }

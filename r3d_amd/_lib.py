@@ -5,7 +5,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "_build", "libr3d_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_float_p = C.c_void_p      # raw device addresses travel as integers (tensor.data_ptr())
 
@@ -143,6 +143,8 @@ _SIGNATURES = {
     "r3d_erank_blocked": ([_P, _I, _I, _I, _P, _P, _P, _P, _I, _P], C.c_int),
     "r3d_erank_bwd_coef": ([_P, _P, _P, _P, _I, _I, _P], C.c_int),
     "r3d_scale_rows": ([_P, _I, _I, _I, _P, _P], C.c_int),
+    "r3d_erank_vt_update": ([_P, _I, _P, _P, _I, _F, _P], C.c_int),
+    "r3d_erank_vt_polish": ([_P, _P, _P, _L, _P], C.c_int),
 }
 
 EXPORTS = tuple(_SIGNATURES)

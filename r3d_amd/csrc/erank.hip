@@ -5,20 +5,118 @@
 // p = sigma / sum(sigma), erank = exp(-sum p log p).  The checker is torch.linalg.svdvals on the oracle's fused
 // features (oracle/futr_oracle.py: effective_rank).
 //
-// Kernel: one workgroup (16 waves) per matrix.  The C column vectors (length R) are held TRANSPOSED in LDS
-// ([C][R|1] floats, odd row stride -> conflict-free transposing fill, coalesced HBM column sweeps on load/store);
-// each round of a round-robin tournament gives every wave disjoint column pairs: three wave-reduced dot products
-// (alpha, beta, gamma), one Givens rotation applied in LDS.  Sweeps repeat until no pair exceeds
-// |gamma| > tol * sqrt(alpha * beta), tol = sqrt(R) * eps_f32 (the sgesvj criterion), or 30 sweeps.
+// LDS-resident kernel: one workgroup (16 waves) per matrix.  The C column vectors (length R, zero-padded to a multiple
+// of 4) are held TRANSPOSED in LDS ([C][Rp] floats: coalesced HBM column sweeps on load/store, 16-byte LDS accesses in
+// the sweep).  A round of the round-robin tournament pairs all columns disjointly; a pair is rotated by a GROUP of G
+// lanes (G = 16: one DPP row, four pairs per wave, 64 pairs per pass -- a whole round of a 128-column matrix at once;
+// G = 64 when there are fewer pairs than that).  Each lane keeps its rows of both columns in registers between the dot
+// product and the rotation; the squared column norms are cached in LDS and updated by the rotation
+// (alpha' = alpha - t gamma, beta' = beta + t gamma; recomputed exactly at the start of every sweep), so a pair costs ONE
+// reduction (gamma), done with v_add_f32_dpp row_ror butterflies -- no LDS crossbar traffic.  Sweeps repeat until no
+// pair exceeds |gamma| > tol * sqrt(alpha * beta), tol = sqrt(R) * eps_f32 (the sgesvj criterion), or max_sweeps.
 // Outputs: singular values (unsorted), entropy, erank, sweep count and optionally the rotated columns
 // Af^T = (X V)^T [C][R], from which the backward  dX = Af diag(g / sigma^3) (Af^T X)  is two MFMA GEMMs
 // (U diag(g) V^T with V^T = Sigma^-2 Af^T X; no accumulation of V in the sweep).
+// Warm start: `v0` (optional, [C][C]) is an orthogonal matrix from an earlier decomposition of a nearby matrix; the
+// caller passes X V0 as x (one MFMA GEMM), whose columns are already almost orthogonal -- 3-5 sweeps instead of 10-11.
 #include "common.h"
 #include "../../include/r3d_hip.h"
 
 namespace r3d {
 
-constexpr int kJacWaves = 16;
+constexpr int kJacThreads = 1024;
+
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+// every lane of a 16-lane DPP row receives the row's sum (row_ror:8,4,2,1 butterfly -> 4 v_add_f32_dpp)
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_f<0x128>(v);
+    v += dpp_f<0x124>(v);
+    v += dpp_f<0x122>(v);
+    v += dpp_f<0x121>(v);
+    return v;
+}
+template <int G> __device__ __forceinline__ float group_sum(float v) {
+    v = row16_sum(v);
+    if (G == 64) {
+        const int x = __builtin_bit_cast(int, v);
+        v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 16)) +
+            __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 48));
+    }
+    return v;
+}
+__device__ __forceinline__ float dot4(const float4 u, const float4 v) { return u.x * v.x + u.y * v.y + u.z * v.z + u.w * v.w; }
+
+// pair k of round t of a round-robin tournament among n players (n even): player n-1 stays, the others rotate
+__device__ __forceinline__ void rr_pair(int n, int t, int k, int& i, int& j) {
+    if (k == 0) { i = n - 1; j = t; }
+    else {
+        i = t + k; if (i >= n - 1) i -= n - 1;
+        j = t - k + (n - 1); if (j >= n - 1) j -= n - 1;
+    }
+    if (i > j) { const int s = i; i = j; j = s; }
+}
+
+template <int G> __device__ __forceinline__ float col_norm2(const float4* col, int Rp4, int lg) {
+    float s = 0.f;
+    for (int ch = lg; ch < Rp4; ch += G) { const float4 u = col[ch]; s += dot4(u, u); }
+    return group_sum<G>(s);
+}
+
+// One Hestenes rotation of columns (i, j) by a group of G lanes (lane lg of the group).  NCH > 0: every lane holds its
+// NCH 16-byte chunks of both columns in registers (needs NCH * G >= Rp4; EXACT: NCH * G == Rp4, no bounds checks, all
+// LDS reads issued before the first use); NCH == 0: any length, two passes over LDS.  Returns true when the pair was rotated.
+template <int G, int NCH, bool EXACT>
+__device__ __forceinline__ bool jac_pair(float4* A4, float* nrm, int Rp4, int i, int j, int lg, float tol2, float negl) {
+    float4* ai = A4 + (size_t)i * Rp4;
+    float4* aj = A4 + (size_t)j * Rp4;
+    float4 u[NCH > 0 ? NCH : 1], v[NCH > 0 ? NCH : 1];
+    float ga = 0.f;
+    if (NCH > 0) {
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) {
+            const int ch = lg + G * q;
+            if (EXACT || ch < Rp4) { u[q] = ai[ch]; v[q] = aj[ch]; }
+            else { u[q] = make_float4(0.f, 0.f, 0.f, 0.f); v[q] = u[q]; }
+        }
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) ga += dot4(u[q], v[q]);
+    } else {
+        for (int ch = lg; ch < Rp4; ch += G) ga += dot4(ai[ch], aj[ch]);
+    }
+    ga = group_sum<G>(ga);
+    const float al = nrm[i], be = nrm[j];
+    // |gamma| > tol sqrt(alpha beta), squared (no v_sqrt on the critical path)
+    const bool rot = ga * ga > tol2 * al * be && al > negl && be > negl;
+    if (rot) {                                  // the same decision in every lane of the group
+        // t = tan(theta) = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)), zeta = (beta - alpha) / (2 gamma), written with
+        // tau = beta - alpha, d = 2 gamma as  sign(tau) d / (|tau| + sqrt(tau^2 + d^2)):  one v_sqrt + one v_rcp
+        const float tau = be - al, d = 2.f * ga;
+        float t = d * __builtin_amdgcn_rcpf(fabsf(tau) + __builtin_amdgcn_sqrtf(tau * tau + d * d));
+        t = tau >= 0.f ? t : -t;
+        const float c = __builtin_amdgcn_rsqf(1.f + t * t), s = c * t;
+        if (NCH > 0) {
+#pragma unroll
+            for (int q = 0; q < NCH; ++q) {
+                const int ch = lg + G * q;
+                if (EXACT || ch < Rp4) {
+                    const float4 a = u[q], b = v[q];
+                    ai[ch] = make_float4(c * a.x - s * b.x, c * a.y - s * b.y, c * a.z - s * b.z, c * a.w - s * b.w);
+                    aj[ch] = make_float4(s * a.x + c * b.x, s * a.y + c * b.y, s * a.z + c * b.z, s * a.w + c * b.w);
+                }
+            }
+        } else {
+            for (int ch = lg; ch < Rp4; ch += G) {
+                const float4 a = ai[ch], b = aj[ch];
+                ai[ch] = make_float4(c * a.x - s * b.x, c * a.y - s * b.y, c * a.z - s * b.z, c * a.w - s * b.w);
+                aj[ch] = make_float4(s * a.x + c * b.x, s * a.y + c * b.y, s * a.z + c * b.z, s * a.w + c * b.w);
+            }
+        }
+        if (lg == 0) { nrm[i] = fmaxf(al - t * ga, 0.f); nrm[j] = be + t * ga; }
+    }
+    return rot;
+}
 
 struct ErankArgs {
     const float* x; int ld; long long batch_stride;      // [batch][R][ld]
@@ -30,100 +128,19 @@ struct ErankArgs {
     int max_sweeps;
 };
 
-__global__ __launch_bounds__(64 * kJacWaves) void erank_jacobi_kernel(const ErankArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float A[];     // [Cp][Rp]
-    __shared__ int rotated;
-    __shared__ float wred[kJacWaves];
-    const int R = a.R, C = a.C;
-    const int Rp = R | 1;
-    const int Cp = (C + 1) & ~1;                                   // even number of players (last may be a dummy)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* X = a.x + (size_t)blockIdx.x * a.batch_stride;
-
-    for (int e = tid; e < R * C; e += 64 * kJacWaves) {
-        const int r = e / C, c = e % C;
-        A[c * Rp + r] = X[(size_t)r * a.ld + c];
-    }
-    if (Cp != C)
-        for (int r = tid; r < R; r += 64 * kJacWaves) A[C * Rp + r] = 0.f;
-    __syncthreads();
-
-    // ||X||_F^2: columns whose squared norm falls below (1e-6 ||X||_F)^2 are numerically zero (rank-deficient
-    // input, e.g. R < C) and are not rotated against each other -- their mutual "angles" are rounding noise.
-    float fpart = 0.f;
-    for (int c = wave; c < C; c += kJacWaves)
-        for (int r = lane; r < R; r += 64) { const float u = A[c * Rp + r]; fpart += u * u; }
-    fpart = wave_sum(fpart);
-    if (lane == 0) wred[wave] = fpart;
-    __syncthreads();
-    float fro2 = 0.f;
-    for (int w = 0; w < kJacWaves; ++w) fro2 += wred[w];
-    __syncthreads();
-    const float negl = fro2 * 1e-12f;
-    const float tol = sqrtf((float)R) * 1.1920929e-7f;
-    const int npairs = Cp / 2, nrounds = Cp - 1;
-    int sweeps = 0;
-    for (; sweeps < a.max_sweeps; ++sweeps) {
-        if (tid == 0) rotated = 0;
-        __syncthreads();
-        int my_rot = 0;
-        for (int rd = 0; rd < nrounds; ++rd) {
-            for (int k = wave; k < npairs; k += kJacWaves) {
-                int i, j;
-                if (k == 0) { i = Cp - 1; j = rd; }
-                else { i = (rd + k) % (Cp - 1); j = (rd - k + (Cp - 1)) % (Cp - 1); }
-                if (i > j) { const int t = i; i = j; j = t; }
-                float* ai = A + i * Rp;
-                float* aj = A + j * Rp;
-                float al = 0.f, be = 0.f, ga = 0.f;
-                for (int r = lane; r < R; r += 64) {
-                    const float u = ai[r], v = aj[r];
-                    al += u * u; be += v * v; ga += u * v;
-                }
-                al = wave_sum(al); be = wave_sum(be); ga = wave_sum(ga);
-                if (fabsf(ga) > tol * sqrtf(al * be) && al > negl && be > negl) {
-                    const float zeta = (be - al) / (2.f * ga);
-                    const float t = (zeta >= 0.f ? 1.f : -1.f) / (fabsf(zeta) + sqrtf(1.f + zeta * zeta));
-                    const float c = 1.f / sqrtf(1.f + t * t), s = c * t;
-                    for (int r = lane; r < R; r += 64) {
-                        const float u = ai[r], v = aj[r];
-                        ai[r] = c * u - s * v;
-                        aj[r] = s * u + c * v;
-                    }
-                    my_rot = 1;
-                }
-            }
-            __syncthreads();
-        }
-        if (my_rot && lane == 0) rotated = 1;
-        __syncthreads();
-        const int any = rotated;
-        __syncthreads();
-        if (!any) { ++sweeps; break; }
-    }
-
-    // singular values, entropy, erank
-    float* sig = a.sigma + (size_t)blockIdx.x * C;
-    for (int c = wave; c < C; c += kJacWaves) {
-        float s2 = 0.f;
-        for (int r = lane; r < R; r += 64) { const float u = A[c * Rp + r]; s2 += u * u; }
-        s2 = wave_sum(s2);
-        float s = sqrtf(s2);
-        if (a.sqrt_out) s = sqrtf(s);
-        if (lane == 0) sig[c] = s;
-    }
-    __syncthreads();                         // sig[] written by this workgroup: visible after the barrier (same CU)
-    __threadfence_block();
+// sigma -> {erank, entropy, sum sigma}; sig: C floats in LDS; wred: 16 floats of LDS scratch; all threads of the block
+__device__ __forceinline__ void erank_stats_block(const float* sig, int C, float* wred, float* st, float sweeps) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     float part = 0.f;
-    for (int c = tid; c < C; c += 64 * kJacWaves) part += sig[c];
+    for (int c = tid; c < C; c += blockDim.x) part += sig[c];
     part = wave_sum(part);
     if (lane == 0) wred[wave] = part;
     __syncthreads();
     float total = 0.f;
-    for (int w = 0; w < kJacWaves; ++w) total += wred[w];
+    for (int w = 0; w < nw; ++w) total += wred[w];
     __syncthreads();
     float ent = 0.f;
-    for (int c = tid; c < C; c += 64 * kJacWaves) {
+    for (int c = tid; c < C; c += blockDim.x) {
         const float p = sig[c] / total;
         if (p > 0.f) ent -= p * logf(p);
     }
@@ -132,30 +149,105 @@ __global__ __launch_bounds__(64 * kJacWaves) void erank_jacobi_kernel(const Eran
     __syncthreads();
     if (tid == 0) {
         float H = 0.f;
-        for (int w = 0; w < kJacWaves; ++w) H += wred[w];
-        float* st = a.stats + (size_t)blockIdx.x * 4;
-        st[0] = expf(H); st[1] = H; st[2] = total; st[3] = (float)sweeps;
+        for (int w = 0; w < nw; ++w) H += wred[w];
+        st[0] = expf(H); st[1] = H; st[2] = total; st[3] = sweeps;
     }
+}
+
+template <int G, int NCH, bool EXACT>
+__global__ __launch_bounds__(kJacThreads) void erank_jacobi_kernel(const ErankArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // A [Cp][Rp], nrm [Cp]
+    __shared__ int rotated;
+    __shared__ float wred[kJacThreads / 64];
+    const int R = a.R, C = a.C;
+    const int Rp = (R + 3) & ~3, Rp4 = Rp >> 2;
+    const int Cp = (C + 1) & ~1;                                   // even number of players (last may be a dummy)
+    float* A = smem;
+    float4* A4 = reinterpret_cast<float4*>(smem);
+    float* nrm = smem + (size_t)Cp * Rp;
+    const int tid = threadIdx.x;
+    const int slot = tid / G, lg = tid % G, nslots = kJacThreads / G;
+    const float* X = a.x + (size_t)blockIdx.x * a.batch_stride;
+
+    // transposing fill: consecutive lanes take consecutive rows of one column (conflict-free LDS stores; the strided
+    // HBM reads of the [R, C] matrix hit each 64-byte sector once, the rest comes from L2)
+    for (int e = tid; e < Cp * Rp; e += kJacThreads) {
+        const int c = e / Rp, r = e - c * Rp;
+        A[e] = (c < C && r < R) ? X[(size_t)r * a.ld + c] : 0.f;
+    }
+    __syncthreads();
+
+    const float tol2 = (float)R * (1.1920929e-7f * 1.1920929e-7f);      // tol = sqrt(R) eps, squared
+    const int npairs = Cp / 2, nrounds = Cp - 1;
+    float negl = 0.f;
+    int sweeps = 0;
+    for (; sweeps < a.max_sweeps; ++sweeps) {
+        // exact squared norms (the cached ones drift by rounding over a sweep of updates)
+        for (int c = slot; c < Cp; c += nslots) {
+            const float s2 = col_norm2<G>(A4 + (size_t)c * Rp4, Rp4, lg);
+            if (lg == 0) nrm[c] = s2;
+        }
+        if (tid == 0) rotated = 0;
+        __syncthreads();
+        if (sweeps == 0) {
+            // ||X||_F^2: columns whose squared norm falls below (1e-6 ||X||_F)^2 are numerically zero (rank-deficient
+            // input, e.g. R < C) and are not rotated against each other -- their mutual "angles" are rounding noise.
+            float f = 0.f;
+            for (int c = 0; c < C; ++c) f += nrm[c];
+            negl = f * 1e-12f;
+        }
+        bool my_rot = false;
+        for (int rd = 0; rd < nrounds; ++rd) {
+            for (int k = slot; k < npairs; k += nslots) {
+                int i, j;
+                rr_pair(Cp, rd, k, i, j);
+                my_rot |= jac_pair<G, NCH, EXACT>(A4, nrm, Rp4, i, j, lg, tol2, negl);
+            }
+            __syncthreads();
+        }
+        if (my_rot) rotated = 1;
+        __syncthreads();
+        const int any = rotated;
+        __syncthreads();
+        if (!any) { ++sweeps; break; }
+    }
+
+    // singular values (from the columns themselves, not the cached norms), entropy, erank
+    float* sig = a.sigma + (size_t)blockIdx.x * C;
+    for (int c = slot; c < C; c += nslots) {
+        const float s2 = col_norm2<G>(A4 + (size_t)c * Rp4, Rp4, lg);
+        float s = s2 > negl ? sqrtf(s2) : 0.f;       // numerically zero columns (rank-deficient input) report sigma = 0
+        if (a.sqrt_out) s = sqrtf(s);
+        if (lg == 0) { nrm[c] = s; sig[c] = s; }
+    }
+    __syncthreads();
+    erank_stats_block(nrm, C, wred, a.stats + (size_t)blockIdx.x * 4, (float)sweeps);
     if (a.af_t) {
         float* out = a.af_t + (size_t)blockIdx.x * C * R;
-        for (int e = tid; e < R * C; e += 64 * kJacWaves) {
-            const int c = e / R, r = e % R;
-            out[e] = A[c * Rp + r];
+        if ((R & 3) == 0) {
+            float4* o4 = reinterpret_cast<float4*>(out);
+            for (int e = tid; e < C * Rp4; e += kJacThreads) o4[e] = A4[e];
+        } else {
+            for (int e = tid; e < R * C; e += kJacThreads) {
+                const int c = e / R, r = e - c * R;
+                out[e] = A[c * Rp + r];
+            }
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // Matrices that do not fit one CU's LDS: two-level (block) one-sided Jacobi.  The columns live transposed in HBM
-// (At [Cpad][R], a few MB: L2 / Infinity-Cache resident), grouped in nblk blocks of b columns.  One sweep =
+// (At [Cpad][Rp], a few MB: L2 / Infinity-Cache resident), grouped in nblk blocks of b columns.  One sweep =
 //   1 launch  "within": workgroup p orthogonalises the b columns of block p against each other,
-//   nblk-1 launches "cross": round-robin over block pairs (p,q); a workgroup holds both blocks in LDS (2b columns)
-//                    and rotates every (i in p, j in q) pair: b inner rounds of b disjoint pairs, one wave per pair.
+//   nblk-1 launches "cross": round-robin over block pairs (p,q); a workgroup holds both blocks in LDS (2b columns,
+//                    16-byte coalesced column sweeps from / to HBM) and rotates every (i in p, j in q) pair: b inner
+//                    rounds of b disjoint pairs, one wave (G = 64) per pair, same rotation code as above.
 // so every column pair is visited exactly once per sweep (a cyclic ordering -> the usual quadratic convergence).
 // The launches of all sweeps are enqueued up front; a device-side flag turns the remainder into no-ops once a sweep
 // made no rotation.  ctrl (ints): [0] done, [1] sweeps run, [2] float bits of ||X||_F^2, [4+s] rotations in sweep s.
 struct ErankBlk {
-    float* at; int R, C, b, nblk;      // nblk even (the last block may be a dummy one: index >= nreal)
+    float* at; int R, Rp, C, b, nblk;  // nblk even (the last block may be a dummy one: index >= nreal)
     int nreal;
     int* ctrl;
 };
@@ -175,7 +267,7 @@ __global__ __launch_bounds__(256) void erank_blk_init_kernel(const float* __rest
     __syncthreads();
     for (int k = ty; k < 32; k += 8) {
         const int c = c0 + k, r = r0 + tx;
-        if (c < g.nreal * g.b && r < g.R) g.at[(size_t)c * g.R + r] = tile[tx][k];
+        if (c < g.nreal * g.b && r < g.Rp) g.at[(size_t)c * g.Rp + r] = tile[tx][k];      // rows R..Rp-1: zeros
     }
     part = wave_sum(part);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
@@ -184,67 +276,50 @@ __global__ __launch_bounds__(256) void erank_blk_init_kernel(const float* __rest
 }
 
 // mode 0: within-block (grid = nreal), mode 1: cross, round rd of the block tournament (grid = nblk / 2)
-__global__ __launch_bounds__(64 * kJacWaves) void erank_blk_round_kernel(ErankBlk g, int mode, int rd, int sweep) {
-    extern __shared__ __attribute__((aligned(16))) float A[];     // [2b][Rp]
+template <int NCH, bool EXACT>
+__global__ __launch_bounds__(kJacThreads) void erank_blk_round_kernel(ErankBlk g, int mode, int rd, int sweep) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];     // A [2b][Rp], nrm [2b]
     if (g.ctrl[0]) return;
-    const int R = g.R, b = g.b, Rp = R | 1;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int G = 64;
+    const int b = g.b, Rp = g.Rp, Rp4 = Rp >> 2;
+    const int tid = threadIdx.x, slot = tid / G, lg = tid % G, nslots = blockDim.x / G;
     int p, q;
     if (mode == 0) { p = blockIdx.x; q = -1; }
     else {
-        const int k = blockIdx.x, n1 = g.nblk - 1;
-        if (k == 0) { p = n1; q = rd; }
-        else { p = (rd + k) % n1; q = (rd - k + n1) % n1; }
-        if (p > q) { const int t = p; p = q; q = t; }
+        rr_pair(g.nblk, rd, blockIdx.x, p, q);
         if (q >= g.nreal) return;                                  // paired with the dummy block
     }
     const int ncol = (mode == 0) ? b : 2 * b;
-    for (int e = tid; e < ncol * R; e += 64 * kJacWaves) {
-        const int c = e / R, r = e - c * R;
-        const int blk = c < b ? p : q;
-        A[c * Rp + r] = g.at[((size_t)blk * b + (c % b)) * R + r];
+    float4* A4 = reinterpret_cast<float4*>(smem);
+    float* nrm = smem + (size_t)ncol * Rp;
+    const float4* P4 = reinterpret_cast<const float4*>(g.at + (size_t)p * b * Rp);
+    const float4* Q4 = reinterpret_cast<const float4*>(g.at + (size_t)(q < 0 ? p : q) * b * Rp);
+    const int half = b * Rp4;
+    for (int e = tid; e < ncol * Rp4; e += blockDim.x) A4[e] = e < half ? P4[e] : Q4[e - half];
+    __syncthreads();
+    for (int c = slot; c < ncol; c += nslots) {
+        const float s2 = col_norm2<G>(A4 + (size_t)c * Rp4, Rp4, lg);
+        if (lg == 0) nrm[c] = s2;
     }
     __syncthreads();
     const float negl = __int_as_float(g.ctrl[2]) * 1e-12f;
-    const float tol = sqrtf((float)R) * 1.1920929e-7f;
-    int my_rot = 0;
+    const float tol2 = (float)g.R * (1.1920929e-7f * 1.1920929e-7f);
+    bool my_rot = false;
     const int npairs = (mode == 0) ? b / 2 : b;
     const int nrounds = (mode == 0) ? b - 1 : b;
     for (int t = 0; t < nrounds; ++t) {
-        for (int k = wave; k < npairs; k += kJacWaves) {
+        for (int k = slot; k < npairs; k += nslots) {
             int i, j;
-            if (mode == 0) {
-                if (k == 0) { i = b - 1; j = t; }
-                else { i = (t + k) % (b - 1); j = (t - k + (b - 1)) % (b - 1); }
-            } else { i = k; j = b + (k + t) % b; }
-            float* ai = A + i * Rp;
-            float* aj = A + j * Rp;
-            float al = 0.f, be = 0.f, ga = 0.f;
-            for (int r = lane; r < R; r += 64) {
-                const float u = ai[r], v = aj[r];
-                al += u * u; be += v * v; ga += u * v;
-            }
-            al = wave_sum(al); be = wave_sum(be); ga = wave_sum(ga);
-            if (fabsf(ga) > tol * sqrtf(al * be) && al > negl && be > negl) {
-                const float zeta = (be - al) / (2.f * ga);
-                const float tt = (zeta >= 0.f ? 1.f : -1.f) / (fabsf(zeta) + sqrtf(1.f + zeta * zeta));
-                const float c = 1.f / sqrtf(1.f + tt * tt), s = c * tt;
-                for (int r = lane; r < R; r += 64) {
-                    const float u = ai[r], v = aj[r];
-                    ai[r] = c * u - s * v;
-                    aj[r] = s * u + c * v;
-                }
-                my_rot = 1;
-            }
+            if (mode == 0) rr_pair(b, t, k, i, j);
+            else { i = k; j = k + t; if (j >= b) j -= b; j += b; }
+            my_rot |= jac_pair<G, NCH, EXACT>(A4, nrm, Rp4, i, j, lg, tol2, negl);
         }
         __syncthreads();
     }
-    for (int e = tid; e < ncol * R; e += 64 * kJacWaves) {
-        const int c = e / R, r = e - c * R;
-        const int blk = c < b ? p : q;
-        g.at[((size_t)blk * b + (c % b)) * R + r] = A[c * Rp + r];
-    }
-    if (my_rot && lane == 0) atomicAdd(g.ctrl + 4 + sweep, 1);
+    float4* Pw = reinterpret_cast<float4*>(g.at + (size_t)p * b * Rp);
+    float4* Qw = reinterpret_cast<float4*>(g.at + (size_t)(q < 0 ? p : q) * b * Rp);
+    for (int e = tid; e < ncol * Rp4; e += blockDim.x) { if (e < half) Pw[e] = A4[e]; else Qw[e - half] = A4[e]; }
+    if (my_rot && lg == 0) atomicAdd(g.ctrl + 4 + sweep, 1);
 }
 
 __global__ void erank_blk_sweep_end_kernel(ErankBlk g, int sweep) {
@@ -253,39 +328,19 @@ __global__ void erank_blk_sweep_end_kernel(ErankBlk g, int sweep) {
     if (g.ctrl[4 + sweep] == 0) g.ctrl[0] = 1;
 }
 
-__global__ __launch_bounds__(64 * kJacWaves) void erank_blk_finish_kernel(ErankBlk g, float* sig, float* stats) {
-    __shared__ float wred[kJacWaves];
-    const int R = g.R, C = g.C;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int c = wave; c < C; c += kJacWaves) {
-        float s2 = 0.f;
-        for (int r = lane; r < R; r += 64) { const float u = g.at[(size_t)c * R + r]; s2 += u * u; }
-        s2 = wave_sum(s2);
-        if (lane == 0) sig[c] = sqrtf(s2);
-    }
-    __syncthreads();
-    __threadfence_block();
-    float part = 0.f;
-    for (int c = tid; c < C; c += 64 * kJacWaves) part += sig[c];
-    part = wave_sum(part);
-    if (lane == 0) wred[wave] = part;
-    __syncthreads();
-    float total = 0.f;
-    for (int w = 0; w < kJacWaves; ++w) total += wred[w];
-    __syncthreads();
-    float ent = 0.f;
-    for (int c = tid; c < C; c += 64 * kJacWaves) {
-        const float p = sig[c] / total;
-        if (p > 0.f) ent -= p * logf(p);
-    }
-    ent = wave_sum(ent);
-    if (lane == 0) wred[wave] = ent;
-    __syncthreads();
-    if (tid == 0) {
-        float H = 0.f;
-        for (int w = 0; w < kJacWaves; ++w) H += wred[w];
-        stats[0] = expf(H); stats[1] = H; stats[2] = total; stats[3] = (float)g.ctrl[1];
-    }
+// sigma[c] = ||column c||: one wave per column, 16 columns per workgroup
+__global__ __launch_bounds__(kJacThreads) void erank_blk_sigma_kernel(ErankBlk g, float* sig) {
+    constexpr int G = 64;
+    const int tid = threadIdx.x, slot = tid / G, lg = tid % G;
+    const int c = blockIdx.x * (kJacThreads / G) + slot;
+    if (c >= g.C) return;
+    const float s2 = col_norm2<G>(reinterpret_cast<const float4*>(g.at + (size_t)c * g.Rp), g.Rp >> 2, lg);
+    if (lg == 0) sig[c] = s2 > __int_as_float(g.ctrl[2]) * 1e-12f ? sqrtf(s2) : 0.f;   // (numerically zero columns: 0)
+}
+
+__global__ __launch_bounds__(kJacThreads) void erank_blk_stats_kernel(ErankBlk g, const float* sig, float* stats) {
+    __shared__ float wred[kJacThreads / 64];
+    erank_stats_block(sig, g.C, wred, stats, (float)g.ctrl[1]);
 }
 
 // coef[k] = gout * d erank / d sigma_k / sigma_k^3, zero where sigma_k is negligible (rank-deficient directions
@@ -319,11 +374,58 @@ __global__ __launch_bounds__(256) void scale_rows_kernel(float* x, int ld, int r
     }
 }
 
+// Warm start for the next decomposition of a nearby matrix (the next training step's fused tokens).  After a sweep
+// X V = Af, so t1 = Af^T X = Sigma^2 V^T: row k of V^T is t1[k, :] / sigma_k^2.  When the smallest singular value is
+// below rel_thresh * the largest the direction carries no usable row (error ~ eps sigma_max / sigma_k): V^T is reset
+// to the identity (a cold start).  One workgroup per row.
+__global__ __launch_bounds__(256) void erank_vt_update_kernel(const float* __restrict__ t1, int ld, const float* __restrict__ sigma,
+                                                              float* __restrict__ vt, int C, float rel_thresh) {
+    __shared__ float red[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float mx = 0.f, mn = 3.4e38f;
+    for (int c = tid; c < C; c += 256) { const float s = sigma[c]; mx = fmaxf(mx, s); mn = fminf(mn, s); }
+    mx = wave_max(mx); mn = -wave_max(-mn);
+    if (lane == 0) { red[wave] = mx; red[4 + wave] = mn; }
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    mn = fminf(fminf(red[4], red[5]), fminf(red[6], red[7]));
+    const int k = blockIdx.x;
+    const bool ok = mn > rel_thresh * mx && mx > 0.f;
+    const float s = sigma[k];
+    const float inv = ok ? 1.f / (s * s) : 0.f;
+    for (int c = tid; c < C; c += 256) vt[(size_t)k * C + c] = ok ? t1[(size_t)k * ld + c] * inv : (c == k ? 1.f : 0.f);
+}
+
+// one Newton-Schulz step towards the nearest orthogonal matrix: V^T <- 1.5 V^T - 0.5 (V^T V) V^T  (gv = (V^T V^T^T) V^T)
+__global__ __launch_bounds__(256) void erank_vt_polish_kernel(const float* __restrict__ vt_raw, const float* __restrict__ gv,
+                                                              float* __restrict__ vt, size_t n) {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256)
+        vt[e] = 1.5f * vt_raw[e] - 0.5f * gv[e];
+}
+
 }  // namespace r3d
 
 using namespace r3d;
 
-R3D_EXPORT int64_t r3d_erank_lds_bytes(int R, int C) { return (int64_t)((C + 1) & ~1) * (R | 1) * 4; }
+static inline int erank_rp(int R) { return (R + 3) & ~3; }
+
+R3D_EXPORT int64_t r3d_erank_lds_bytes(int R, int C) { return ((int64_t)((C + 1) & ~1) * erank_rp(R) + ((C + 1) & ~1)) * 4; }
+
+template <int G, int NCH, bool EXACT>
+static int erank_launch2(const ErankArgs& a, int batch, int64_t lds, hipStream_t st) {
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)erank_jacobi_kernel<G, NCH, EXACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL((erank_jacobi_kernel<G, NCH, EXACT>), dim3(batch), dim3(kJacThreads), (size_t)lds, st, a);
+    R3D_LAUNCH_CHECK();
+    return R3D_OK;
+}
+template <int G, int NCH>
+static int erank_launch(const ErankArgs& a, int batch, int64_t lds, hipStream_t st) {
+    if (NCH > 0 && ((a.R + 3) >> 2) == G * NCH) return erank_launch2<G, NCH, true>(a, batch, lds, st);
+    return erank_launch2<G, NCH, false>(a, batch, lds, st);
+}
 
 /* Batched effective rank.  x: [batch][R][ld] (row-major matrices X[R,C]); sigma [batch][C] (unsorted);
  * af_t (optional) [batch][C][R] rotated columns for the backward; stats [batch][4] = {erank, entropy, sum sigma,
@@ -335,66 +437,102 @@ R3D_EXPORT int r3d_erank_jacobi(const float* x, int ld, int64_t batch_stride, in
     R3D_REQUIRE(!gram || R == C);
     const int64_t lds = r3d_erank_lds_bytes(R, C);
     R3D_REQUIRE(lds <= 160 * 1024 - 256);
+    if (af_t && (R & 3) == 0) R3D_REQUIRE(r3d_aligned16(af_t));
     ErankArgs a{x, ld, (long long)batch_stride, R, C, sigma, af_t, stats, gram, max_sweeps > 0 ? max_sweeps : 30};
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)erank_jacobi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
+    hipStream_t st = (hipStream_t)stream;
+    const int npairs = ((C + 1) & ~1) / 2, rp4 = erank_rp(R) / 4;
+    if (npairs > 16) {                          // 16 lanes per pair: 64 pairs per pass
+        if (rp4 <= 16) return erank_launch<16, 1>(a, batch, lds, st);
+        if (rp4 <= 32) return erank_launch<16, 2>(a, batch, lds, st);
+        if (rp4 <= 64) return erank_launch<16, 4>(a, batch, lds, st);
+        if (rp4 <= 128) return erank_launch<16, 8>(a, batch, lds, st);
+        return erank_launch<16, 0>(a, batch, lds, st);
     }
-    hipLaunchKernelGGL(erank_jacobi_kernel, dim3(batch), dim3(64 * kJacWaves), (size_t)lds, (hipStream_t)stream, a);
-    R3D_LAUNCH_CHECK();
-    return R3D_OK;
+    if (rp4 <= 64) return erank_launch<64, 1>(a, batch, lds, st);
+    if (rp4 <= 128) return erank_launch<64, 2>(a, batch, lds, st);
+    if (rp4 <= 256) return erank_launch<64, 4>(a, batch, lds, st);
+    if (rp4 <= 512) return erank_launch<64, 8>(a, batch, lds, st);
+    return erank_launch<64, 0>(a, batch, lds, st);
 }
-
 
 /* Block size (columns per block) of the two-level Jacobi for column length R: two blocks must fit one CU's LDS. */
 static int erank_blk_b(int R) {
     int b = 16;
-    while (b > 2 && (int64_t)2 * b * (R | 1) * 4 > 150 * 1024) b >>= 1;
+    while (b > 2 && ((int64_t)2 * b * erank_rp(R) + 2 * b) * 4 > 150 * 1024) b >>= 1;
     return b;
 }
 
-/* Sizes for r3d_erank_blocked: out[0] = floats of af_t ([Cpad][R], Cpad = C rounded up to the block size),
- * out[1] = ints of ctrl.  Returns R3D_EINVAL when even two 2-column blocks exceed the LDS (R > ~9500). */
+/* Sizes for r3d_erank_blocked: out[0] = floats of af_t ([Cpad][Rp], Cpad = C rounded up to the block size, Rp = R
+ * rounded up to 4), out[1] = ints of ctrl, out[2] = Rp (row stride of af_t), out[3] = block size b.
+ * Returns R3D_EINVAL when even two 2-column blocks exceed the LDS (R > ~9500). */
 R3D_EXPORT int r3d_erank_blocked_sizes(int R, int C, int max_sweeps, int64_t* out) {
     R3D_REQUIRE(out && R > 0 && C > 0);
     const int b = erank_blk_b(R);
-    R3D_REQUIRE((int64_t)2 * b * (R | 1) * 4 <= 150 * 1024);
+    R3D_REQUIRE(((int64_t)2 * b * erank_rp(R) + 2 * b) * 4 <= 150 * 1024);
     const int nreal = r3d_cdiv(C, b);
-    out[0] = (int64_t)nreal * b * R;
-    out[1] = 4 + (max_sweeps > 0 ? max_sweeps : 30);
+    out[0] = (int64_t)nreal * b * erank_rp(R);
+    out[1] = 4 + (max_sweeps > 0 ? max_sweeps : 20);
+    out[2] = erank_rp(R);
+    out[3] = b;
     return R3D_OK;
 }
 
+template <int NCH, bool EXACT>
+static int erank_blk_sweeps2(const ErankBlk& g, int ms, int64_t lds, hipStream_t st) {
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)erank_blk_round_kernel<NCH, EXACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    const int b = g.b;
+    const int tw = 64 * (b / 2 < 1 ? 1 : (b / 2 > 16 ? 16 : b / 2)), tc = 64 * (b > 16 ? 16 : b);
+    for (int s = 0; s < ms; ++s) {
+        hipLaunchKernelGGL((erank_blk_round_kernel<NCH, EXACT>), dim3(g.nreal), dim3(tw), (size_t)lds, st, g, 0, 0, s);
+        if (g.nblk > 1)
+            for (int rd = 0; rd < g.nblk - 1; ++rd)
+                hipLaunchKernelGGL((erank_blk_round_kernel<NCH, EXACT>), dim3(g.nblk / 2), dim3(tc), (size_t)lds, st, g, 1, rd, s);
+        hipLaunchKernelGGL(erank_blk_sweep_end_kernel, dim3(1), dim3(1), 0, st, g, s);
+    }
+    R3D_LAUNCH_CHECK();
+    return R3D_OK;
+}
+
+template <int NCH>
+static int erank_blk_sweeps(const ErankBlk& g, int ms, int64_t lds, hipStream_t st) {
+    if (NCH > 0 && (g.Rp >> 2) == 64 * NCH) return erank_blk_sweeps2<NCH, true>(g, ms, lds, st);
+    return erank_blk_sweeps2<NCH, false>(g, ms, lds, st);
+}
+
 /* Effective rank of ONE matrix X[R, C] (row-major, leading dimension ld) of any size: two-level one-sided Jacobi
- * with the columns in HBM (see above).  af_t [Cpad][R] receives the rotated columns (X V)^T (rows >= C are zero
- * padding); ctrl is integer scratch; sizes from r3d_erank_blocked_sizes.  sigma [C], stats [4] as r3d_erank_jacobi.
- * Enqueues 2 + max_sweeps * (nblk + 1) launches on the stream, never synchronises. */
+ * with the columns in HBM (see above).  af_t [Cpad][Rp] receives the rotated columns (X V)^T (rows >= C and the
+ * columns R..Rp-1 of every row are zero padding); ctrl is integer scratch; sizes from r3d_erank_blocked_sizes.
+ * sigma [C], stats [4] as r3d_erank_jacobi.  Enqueues 3 + max_sweeps * (nblk + 1) launches on the stream (default
+ * max_sweeps 20; launches after convergence return at once), never synchronises. */
 R3D_EXPORT int r3d_erank_blocked(const float* x, int ld, int R, int C, float* sigma, float* af_t, int* ctrl, float* stats,
                                  int max_sweeps, void* stream) {
     R3D_REQUIRE(x && sigma && af_t && ctrl && stats && R > 0 && C > 0 && ld >= C);
+    R3D_REQUIRE(r3d_aligned16(af_t));
     const int b = erank_blk_b(R);
-    const int64_t lds = (int64_t)2 * b * (R | 1) * 4;
+    const int Rp = erank_rp(R);
+    const int64_t lds = ((int64_t)2 * b * Rp + 2 * b) * 4;
     R3D_REQUIRE(lds <= 150 * 1024);
-    const int ms = max_sweeps > 0 ? max_sweeps : 30;
+    const int ms = max_sweeps > 0 ? max_sweeps : 20;
     const int nreal = r3d_cdiv(C, b);
     const int nblk = (nreal + 1) & ~1;
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(ctrl, 0, sizeof(int) * (4 + ms), st);
     if (e != hipSuccess) return (int)e;
-    ErankBlk g{af_t, R, C, b, nblk, nreal, ctrl};
-    if (lds > 64 * 1024) {
-        e = hipFuncSetAttribute((const void*)erank_blk_round_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-    }
-    hipLaunchKernelGGL(erank_blk_init_kernel, dim3(r3d_cdiv(nreal * b, 32), r3d_cdiv(R, 32)), dim3(256), 0, st, x, ld, g);
-    for (int s = 0; s < ms; ++s) {
-        hipLaunchKernelGGL(erank_blk_round_kernel, dim3(nreal), dim3(64 * kJacWaves), (size_t)lds / 2 + 16, st, g, 0, 0, s);
-        if (nblk > 1)
-            for (int rd = 0; rd < nblk - 1; ++rd)
-                hipLaunchKernelGGL(erank_blk_round_kernel, dim3(nblk / 2), dim3(64 * kJacWaves), (size_t)lds, st, g, 1, rd, s);
-        hipLaunchKernelGGL(erank_blk_sweep_end_kernel, dim3(1), dim3(1), 0, st, g, s);
-    }
-    hipLaunchKernelGGL(erank_blk_finish_kernel, dim3(1), dim3(64 * kJacWaves), 0, st, g, sigma, stats);
+    ErankBlk g{af_t, R, Rp, C, b, nblk, nreal, ctrl};
+    hipLaunchKernelGGL(erank_blk_init_kernel, dim3(r3d_cdiv(nreal * b, 32), r3d_cdiv(Rp, 32)), dim3(256), 0, st, x, ld, g);
+    const int rp4 = Rp / 4;
+    int rc;
+    if (rp4 <= 64) rc = erank_blk_sweeps<1>(g, ms, lds, st);
+    else if (rp4 <= 128) rc = erank_blk_sweeps<2>(g, ms, lds, st);
+    else if (rp4 <= 256) rc = erank_blk_sweeps<4>(g, ms, lds, st);
+    else if (rp4 <= 512) rc = erank_blk_sweeps<8>(g, ms, lds, st);
+    else rc = erank_blk_sweeps<0>(g, ms, lds, st);
+    if (rc != R3D_OK) return rc;
+    hipLaunchKernelGGL(erank_blk_sigma_kernel, dim3(r3d_cdiv(C, kJacThreads / 64)), dim3(kJacThreads), 0, st, g, sigma);
+    hipLaunchKernelGGL(erank_blk_stats_kernel, dim3(1), dim3(kJacThreads), 0, st, g, (const float*)sigma, stats);
     R3D_LAUNCH_CHECK();
     return R3D_OK;
 }
@@ -415,6 +553,25 @@ R3D_EXPORT int r3d_scale_rows(float* x, int ld, int rows, int cols, const float*
     const size_t total = (size_t)rows * cols;
     const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
     hipLaunchKernelGGL(scale_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ld, rows, cols, coef);
+    R3D_LAUNCH_CHECK();
+    return R3D_OK;
+}
+
+/* Warm start (see erank_vt_update_kernel): vt [C][C] <- diag(1 / sigma^2) t1, or the identity when
+ * min sigma <= rel_thresh * max sigma.  t1 [C][ld] = Af^T X as the backward computes it (before r3d_scale_rows). */
+R3D_EXPORT int r3d_erank_vt_update(const float* t1, int ld, const float* sigma, float* vt, int C, float rel_thresh,
+                                   void* stream) {
+    R3D_REQUIRE(t1 && sigma && vt && C > 0 && ld >= C && rel_thresh >= 0.f);
+    hipLaunchKernelGGL(erank_vt_update_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, t1, ld, sigma, vt, C, rel_thresh);
+    R3D_LAUNCH_CHECK();
+    return R3D_OK;
+}
+
+/* vt <- 1.5 vt_raw - 0.5 gv (n elements): the Newton-Schulz orthogonality polish of the warm-start basis. */
+R3D_EXPORT int r3d_erank_vt_polish(const float* vt_raw, const float* gv, float* vt, int64_t n, void* stream) {
+    R3D_REQUIRE(vt_raw && gv && vt && n > 0);
+    const int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    hipLaunchKernelGGL(erank_vt_polish_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, vt_raw, gv, vt, (size_t)n);
     R3D_LAUNCH_CHECK();
     return R3D_OK;
 }

@@ -207,6 +207,7 @@ class FusionEngine:
         self.dropout_enabled = bool(getattr(module, "r3d_dropout_enabled", True))
         self.erank_weight = 0.0           # > 0: total loss -= erank_weight * effective_rank(fused token matrix) (build-side
                                           # rank-enhancing penalty; the reference only describes it, README.md:8-14)
+        self.erank_warm_start = True      # Jacobi on X V0 (V0 from the previous step), see _erank_forward
         self.shapes = {}
         self.train_mask = None            # cached train-mode selection (data independent)
         self.drop_seed = 0x5EED
@@ -454,6 +455,11 @@ class FusionEngine:
 
     # ---- effective-rank penalty on the fused token matrix [N, H] (erank.hip; Appendix A.11) ------------------------------
     def _erank_forward(self, w):
+        """Jacobi forward on the fused tokens.  Warm start (erank_warm_start): the sweep runs on X V0, V0 the right
+        singular basis the previous step's backward left behind (identity on the first step) -- the tokens move little
+        between optimiser steps, so X V0 has almost orthogonal columns and 3-5 sweeps replace 10-11.  The singular values
+        of X V0 are those of X (V0 orthogonal), and the rotated columns Af = X V0 V' are the same (X V) the backward
+        needs."""
         N, H = w.N, self.H
         if not hasattr(w, "er_sigma"):
             f = lambda *s: torch.empty(*s, dtype=torch.float32, device=self.device)     # noqa: E731
@@ -462,13 +468,26 @@ class FusionEngine:
                                           f"({N}x{H}); use r3d_amd.erank.effective_rank for measurement at this size")
             w.er_sigma, w.er_stats, w.er_af = f(1, H), f(1, 4), f(1, H, N)
             w.er_coef, w.er_t1, w.er_gout = f(H), f(H, H), f(1)
-        ops.erank_jacobi(w.fused, w.er_sigma, w.er_stats, af_t=w.er_af)
+            w.er_vt = torch.eye(H, dtype=torch.float32, device=self.device)      # V0^T
+            w.er_vraw, w.er_vg, w.er_gv, w.er_xw = f(H, H), f(H, H), f(H, H), f(N, H)
+        if self.erank_warm_start:
+            ops.gemm(GEMM_NT, w.fused, w.er_vt, w.er_xw, ws=self.ws)            # X V0
+            ops.erank_jacobi(w.er_xw, w.er_sigma, w.er_stats, af_t=w.er_af)
+        else:
+            ops.erank_jacobi(w.fused, w.er_sigma, w.er_stats, af_t=w.er_af)
 
     def _erank_backward(self, w, ws):
         """d_fused2 += d(-erank_weight * erank)/d(fused) = Af diag(coef) (Af^T X): two GEMMs and a row scale."""
         w.er_gout.fill_(-float(self.erank_weight))
         ops.erank_bwd_coef(w.er_sigma[0], w.er_stats[0], w.er_gout, w.er_coef, max_rank=min(w.N, self.H))
-        ops.gemm(GEMM_NN, w.er_af[0], w.fused, w.er_t1, ws=ws)
+        ops.gemm(GEMM_NN, w.er_af[0], w.fused, w.er_t1, ws=ws)                  # Af^T X = Sigma^2 V^T
+        if self.erank_warm_start:
+            # next step's basis: V^T = Sigma^-2 (Af^T X), then one Newton-Schulz step (rows of small sigma carry an
+            # error ~ eps sigma_max / sigma_k; the polish squares the departure from orthogonality)
+            ops.erank_vt_update(w.er_t1, w.er_sigma[0], w.er_vraw)
+            ops.gemm(GEMM_NT, w.er_vraw, w.er_vraw, w.er_vg, ws=ws)             # V^T V
+            ops.gemm(GEMM_NN, w.er_vg, w.er_vraw, w.er_gv, ws=ws)
+            ops.erank_vt_polish(w.er_vraw, w.er_gv, w.er_vt)
         ops.scale_rows(w.er_t1, w.er_coef)
         ops.gemm(GEMM_TN, w.er_af[0], w.er_t1, w.d_fused2, accumulate=True, ws=ws)
 

@@ -599,21 +599,23 @@ def erank_jacobi(x, sigma, stats, *, af_t=None, gram=False, max_sweeps=30):
                                max_sweeps, _stream()), "r3d_erank_jacobi")
 
 
-def erank_blocked(x, max_sweeps=30):
-    """x: [R, C] (row stride >= C).  Returns (sigma [C], stats [4], af_t [Cpad, R]) -- any size, columns in HBM."""
+def erank_blocked(x, max_sweeps=20):
+    """x: [R, C] (row stride >= C).  Returns (sigma [C], stats [4], af_t [Cpad, R] -- a view of the [Cpad, Rp] buffer the
+    kernel sweeps, Rp = R rounded up to 4) -- any size, columns in HBM."""
     import ctypes
     lib = _lib.load()
     R, Cc = x.shape
     assert x.stride(1) == 1
-    sz = (ctypes.c_int64 * 2)()
+    sz = (ctypes.c_int64 * 4)()
     check(lib.r3d_erank_blocked_sizes(R, Cc, max_sweeps, ctypes.cast(sz, ctypes.c_void_p)), "r3d_erank_blocked_sizes")
-    af_t = torch.empty(sz[0] // R, R, dtype=torch.float32, device=x.device)
+    Rp = int(sz[2])
+    af_t = torch.empty(sz[0] // Rp, Rp, dtype=torch.float32, device=x.device)
     ctrl = torch.empty(sz[1], dtype=torch.int32, device=x.device)
     sigma = torch.empty(Cc, dtype=torch.float32, device=x.device)
     stats = torch.empty(4, dtype=torch.float32, device=x.device)
     check(lib.r3d_erank_blocked(_p(x), x.stride(0), R, Cc, _p(sigma), _p(af_t), _p(ctrl), _p(stats), max_sweeps, _stream()),
           "r3d_erank_blocked")
-    return sigma, stats, af_t
+    return sigma, stats, af_t[:, :R]
 
 
 def erank_bwd_coef(sigma, stats, gout, coef, max_rank=0):
@@ -627,3 +629,17 @@ def scale_rows(x, coef):
     lib = _lib.load()
     rows, cols = x.shape
     check(lib.r3d_scale_rows(_p(x), _ld(x), rows, cols, _p(coef), _stream()), "r3d_scale_rows")
+
+
+def erank_vt_update(t1, sigma, vt, rel_thresh=1e-3):
+    """vt [C, C] <- diag(1 / sigma^2) t1 (warm-start basis V^T), identity when the spectrum is too wide."""
+    lib = _lib.load()
+    Cc = vt.shape[0]
+    assert vt.is_contiguous() and vt.shape == (Cc, Cc) and t1.shape == (Cc, Cc)
+    check(lib.r3d_erank_vt_update(_p(t1), _ld(t1), _p(sigma), _p(vt), Cc, rel_thresh, _stream()), "r3d_erank_vt_update")
+
+
+def erank_vt_polish(vt_raw, gv, vt):
+    lib = _lib.load()
+    assert vt_raw.is_contiguous() and gv.is_contiguous() and vt.is_contiguous()
+    check(lib.r3d_erank_vt_polish(_p(vt_raw), _p(gv), _p(vt), vt.numel(), _stream()), "r3d_erank_vt_polish")

@@ -383,6 +383,45 @@ def test_effective_rank_penalty_gradients(tag, paired, oracle_lib):
             close_rel(eng.arena.g(n), p.grad, f"{tag}/erank-penalised grad {n}", rtol=3e-3)
 
 
+def test_effective_rank_warm_start(oracle_lib):
+    """erank_warm_start: the Jacobi sweep of step t runs on X V0 with V0 from step t-1's backward.  Same singular
+    values / effective rank (against svdvals on the CPU copy of the step's fused tokens), same gradients as the cold
+    start at the same parameters, fewer sweeps once the basis is warm."""
+    lam = 0.05
+    fx = load_fixture("step_cfg2")
+    m = fx["meta"]
+    d = [t.cuda() for t in fixture_batch(fx)]
+    model = build_model(fx).eval()
+    eng = model.engine()
+    eng.erank_weight = lam
+    sweeps = []
+    for it in range(4):
+        eng.forward(d[0], d[1], d[2], "train", training=False)
+        eng.losses(d[2], d[4], d[3], tick=True)
+        eng.backward()
+        torch.cuda.synchronize()
+        w = eng.last["w"]
+        sweeps.append(float(w.er_stats[0, 3]))
+        want = O.effective_rank(w.fused.cpu().reshape(-1, m["H"]))
+        assert abs(float(eng.erank_value()) - want) < 5e-3 * max(1.0, want / 50), (it, float(eng.erank_value()), want)
+        vt = w.er_vt.double().cpu()
+        assert float((vt @ vt.t() - torch.eye(vt.shape[0], dtype=torch.float64)).abs().max()) < 1e-4
+        if it < 3:
+            # a late-training-sized update (at lr 1e-3 this fixture's analytic parameters move the tokens by 20-100 %
+            # per step, which no basis survives; the warm start then simply costs what a cold one does)
+            eng.adamw(2e-6, 5e-3, ticked=True)
+    assert max(sweeps[1:]) < sweeps[0], sweeps
+    warm = {n: eng.arena.g(n).clone() for n in eng.arena.live_names}
+    eng.erank_warm_start = False
+    eng.forward(d[0], d[1], d[2], "train", training=False)
+    eng.losses(d[2], d[4], d[3])
+    eng.backward()
+    torch.cuda.synchronize()
+    assert float(eng.last["w"].er_stats[0, 3]) > max(sweeps[1:])
+    for n, g in warm.items():
+        close_rel(g, eng.arena.g(n).cpu(), f"warm vs cold erank-penalised grad {n}", rtol=3e-3)
+
+
 def test_deferred_tail_one_launch_equals_three(oracle_lib):
     """engine.defer_tail: the decoder tail's forward, the losses and the tail's backward as ONE launch
     (r3d_decoder_tail_losses) give the same outputs, losses, counters and gradients as the three separate launches,

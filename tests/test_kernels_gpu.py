@@ -475,7 +475,7 @@ def test_dropout_mask_statistics(ops):
 # ----------------------------------------------------------------------------------------------------------
 # effective rank
 # ----------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("R,Cc", [(128, 128), (40, 24), (256, 128), (33, 64)])
+@pytest.mark.parametrize("R,Cc", [(128, 128), (40, 24), (256, 128), (33, 64), (64, 512), (1024, 32), (16, 16), (127, 129)])
 def test_erank_jacobi_vs_svdvals(ops, R, Cc):
     from oracle import futr_oracle as O
     x = rnd(R, Cc, seed=R) @ torch.diag(torch.linspace(0.05, 2.0, Cc)) + 0.3
@@ -493,7 +493,7 @@ def test_erank_jacobi_vs_svdvals(ops, R, Cc):
     assert float(off.abs().max()) < 1e-3 * float(sv[0]) ** 2
 
 
-@pytest.mark.parametrize("R,Cc", [(512, 512), (128, 512), (2048, 256), (300, 200), (64, 40)])
+@pytest.mark.parametrize("R,Cc", [(512, 512), (128, 512), (2048, 256), (300, 200), (64, 40), (2048, 1024), (256, 1024), (130, 70)])
 def test_erank_blocked_vs_svdvals(ops, R, Cc):
     """The two-level Jacobi (columns in HBM) for matrices that exceed one CU's LDS -- and small ones for coverage."""
     from oracle import futr_oracle as O
@@ -511,7 +511,7 @@ def test_erank_blocked_vs_svdvals(ops, R, Cc):
         torch.cuda.synchronize()
         sv = torch.linalg.svdvals(x.double())
         assert_close(torch.sort(sig.cpu(), descending=True)[0], sv, 1e-4, 1e-4 * float(sv[0]), "sigma")
-        assert float(st[3]) < 30, "did not converge"
+        assert float(st[3]) < 20, "did not converge"
         A = aft[:Cc].cpu().double()
         G = A @ A.t()
         off = G - torch.diag(torch.diag(G))
