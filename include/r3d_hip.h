@@ -369,6 +369,18 @@ int r3d_scale_rows(float* x, int ld, int rows, int cols, const float* coef, void
 int r3d_erank_vt_update(const float* t1, int ld, const float* sigma, float* vt, int C, float rel_thresh, void* stream);
 int r3d_erank_vt_polish(const float* vt_raw, const float* gv, float* vt, int64_t n, void* stream);
 
+/* ---- depth-as-query model (reference model/futr_unsupervised_depth.py) ------------------------------------------------
+ * r3d_posenc_fwd / bwd: PositionalEncoding.forward (model/extras/position.py:29-35) on b-major rows,
+ *   y[r, :] = dropout(x[r, :] + table[r % S, :]); backward dx = dy * keep * scale, zero where gate <= 0 (gate: NULL or
+ *   the post-ReLU embedding of futr_unsupervised_depth.py:97).  drop: NULL or rows*H contiguous keep-bytes.
+ * r3d_avgpool_rows_fwd / bwd: F.adaptive_avg_pool1d over the S decoder rows of each clip down to Q rows (:134). */
+int r3d_posenc_fwd(const float* x, int ldx, const float* table, int ldt, int S, const uint8_t* drop, float drop_scale,
+                   float* y, int ldy, int rows, int H, void* stream);
+int r3d_posenc_bwd(const float* dy, int lddy, const uint8_t* drop, float drop_scale, const float* gate, int ldg, float* dx,
+                   int lddx, int rows, int H, void* stream);
+int r3d_avgpool_rows_fwd(const float* x, int ldx, float* y, int ldy, int B, int S, int Q, int H, void* stream);
+int r3d_avgpool_rows_bwd(const float* dy, int lddy, float* dx, int lddx, int B, int S, int Q, int H, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -371,6 +371,53 @@ def forward(p, inputs, depth, mode, pad_idx, n_head=8, n_layers=1, want_seg=True
 
 
 # ----------------------------------------------------------------------------------------
+# depth-as-query model (model/futr_unsupervised_depth.py)
+# ----------------------------------------------------------------------------------------
+def sinusoid_table(max_len, d_model):
+    """PositionalEncoding's buffer `pos_table` [1, max_len, d_model] (model/extras/position.py:19-27)."""
+    position = torch.arange(max_len).unsqueeze(1)
+    div_term = torch.exp(torch.arange(0, d_model, 2) * (-math.log(10000.0) / d_model))
+    pe = torch.zeros(1, max_len, d_model)
+    pe[0, :, 0::2] = torch.sin(position * div_term)
+    pe[0, :, 1::2] = torch.cos(position * div_term)
+    return pe
+
+
+def forward_unsup_depth(p, inputs, depth, mode, pad_idx, n_head=8, n_layers=1, n_query=8):
+    """FUTR.forward of model/futr_unsupervised_depth.py:85-163, input_type 'i3d_transcript', dropout omitted
+    (eval state).  The RGB embedding + sinusoidal encoding is the decoder's MEMORY (the encoder is bypassed,
+    transformer.py:77-78); the depth embedding + sinusoidal encoding is its per-clip QUERY (S queries per clip, :115,
+    :128); the S decoder outputs are average-pooled to n_query rows (:134) before the anticipation heads.
+    In any mode but 'train' the reference takes `inputs` as the bare feature tensor (:90) -- its own validate() passes a
+    tuple there and crashes; a tuple is accepted here."""
+    if mode == "train":
+        src, src_label = inputs                                                      # :87
+        kpm = (src_label == pad_idx)                                                 # :89
+    else:
+        src = inputs[0] if isinstance(inputs, (tuple, list)) else inputs            # :91
+        kpm = None
+    B, S, _ = src.shape
+    H = p["input_embed.weight"].shape[0]
+    pe = sinusoid_table(3000, H)[:, :S]
+    mem = F.relu(F.linear(src, p["input_embed.weight"], p["input_embed.bias"])) + pe   # :96-99 (pos_enc, dropout omitted)
+    pos = p["pos_embedding"][:, :S]                                                  # :104
+    d = depth.reshape(B, S, -1)                                                      # :107-108 (depth is [B,S,Hh,Ww] here)
+    d = F.linear(d, p["depth_projection.weight"], p["depth_projection.bias"])        # :109
+    d = F.relu(layer_norm(d, p["depth_layernorm.weight"], p["depth_layernorm.bias"]))  # :110-111
+    query = d + pe                                                                   # :115 (pos_enc_depth)
+    tgt = decoder(p, mem, pos, query, kpm, n_head, n_layers)                         # :128, tgt = zeros_like(query) :126
+    pooled = F.adaptive_avg_pool1d(tgt.permute(0, 2, 1), n_query).permute(0, 2, 1)   # :134
+    out = {"action": F.linear(pooled, p["fc.weight"], p["fc.bias"]),                  # :140-144
+           "duration": F.linear(pooled, p["fc_len.weight"], p["fc_len.bias"]).squeeze(2),
+           "seg": F.linear(mem, p["fc_seg.weight"], p["fc_seg.bias"])}               # :148 (src returned unchanged = memory)
+    return out, dict(memory=mem, query=query, tgt=tgt, pooled=pooled)
+
+
+UNSUP_LIVE_PREFIXES = ("input_embed.", "depth_projection.", "depth_layernorm.", "pos_embedding", "transformer.decoder.",
+                       "fc_seg.", "fc.", "fc_len.")
+
+
+# ----------------------------------------------------------------------------------------
 # losses (utils.py:325-328, 358-378, 410-490; train/train_proposed_depth.py:28-50, 171-213)
 # ----------------------------------------------------------------------------------------
 EXCLUDE_CLASS_IDX = 47   # hard-coded in train_proposed_depth.py:181,195
@@ -517,11 +564,16 @@ def is_live(name, bn=False):
 class CpuTrainer:
     """fwd + 3 losses + autograd bwd + AdamW over a parameter dict (reference semantics)."""
 
-    def __init__(self, params, pad_idx, n_head=8, n_layers=1, lr=1e-3, wd=5e-3, bn_state=None, bn_training=True):
-        """bn_state: BatchNorm buffers -> the BN-blend variant (its alpha / bn_* parameters must be in params)."""
+    def __init__(self, params, pad_idx, n_head=8, n_layers=1, lr=1e-3, wd=5e-3, bn_state=None, bn_training=True,
+                 unsup_depth=False, n_query=8):
+        """bn_state: BatchNorm buffers -> the BN-blend variant (its alpha / bn_* parameters must be in params).
+        unsup_depth: the depth-as-query model (forward_unsup_depth)."""
         self.bn_state = None if bn_state is None else {k: v.clone() for k, v in bn_state.items()}
         self.bn_training = bn_training
+        self.unsup_depth, self.n_query = unsup_depth, n_query
         live = (lambda k: is_live(k, bn=True)) if bn_state is not None else is_live
+        if unsup_depth:
+            live = lambda k: k.startswith(UNSUP_LIVE_PREFIXES)       # noqa: E731
         self.p = {k: v.clone().requires_grad_(live(k)) for k, v in params.items()}
         self.pad_idx, self.n_head, self.n_layers = pad_idx, n_head, n_layers
         self.lr, self.wd = lr, wd
@@ -533,8 +585,12 @@ class CpuTrainer:
         feats, depth, lab, dur, tgt = batch
         for q in self.p.values():
             q.grad = None
-        out, aux = forward(self.p, (feats, lab), depth, "train", self.pad_idx, self.n_head, self.n_layers,
-                           bn_state=self.bn_state, bn_training=self.bn_training)
+        if self.unsup_depth:
+            out, aux = forward_unsup_depth(self.p, (feats, lab), depth, "train", self.pad_idx, self.n_head, self.n_layers,
+                                           self.n_query)
+        else:
+            out, aux = forward(self.p, (feats, lab), depth, "train", self.pad_idx, self.n_head, self.n_layers,
+                               bn_state=self.bn_state, bn_training=self.bn_training)
         res = losses(out, lab, dur, tgt, self.pad_idx)
         res["loss"].backward()
         if apply:

@@ -143,6 +143,10 @@ _SIGNATURES = {
     "r3d_erank_blocked": ([_P, _I, _I, _I, _P, _P, _P, _P, _I, _P], C.c_int),
     "r3d_erank_bwd_coef": ([_P, _P, _P, _P, _I, _I, _P], C.c_int),
     "r3d_scale_rows": ([_P, _I, _I, _I, _P, _P], C.c_int),
+    "r3d_posenc_fwd": ([_P, _I, _P, _I, _I, _P, _F, _P, _I, _I, _I, _P], C.c_int),
+    "r3d_posenc_bwd": ([_P, _I, _P, _F, _P, _I, _P, _I, _I, _I, _P], C.c_int),
+    "r3d_avgpool_rows_fwd": ([_P, _I, _P, _I, _I, _I, _I, _I, _P], C.c_int),
+    "r3d_avgpool_rows_bwd": ([_P, _I, _P, _I, _I, _I, _I, _I, _P], C.c_int),
     "r3d_erank_vt_update": ([_P, _I, _P, _P, _I, _F, _P], C.c_int),
     "r3d_erank_vt_polish": ([_P, _P, _P, _L, _P], C.c_int),
 }

@@ -643,3 +643,32 @@ def erank_vt_polish(vt_raw, gv, vt):
     lib = _lib.load()
     assert vt_raw.is_contiguous() and gv.is_contiguous() and vt.is_contiguous()
     check(lib.r3d_erank_vt_polish(_p(vt_raw), _p(gv), _p(vt), vt.numel(), _stream()), "r3d_erank_vt_polish")
+
+
+# ----------------------------------------------------------------------------------------------------------
+# depth-as-query model (model/futr_unsupervised_depth.py)
+# ----------------------------------------------------------------------------------------------------------
+def posenc_fwd(x, table, S, y, *, drop_mask=None, drop_scale=1.0):
+    """y = dropout(x + table[row % S]) (model/extras/position.py:29-35)."""
+    rows, H = x.shape
+    assert table.shape[0] >= S and table.shape[1] == H
+    check(_lib.load().r3d_posenc_fwd(_p(x), _ld(x), _p(table), _ld(table), S, _p(drop_mask), drop_scale, _p(y), _ld(y), rows, H,
+                                     _stream()), "r3d_posenc_fwd")
+
+
+def posenc_bwd(dy, dx, *, drop_mask=None, drop_scale=1.0, gate=None):
+    rows, H = dy.shape
+    check(_lib.load().r3d_posenc_bwd(_p(dy), _ld(dy), _p(drop_mask), drop_scale, _p(gate), _ld(gate) if gate is not None else 0,
+                                     _p(dx), _ld(dx), rows, H, _stream()), "r3d_posenc_bwd")
+
+
+def avgpool_rows_fwd(x, y, B, S, Q):
+    H = x.shape[1]
+    assert x.shape[0] == B * S and tuple(y.shape) == (B * Q, H)
+    check(_lib.load().r3d_avgpool_rows_fwd(_p(x), _ld(x), _p(y), _ld(y), B, S, Q, H, _stream()), "r3d_avgpool_rows_fwd")
+
+
+def avgpool_rows_bwd(dy, dx, B, S, Q):
+    H = dy.shape[1]
+    assert dy.shape[0] == B * Q and tuple(dx.shape) == (B * S, H)
+    check(_lib.load().r3d_avgpool_rows_bwd(_p(dy), _ld(dy), _p(dx), _ld(dx), B, S, Q, H, _stream()), "r3d_avgpool_rows_bwd")

@@ -16,16 +16,18 @@ import torch
 import torch.distributed as dist
 
 from .model.futr_safuser_tokenfusion import FUTR
+from .model.futr_unsupervised_depth import FUTR as FUTRDepthQuery
 from .optim import FlatAdamW
 from .parallel import DataParallelStep
 
 
 def _unwrap(model):
     m = model
-    while hasattr(m, "module") and not isinstance(m, FUTR):
+    while hasattr(m, "module") and not isinstance(m, (FUTR, FUTRDepthQuery)):
         m = m.module
-    if not isinstance(m, FUTR):
-        raise TypeError("r3d_amd.train_proposed_depth drives r3d_amd.model.futr_safuser_tokenfusion.FUTR")
+    if not isinstance(m, (FUTR, FUTRDepthQuery)):
+        raise TypeError("r3d_amd.train_proposed_depth drives r3d_amd.model.futr_safuser_tokenfusion.FUTR (or its "
+                        "BN-blend subclass) and r3d_amd.model.futr_unsupervised_depth.FUTR")
     return m
 
 
