@@ -363,10 +363,14 @@ int r3d_erank_blocked(const float* x, int ld, int R, int C, float* sigma, float*
 int r3d_erank_bwd_coef(const float* sigma, const float* stats, const float* gout, float* coef, int C, int max_rank,
                        void* stream);
 int r3d_scale_rows(float* x, int ld, int rows, int cols, const float* coef, void* stream);
-/* Warm start of the next decomposition of a nearby matrix: after a sweep X V = Af, so t1 = Af^T X = Sigma^2 V^T and
- * vt [C][C] <- diag(1 / sigma^2) t1 (the identity when min sigma <= rel_thresh * max sigma); r3d_erank_vt_polish is one
- * Newton-Schulz step vt <- 1.5 vt_raw - 0.5 gv with gv = (vt_raw vt_raw^T) vt_raw.  The caller then decomposes X vt^T. */
-int r3d_erank_vt_update(const float* t1, int ld, const float* sigma, float* vt, int C, float rel_thresh, void* stream);
+/* r3d_erank_jacobi that also carries the right singular basis (batch == 1): every rotation is applied to the rows of
+ * V^T as well, vt_out [C][C] = (V0 V')^T.  vt_in = V0^T from an earlier decomposition of a nearby matrix and x = X V0
+ * (NULL: identity): a warm start, 3-5 sweeps instead of 10-11.  Matrix and basis must fit the LDS together
+ * (r3d_erank_lds_bytes_v).  r3d_erank_vt_polish: one Newton-Schulz step vt <- 1.5 vt_raw - 0.5 gv with
+ * gv = (vt_raw vt_raw^T) vt_raw, which keeps the carried basis orthogonal to rounding over many steps. */
+int64_t r3d_erank_lds_bytes_v(int R, int C);
+int r3d_erank_jacobi_warm(const float* x, int ld, int64_t batch_stride, int batch, int R, int C, int gram, float* sigma,
+                          float* af_t, float* stats, int max_sweeps, const float* vt_in, float* vt_out, void* stream);
 int r3d_erank_vt_polish(const float* vt_raw, const float* gv, float* vt, int64_t n, void* stream);
 
 /* ---- depth-as-query model (reference model/futr_unsupervised_depth.py) ------------------------------------------------

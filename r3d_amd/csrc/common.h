@@ -26,20 +26,50 @@ namespace r3d {
 
 constexpr int kWave = 64;
 
+// Wave-wide reductions without the LDS crossbar: a row_ror butterfly inside each 16-lane DPP row (4 x v_add_f32_dpp,
+// every lane of a row ends with the row's value), then the four row values are read with v_readlane and combined in
+// a fixed order -- ~12 instructions against six dependent ds_bpermute round trips for the __shfl_xor form (the row
+// kernels of the step are latency chains of such reductions).  All 64 lanes must be active at the call (they are:
+// every call site reduces over a whole wave with out-of-range lanes contributing the identity).
+template <int CTRL> __device__ __forceinline__ float dpp_mov_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    v += dpp_mov_f<0x128>(v);          // row_ror:8
+    v += dpp_mov_f<0x124>(v);          // row_ror:4
+    v += dpp_mov_f<0x122>(v);          // row_ror:2
+    v += dpp_mov_f<0x121>(v);          // row_ror:1
+    return (readlane_f(v, 0) + readlane_f(v, 16)) + (readlane_f(v, 32) + readlane_f(v, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-    return v;
+    v = fmaxf(v, dpp_mov_f<0x128>(v));
+    v = fmaxf(v, dpp_mov_f<0x124>(v));
+    v = fmaxf(v, dpp_mov_f<0x122>(v));
+    v = fmaxf(v, dpp_mov_f<0x121>(v));
+    return fmaxf(fmaxf(readlane_f(v, 0), readlane_f(v, 16)), fmaxf(readlane_f(v, 32), readlane_f(v, 48)));
+}
+__device__ __forceinline__ double dpp_mov_d(double v, int) { return v; }
+template <int CTRL> __device__ __forceinline__ double dpp_mov_d(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
+}
+__device__ __forceinline__ double readlane_d(double v, int lane) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
 }
 __device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    v += dpp_mov_d<0x128>(v);
+    v += dpp_mov_d<0x124>(v);
+    v += dpp_mov_d<0x122>(v);
+    v += dpp_mov_d<0x121>(v);
+    return (readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + readlane_d(v, 48));
 }
 
 // exact-erf GELU (nn.GELU(approximate='none'), model/extras/transformerblock.py:80,86)

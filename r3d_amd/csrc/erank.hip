@@ -64,26 +64,31 @@ template <int G> __device__ __forceinline__ float col_norm2(const float4* col, i
     return group_sum<G>(s);
 }
 
-// One Hestenes rotation of columns (i, j) by a group of G lanes (lane lg of the group).  NCH > 0: every lane holds its
-// NCH 16-byte chunks of both columns in registers (needs NCH * G >= Rp4; EXACT: NCH * G == Rp4, no bounds checks, all
-// LDS reads issued before the first use); NCH == 0: any length, two passes over LDS.  Returns true when the pair was rotated.
+// One Hestenes rotation of columns (i, j) by a group of G lanes (lane lg of the group).  A column is S4 16-byte chunks
+// long; the dot product runs over its first D4 chunks only (the matrix rows), the rotation over all of them (the tail
+// holds the column's slice of the accumulated right singular basis V when a warm start is kept, see ErankArgs::vt_out).
+// NCH > 0: every lane holds its NCH chunks of both columns in registers (needs NCH * G >= S4; EXACT: NCH * G == S4 and
+// D4 == nchd * G, no bounds checks, all LDS reads issued before the first use); NCH == 0: any length, two passes over
+// LDS.  Returns true when the pair was rotated.
 template <int G, int NCH, bool EXACT>
-__device__ __forceinline__ bool jac_pair(float4* A4, float* nrm, int Rp4, int i, int j, int lg, float tol2, float negl) {
-    float4* ai = A4 + (size_t)i * Rp4;
-    float4* aj = A4 + (size_t)j * Rp4;
+__device__ __forceinline__ bool jac_pair(float4* A4, float* nrm, int S4, int D4, int nchd, int i, int j, int lg, float tol2,
+                                         float negl) {
+    float4* ai = A4 + (size_t)i * S4;
+    float4* aj = A4 + (size_t)j * S4;
     float4 u[NCH > 0 ? NCH : 1], v[NCH > 0 ? NCH : 1];
     float ga = 0.f;
     if (NCH > 0) {
 #pragma unroll
         for (int q = 0; q < NCH; ++q) {
             const int ch = lg + G * q;
-            if (EXACT || ch < Rp4) { u[q] = ai[ch]; v[q] = aj[ch]; }
+            if (EXACT || ch < S4) { u[q] = ai[ch]; v[q] = aj[ch]; }
             else { u[q] = make_float4(0.f, 0.f, 0.f, 0.f); v[q] = u[q]; }
         }
 #pragma unroll
-        for (int q = 0; q < NCH; ++q) ga += dot4(u[q], v[q]);
+        for (int q = 0; q < NCH; ++q)
+            if (EXACT ? (q < nchd) : (lg + G * q < D4)) ga += dot4(u[q], v[q]);
     } else {
-        for (int ch = lg; ch < Rp4; ch += G) ga += dot4(ai[ch], aj[ch]);
+        for (int ch = lg; ch < D4; ch += G) ga += dot4(ai[ch], aj[ch]);
     }
     ga = group_sum<G>(ga);
     const float al = nrm[i], be = nrm[j];
@@ -100,14 +105,14 @@ __device__ __forceinline__ bool jac_pair(float4* A4, float* nrm, int Rp4, int i,
 #pragma unroll
             for (int q = 0; q < NCH; ++q) {
                 const int ch = lg + G * q;
-                if (EXACT || ch < Rp4) {
+                if (EXACT || ch < S4) {
                     const float4 a = u[q], b = v[q];
                     ai[ch] = make_float4(c * a.x - s * b.x, c * a.y - s * b.y, c * a.z - s * b.z, c * a.w - s * b.w);
                     aj[ch] = make_float4(s * a.x + c * b.x, s * a.y + c * b.y, s * a.z + c * b.z, s * a.w + c * b.w);
                 }
             }
         } else {
-            for (int ch = lg; ch < Rp4; ch += G) {
+            for (int ch = lg; ch < S4; ch += G) {
                 const float4 a = ai[ch], b = aj[ch];
                 ai[ch] = make_float4(c * a.x - s * b.x, c * a.y - s * b.y, c * a.z - s * b.z, c * a.w - s * b.w);
                 aj[ch] = make_float4(s * a.x + c * b.x, s * a.y + c * b.y, s * a.z + c * b.z, s * a.w + c * b.w);
@@ -126,6 +131,8 @@ struct ErankArgs {
     float* stats;          // [batch][4] = {erank, entropy, sum sigma, sweeps}
     int sqrt_out;          // input is a Gram matrix: report sqrt of its singular values
     int max_sweeps;
+    const float* vt_in;    // warm start (batch == 1): V0^T [C][C]; x already holds X V0.  NULL: V0 = identity
+    float* vt_out;         // (V0 V')^T [C][C]: the right singular basis after the sweeps (rotations applied to V0's rows too)
 };
 
 // sigma -> {erank, entropy, sum sigma}; sig: C floats in LDS; wred: 16 floats of LDS scratch; all threads of the block
@@ -156,15 +163,18 @@ __device__ __forceinline__ void erank_stats_block(const float* sig, int C, float
 
 template <int G, int NCH, bool EXACT>
 __global__ __launch_bounds__(kJacThreads) void erank_jacobi_kernel(const ErankArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // A [Cp][Rp], nrm [Cp]
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // columns [Cp][Sp] (Sp = Rp [+ Cv]), nrm [Cp]
     __shared__ int rotated;
     __shared__ float wred[kJacThreads / 64];
     const int R = a.R, C = a.C;
     const int Rp = (R + 3) & ~3, Rp4 = Rp >> 2;
     const int Cp = (C + 1) & ~1;                                   // even number of players (last may be a dummy)
+    const int Cv = a.vt_out ? (C + 3) & ~3 : 0;                    // rows of V^T kept behind every column
+    const int Sp = Rp + Cv, S4 = Sp >> 2;
+    const int nchd = Rp4 / G;                                      // (EXACT: chunks of the dot product per lane)
     float* A = smem;
     float4* A4 = reinterpret_cast<float4*>(smem);
-    float* nrm = smem + (size_t)Cp * Rp;
+    float* nrm = smem + (size_t)Cp * Sp;
     const int tid = threadIdx.x;
     const int slot = tid / G, lg = tid % G, nslots = kJacThreads / G;
     const float* X = a.x + (size_t)blockIdx.x * a.batch_stride;
@@ -173,7 +183,15 @@ __global__ __launch_bounds__(kJacThreads) void erank_jacobi_kernel(const ErankAr
     // HBM reads of the [R, C] matrix hit each 64-byte sector once, the rest comes from L2)
     for (int e = tid; e < Cp * Rp; e += kJacThreads) {
         const int c = e / Rp, r = e - c * Rp;
-        A[e] = (c < C && r < R) ? X[(size_t)r * a.ld + c] : 0.f;
+        A[(size_t)c * Sp + r] = (c < C && r < R) ? X[(size_t)r * a.ld + c] : 0.f;
+    }
+    if (Cv) {                                                       // column c carries row c of V^T = column c of V
+        for (int e = tid; e < Cp * Cv; e += kJacThreads) {
+            const int c = e / Cv, k = e - c * Cv;
+            float v = 0.f;
+            if (c < C && k < C) v = a.vt_in ? a.vt_in[(size_t)c * C + k] : (c == k ? 1.f : 0.f);
+            A[(size_t)c * Sp + Rp + k] = v;
+        }
     }
     __syncthreads();
 
@@ -184,7 +202,7 @@ __global__ __launch_bounds__(kJacThreads) void erank_jacobi_kernel(const ErankAr
     for (; sweeps < a.max_sweeps; ++sweeps) {
         // exact squared norms (the cached ones drift by rounding over a sweep of updates)
         for (int c = slot; c < Cp; c += nslots) {
-            const float s2 = col_norm2<G>(A4 + (size_t)c * Rp4, Rp4, lg);
+            const float s2 = col_norm2<G>(A4 + (size_t)c * S4, Rp4, lg);
             if (lg == 0) nrm[c] = s2;
         }
         if (tid == 0) rotated = 0;
@@ -201,7 +219,7 @@ __global__ __launch_bounds__(kJacThreads) void erank_jacobi_kernel(const ErankAr
             for (int k = slot; k < npairs; k += nslots) {
                 int i, j;
                 rr_pair(Cp, rd, k, i, j);
-                my_rot |= jac_pair<G, NCH, EXACT>(A4, nrm, Rp4, i, j, lg, tol2, negl);
+                my_rot |= jac_pair<G, NCH, EXACT>(A4, nrm, S4, Rp4, nchd, i, j, lg, tol2, negl);
             }
             __syncthreads();
         }
@@ -215,7 +233,7 @@ __global__ __launch_bounds__(kJacThreads) void erank_jacobi_kernel(const ErankAr
     // singular values (from the columns themselves, not the cached norms), entropy, erank
     float* sig = a.sigma + (size_t)blockIdx.x * C;
     for (int c = slot; c < C; c += nslots) {
-        const float s2 = col_norm2<G>(A4 + (size_t)c * Rp4, Rp4, lg);
+        const float s2 = col_norm2<G>(A4 + (size_t)c * S4, Rp4, lg);
         float s = s2 > negl ? sqrtf(s2) : 0.f;       // numerically zero columns (rank-deficient input) report sigma = 0
         if (a.sqrt_out) s = sqrtf(s);
         if (lg == 0) { nrm[c] = s; sig[c] = s; }
@@ -226,12 +244,21 @@ __global__ __launch_bounds__(kJacThreads) void erank_jacobi_kernel(const ErankAr
         float* out = a.af_t + (size_t)blockIdx.x * C * R;
         if ((R & 3) == 0) {
             float4* o4 = reinterpret_cast<float4*>(out);
-            for (int e = tid; e < C * Rp4; e += kJacThreads) o4[e] = A4[e];
+            for (int e = tid; e < C * Rp4; e += kJacThreads) {
+                const int c = e / Rp4, q = e - c * Rp4;
+                o4[e] = A4[(size_t)c * S4 + q];
+            }
         } else {
             for (int e = tid; e < R * C; e += kJacThreads) {
                 const int c = e / R, r = e - c * R;
-                out[e] = A[c * Rp + r];
+                out[e] = A[(size_t)c * Sp + r];
             }
+        }
+    }
+    if (Cv) {
+        for (int e = tid; e < C * C; e += kJacThreads) {
+            const int c = e / C, k = e - c * C;
+            a.vt_out[e] = A[(size_t)c * Sp + Rp + k];
         }
     }
 }
@@ -312,7 +339,7 @@ __global__ __launch_bounds__(kJacThreads) void erank_blk_round_kernel(ErankBlk g
             int i, j;
             if (mode == 0) rr_pair(b, t, k, i, j);
             else { i = k; j = k + t; if (j >= b) j -= b; j += b; }
-            my_rot |= jac_pair<G, NCH, EXACT>(A4, nrm, Rp4, i, j, lg, tol2, negl);
+            my_rot |= jac_pair<G, NCH, EXACT>(A4, nrm, Rp4, Rp4, Rp4 / G, i, j, lg, tol2, negl);
         }
         __syncthreads();
     }
@@ -374,28 +401,6 @@ __global__ __launch_bounds__(256) void scale_rows_kernel(float* x, int ld, int r
     }
 }
 
-// Warm start for the next decomposition of a nearby matrix (the next training step's fused tokens).  After a sweep
-// X V = Af, so t1 = Af^T X = Sigma^2 V^T: row k of V^T is t1[k, :] / sigma_k^2.  When the smallest singular value is
-// below rel_thresh * the largest the direction carries no usable row (error ~ eps sigma_max / sigma_k): V^T is reset
-// to the identity (a cold start).  One workgroup per row.
-__global__ __launch_bounds__(256) void erank_vt_update_kernel(const float* __restrict__ t1, int ld, const float* __restrict__ sigma,
-                                                              float* __restrict__ vt, int C, float rel_thresh) {
-    __shared__ float red[8];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float mx = 0.f, mn = 3.4e38f;
-    for (int c = tid; c < C; c += 256) { const float s = sigma[c]; mx = fmaxf(mx, s); mn = fminf(mn, s); }
-    mx = wave_max(mx); mn = -wave_max(-mn);
-    if (lane == 0) { red[wave] = mx; red[4 + wave] = mn; }
-    __syncthreads();
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    mn = fminf(fminf(red[4], red[5]), fminf(red[6], red[7]));
-    const int k = blockIdx.x;
-    const bool ok = mn > rel_thresh * mx && mx > 0.f;
-    const float s = sigma[k];
-    const float inv = ok ? 1.f / (s * s) : 0.f;
-    for (int c = tid; c < C; c += 256) vt[(size_t)k * C + c] = ok ? t1[(size_t)k * ld + c] * inv : (c == k ? 1.f : 0.f);
-}
-
 // one Newton-Schulz step towards the nearest orthogonal matrix: V^T <- 1.5 V^T - 0.5 (V^T V) V^T  (gv = (V^T V^T^T) V^T)
 __global__ __launch_bounds__(256) void erank_vt_polish_kernel(const float* __restrict__ vt_raw, const float* __restrict__ gv,
                                                               float* __restrict__ vt, size_t n) {
@@ -407,9 +412,17 @@ __global__ __launch_bounds__(256) void erank_vt_polish_kernel(const float* __res
 
 using namespace r3d;
 
+R3D_EXPORT int r3d_erank_jacobi_warm(const float* x, int ld, int64_t batch_stride, int batch, int R, int C, int gram,
+                                     float* sigma, float* af_t, float* stats, int max_sweeps, const float* vt_in,
+                                     float* vt_out, void* stream);
+
 static inline int erank_rp(int R) { return (R + 3) & ~3; }
 
+/* LDS bytes of r3d_erank_jacobi for an [R, C] matrix; keep_v != 0: with the C x C right singular basis riding along. */
 R3D_EXPORT int64_t r3d_erank_lds_bytes(int R, int C) { return ((int64_t)((C + 1) & ~1) * erank_rp(R) + ((C + 1) & ~1)) * 4; }
+R3D_EXPORT int64_t r3d_erank_lds_bytes_v(int R, int C) {
+    return ((int64_t)((C + 1) & ~1) * (erank_rp(R) + ((C + 3) & ~3)) + ((C + 1) & ~1)) * 4;
+}
 
 template <int G, int NCH, bool EXACT>
 static int erank_launch2(const ErankArgs& a, int batch, int64_t lds, hipStream_t st) {
@@ -423,7 +436,8 @@ static int erank_launch2(const ErankArgs& a, int batch, int64_t lds, hipStream_t
 }
 template <int G, int NCH>
 static int erank_launch(const ErankArgs& a, int batch, int64_t lds, hipStream_t st) {
-    if (NCH > 0 && ((a.R + 3) >> 2) == G * NCH) return erank_launch2<G, NCH, true>(a, batch, lds, st);
+    const int rp4 = erank_rp(a.R) / 4, s4 = rp4 + (a.vt_out ? ((a.C + 3) & ~3) / 4 : 0);
+    if (NCH > 0 && s4 == G * NCH && rp4 % G == 0) return erank_launch2<G, NCH, true>(a, batch, lds, st);
     return erank_launch2<G, NCH, false>(a, batch, lds, st);
 }
 
@@ -433,25 +447,40 @@ static int erank_launch(const ErankArgs& a, int batch, int64_t lds, hipStream_t 
  * Returns R3D_EINVAL when the matrix does not fit the 160 KB LDS of one CU (see r3d_erank_lds_bytes). */
 R3D_EXPORT int r3d_erank_jacobi(const float* x, int ld, int64_t batch_stride, int batch, int R, int C, int gram,
                                 float* sigma, float* af_t, float* stats, int max_sweeps, void* stream) {
+    return r3d_erank_jacobi_warm(x, ld, batch_stride, batch, R, C, gram, sigma, af_t, stats, max_sweeps, nullptr, nullptr,
+                                 stream);
+}
+
+/* r3d_erank_jacobi that also carries the right singular basis: every rotation of two columns of X V0 is applied to
+ * the same two rows of V^T, so vt_out [C][C] = (V0 V')^T with X (V0 V') = the rotated columns.  vt_in: V0^T of an
+ * earlier decomposition of a NEARBY matrix (the caller passes x = X V0, one GEMM; NULL = identity): the columns start
+ * almost orthogonal and the sweep count drops from 10-11 to 3-5.  batch must be 1; the matrix and the basis must fit
+ * the LDS together (r3d_erank_lds_bytes_v).  vt_out == NULL: plain r3d_erank_jacobi. */
+R3D_EXPORT int r3d_erank_jacobi_warm(const float* x, int ld, int64_t batch_stride, int batch, int R, int C, int gram,
+                                     float* sigma, float* af_t, float* stats, int max_sweeps, const float* vt_in,
+                                     float* vt_out, void* stream) {
     R3D_REQUIRE(x && sigma && stats && batch > 0 && R > 0 && C > 0 && ld >= C);
     R3D_REQUIRE(!gram || R == C);
-    const int64_t lds = r3d_erank_lds_bytes(R, C);
+    R3D_REQUIRE(!vt_in || vt_out);
+    R3D_REQUIRE(!vt_out || batch == 1);
+    const int64_t lds = vt_out ? r3d_erank_lds_bytes_v(R, C) : r3d_erank_lds_bytes(R, C);
     R3D_REQUIRE(lds <= 160 * 1024 - 256);
     if (af_t && (R & 3) == 0) R3D_REQUIRE(r3d_aligned16(af_t));
-    ErankArgs a{x, ld, (long long)batch_stride, R, C, sigma, af_t, stats, gram, max_sweeps > 0 ? max_sweeps : 30};
+    ErankArgs a{x, ld, (long long)batch_stride, R, C, sigma, af_t, stats, gram, max_sweeps > 0 ? max_sweeps : 30, vt_in, vt_out};
     hipStream_t st = (hipStream_t)stream;
-    const int npairs = ((C + 1) & ~1) / 2, rp4 = erank_rp(R) / 4;
+    const int npairs = ((C + 1) & ~1) / 2;
+    const int s4 = erank_rp(R) / 4 + (vt_out ? ((C + 3) & ~3) / 4 : 0);       // 16-byte chunks per column
     if (npairs > 16) {                          // 16 lanes per pair: 64 pairs per pass
-        if (rp4 <= 16) return erank_launch<16, 1>(a, batch, lds, st);
-        if (rp4 <= 32) return erank_launch<16, 2>(a, batch, lds, st);
-        if (rp4 <= 64) return erank_launch<16, 4>(a, batch, lds, st);
-        if (rp4 <= 128) return erank_launch<16, 8>(a, batch, lds, st);
+        if (s4 <= 16) return erank_launch<16, 1>(a, batch, lds, st);
+        if (s4 <= 32) return erank_launch<16, 2>(a, batch, lds, st);
+        if (s4 <= 64) return erank_launch<16, 4>(a, batch, lds, st);
+        if (s4 <= 128) return erank_launch<16, 8>(a, batch, lds, st);
         return erank_launch<16, 0>(a, batch, lds, st);
     }
-    if (rp4 <= 64) return erank_launch<64, 1>(a, batch, lds, st);
-    if (rp4 <= 128) return erank_launch<64, 2>(a, batch, lds, st);
-    if (rp4 <= 256) return erank_launch<64, 4>(a, batch, lds, st);
-    if (rp4 <= 512) return erank_launch<64, 8>(a, batch, lds, st);
+    if (s4 <= 64) return erank_launch<64, 1>(a, batch, lds, st);
+    if (s4 <= 128) return erank_launch<64, 2>(a, batch, lds, st);
+    if (s4 <= 256) return erank_launch<64, 4>(a, batch, lds, st);
+    if (s4 <= 512) return erank_launch<64, 8>(a, batch, lds, st);
     return erank_launch<64, 0>(a, batch, lds, st);
 }
 
@@ -553,16 +582,6 @@ R3D_EXPORT int r3d_scale_rows(float* x, int ld, int rows, int cols, const float*
     const size_t total = (size_t)rows * cols;
     const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
     hipLaunchKernelGGL(scale_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ld, rows, cols, coef);
-    R3D_LAUNCH_CHECK();
-    return R3D_OK;
-}
-
-/* Warm start (see erank_vt_update_kernel): vt [C][C] <- diag(1 / sigma^2) t1, or the identity when
- * min sigma <= rel_thresh * max sigma.  t1 [C][ld] = Af^T X as the backward computes it (before r3d_scale_rows). */
-R3D_EXPORT int r3d_erank_vt_update(const float* t1, int ld, const float* sigma, float* vt, int C, float rel_thresh,
-                                   void* stream) {
-    R3D_REQUIRE(t1 && sigma && vt && C > 0 && ld >= C && rel_thresh >= 0.f);
-    hipLaunchKernelGGL(erank_vt_update_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, t1, ld, sigma, vt, C, rel_thresh);
     R3D_LAUNCH_CHECK();
     return R3D_OK;
 }

@@ -456,10 +456,10 @@ class FusionEngine:
     # ---- effective-rank penalty on the fused token matrix [N, H] (erank.hip; Appendix A.11) ------------------------------
     def _erank_forward(self, w):
         """Jacobi forward on the fused tokens.  Warm start (erank_warm_start): the sweep runs on X V0, V0 the right
-        singular basis the previous step's backward left behind (identity on the first step) -- the tokens move little
-        between optimiser steps, so X V0 has almost orthogonal columns and 3-5 sweeps replace 10-11.  The singular values
-        of X V0 are those of X (V0 orthogonal), and the rotated columns Af = X V0 V' are the same (X V) the backward
-        needs."""
+        singular basis the previous step's sweep left behind (the kernel applies its rotations to V too; identity on the
+        first step) -- when the tokens move little between optimiser steps X V0 has almost orthogonal columns and 3-5
+        sweeps replace 10-11.  The singular values of X V0 are those of X (V0 orthogonal), and the rotated columns
+        Af = X V0 V' are the same (X V) the backward needs."""
         N, H = w.N, self.H
         if not hasattr(w, "er_sigma"):
             f = lambda *s: torch.empty(*s, dtype=torch.float32, device=self.device)     # noqa: E731
@@ -470,9 +470,14 @@ class FusionEngine:
             w.er_coef, w.er_t1, w.er_gout = f(H), f(H, H), f(1)
             w.er_vt = torch.eye(H, dtype=torch.float32, device=self.device)      # V0^T
             w.er_vraw, w.er_vg, w.er_gv, w.er_xw = f(H, H), f(H, H), f(H, H), f(N, H)
-        if self.erank_warm_start:
+        if self.erank_warm_start and ops.erank_fits_warm(N, H):
             ops.gemm(GEMM_NT, w.fused, w.er_vt, w.er_xw, ws=self.ws)            # X V0
-            ops.erank_jacobi(w.er_xw, w.er_sigma, w.er_stats, af_t=w.er_af)
+            ops.erank_jacobi_warm(w.er_xw, w.er_sigma, w.er_stats, w.er_vraw, vt_in=w.er_vt, af_t=w.er_af)
+            # the carried basis is a product of ever more rotations: one Newton-Schulz step per use keeps its departure
+            # from orthogonality at rounding level (V^T <- 1.5 V^T - 0.5 (V^T V) V^T)
+            ops.gemm(GEMM_NT, w.er_vraw, w.er_vraw, w.er_vg, ws=self.ws)
+            ops.gemm(GEMM_NN, w.er_vg, w.er_vraw, w.er_gv, ws=self.ws)
+            ops.erank_vt_polish(w.er_vraw, w.er_gv, w.er_vt)
         else:
             ops.erank_jacobi(w.fused, w.er_sigma, w.er_stats, af_t=w.er_af)
 
@@ -481,13 +486,6 @@ class FusionEngine:
         w.er_gout.fill_(-float(self.erank_weight))
         ops.erank_bwd_coef(w.er_sigma[0], w.er_stats[0], w.er_gout, w.er_coef, max_rank=min(w.N, self.H))
         ops.gemm(GEMM_NN, w.er_af[0], w.fused, w.er_t1, ws=ws)                  # Af^T X = Sigma^2 V^T
-        if self.erank_warm_start:
-            # next step's basis: V^T = Sigma^-2 (Af^T X), then one Newton-Schulz step (rows of small sigma carry an
-            # error ~ eps sigma_max / sigma_k; the polish squares the departure from orthogonality)
-            ops.erank_vt_update(w.er_t1, w.er_sigma[0], w.er_vraw)
-            ops.gemm(GEMM_NT, w.er_vraw, w.er_vraw, w.er_vg, ws=ws)             # V^T V
-            ops.gemm(GEMM_NN, w.er_vg, w.er_vraw, w.er_gv, ws=ws)
-            ops.erank_vt_polish(w.er_vraw, w.er_gv, w.er_vt)
         ops.scale_rows(w.er_t1, w.er_coef)
         ops.gemm(GEMM_TN, w.er_af[0], w.er_t1, w.d_fused2, accumulate=True, ws=ws)
 

@@ -631,12 +631,18 @@ def scale_rows(x, coef):
     check(lib.r3d_scale_rows(_p(x), _ld(x), rows, cols, _p(coef), _stream()), "r3d_scale_rows")
 
 
-def erank_vt_update(t1, sigma, vt, rel_thresh=1e-3):
-    """vt [C, C] <- diag(1 / sigma^2) t1 (warm-start basis V^T), identity when the spectrum is too wide."""
+def erank_fits_warm(R, Cc):
+    return _lib.load().r3d_erank_lds_bytes_v(R, Cc) <= 160 * 1024 - 256
+
+
+def erank_jacobi_warm(x, sigma, stats, vt_out, *, vt_in=None, af_t=None, max_sweeps=30):
+    """x: [R, C] = X V0 (vt_in = V0^T, None: identity); vt_out [C, C] <- (V0 V')^T.  See r3d_erank_jacobi_warm."""
     lib = _lib.load()
-    Cc = vt.shape[0]
-    assert vt.is_contiguous() and vt.shape == (Cc, Cc) and t1.shape == (Cc, Cc)
-    check(lib.r3d_erank_vt_update(_p(t1), _ld(t1), _p(sigma), _p(vt), Cc, rel_thresh, _stream()), "r3d_erank_vt_update")
+    R, Cc = x.shape
+    assert x.stride(1) == 1 and vt_out.is_contiguous() and tuple(vt_out.shape) == (Cc, Cc)
+    assert vt_in is None or (vt_in.is_contiguous() and tuple(vt_in.shape) == (Cc, Cc))
+    check(lib.r3d_erank_jacobi_warm(_p(x), x.stride(0), 0, 1, R, Cc, 0, _p(sigma), _p(af_t), _p(stats), max_sweeps, _p(vt_in),
+                                    _p(vt_out), _stream()), "r3d_erank_jacobi_warm")
 
 
 def erank_vt_polish(vt_raw, gv, vt):

@@ -493,6 +493,39 @@ def test_erank_jacobi_vs_svdvals(ops, R, Cc):
     assert float(off.abs().max()) < 1e-3 * float(sv[0]) ** 2
 
 
+@pytest.mark.parametrize("R,Cc", [(128, 128), (96, 64), (70, 30)])
+def test_erank_jacobi_warm_start(ops, R, Cc):
+    """r3d_erank_jacobi_warm: the right singular basis rides along (X V = rotated columns, V orthogonal), and a nearby
+    matrix decomposed from that basis needs fewer sweeps for the same singular values (vs svdvals)."""
+    from oracle import futr_oracle as O
+    k = min(R, Cc)
+    q1 = torch.linalg.qr(rnd(R, k, seed=R).double())[0]
+    q2 = torch.linalg.qr(rnd(Cc, k, seed=R + 1).double())[0]
+    sv0 = torch.cat([torch.tensor([6.0]), torch.exp(-torch.arange(k - 1, dtype=torch.float64) / (0.3 * k)) + 1e-3])
+    x = (q1 @ torch.diag(sv0) @ q2.t()).float()
+    xd = dev(x)
+    sig, st = torch.empty(1, Cc, device="cuda"), torch.empty(1, 4, device="cuda")
+    aft, vt = torch.empty(1, Cc, R, device="cuda"), torch.empty(Cc, Cc, device="cuda")
+    ops.erank_jacobi_warm(xd, sig, st, vt, af_t=aft)                      # cold: V0 = identity
+    torch.cuda.synchronize()
+    cold = float(st[0, 3])
+    V = vt.double().cpu().t()
+    assert float((V.t() @ V - torch.eye(Cc, dtype=torch.float64)).abs().max()) < 5e-5
+    assert float((x.double() @ V - aft[0].double().cpu().t()).abs().max()) < 2e-4 * float(sv0[0])
+    assert abs(float(st[0, 0]) - O.effective_rank(x)) < 5e-3
+    x2 = x + 2e-4 * float(x.abs().max()) * rnd(R, Cc, seed=7)
+    xw = (dev(x2) @ vt.t()).contiguous()
+    vt2 = torch.empty_like(vt)
+    ops.erank_jacobi_warm(xw, sig, st, vt2, vt_in=vt, af_t=aft)
+    torch.cuda.synchronize()
+    assert float(st[0, 3]) < cold, (float(st[0, 3]), cold)
+    sv = torch.linalg.svdvals(x2.double())
+    assert_close(torch.sort(sig[0].cpu(), descending=True)[0][:k], sv, 1e-4, 2e-4 * float(sv[0]), "sigma (warm)")
+    V2 = vt2.double().cpu().t()
+    assert float((V2.t() @ V2 - torch.eye(Cc, dtype=torch.float64)).abs().max()) < 1e-4
+    assert float((x2.double() @ V2 - aft[0].double().cpu().t()).abs().max()) < 4e-4 * float(sv[0])
+
+
 @pytest.mark.parametrize("R,Cc", [(512, 512), (128, 512), (2048, 256), (300, 200), (64, 40), (2048, 1024), (256, 1024), (130, 70)])
 def test_erank_blocked_vs_svdvals(ops, R, Cc):
     """The two-level Jacobi (columns in HBM) for matrices that exceed one CU's LDS -- and small ones for coverage."""
