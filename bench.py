@@ -262,7 +262,8 @@ def main():
                     help="profiling only: run the step WITH the build-side rank-enhancing penalty (Jacobi forward on the "
                          "fused tokens + two-GEMM backward inside the step); the headline line is always 0 = the "
                          "reference's loss")
-    ap.add_argument("--erank-cold", action="store_true", help="with --erank-weight: no warm start of the Jacobi sweep")
+    ap.add_argument("--erank-warm", action="store_true",
+                    help="with --erank-weight: warm-start the Jacobi sweep from the previous step's singular basis")
     ap.add_argument("--probe-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-probe", action="store_true",
                     help="multi-GPU: skip the child-process rehearsal of the RCCL step (needed under a profiler)")
@@ -310,7 +311,7 @@ def main():
         model.eval()
     eng = model.engine()
     eng.erank_weight = a.erank_weight
-    eng.erank_warm_start = not a.erank_cold
+    eng.erank_warm_start = a.erank_warm
     eng.use_side_stream = a.side_stream
     eng.use_fused_decoder = a.fused_decoder
     eng.defer_tail = not a.separate_tail      # forward -> losses -> backward run back to back: one tail/loss launch
@@ -596,7 +597,7 @@ def main():
             out["config"]["workload"] += f" [{a.variant} fuser variant: profiling only, not the headline model]"
         if a.erank_weight != 0.0:
             out["config"]["workload"] += (f" [with the build-side effective-rank penalty, weight {a.erank_weight}, "
-                                          f"{'cold' if a.erank_cold else 'warm-started'} Jacobi in the step: profiling only]")
+                                          f"{'warm-started' if a.erank_warm else 'cold'} Jacobi in the step: profiling only]")
             out["erank_in_step"] = dict(sweeps=float(eng.last["w"].er_stats[0, 3]), erank=float(eng.last["w"].er_stats[0, 0]))
         if world == 1 and not a.no_cpu_baseline and a.config == "cfg2" and a.variant == "tokenfusion":
             out["cpu_baseline"] = cpu_baseline(c)

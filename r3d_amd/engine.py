@@ -207,7 +207,11 @@ class FusionEngine:
         self.dropout_enabled = bool(getattr(module, "r3d_dropout_enabled", True))
         self.erank_weight = 0.0           # > 0: total loss -= erank_weight * effective_rank(fused token matrix) (build-side
                                           # rank-enhancing penalty; the reference only describes it, README.md:8-14)
-        self.erank_warm_start = True      # Jacobi on X V0 (V0 from the previous step), see _erank_forward
+        # Jacobi on X V0 (V0 = the previous step's right singular basis, carried through the sweep): pays when the tokens
+        # move little between steps (late training: 3-5 sweeps instead of 9-11, each 1.7x dearer with V riding along);
+        # at lr 1e-3 from a random init the tokens move 20-100 % per step and no basis survives (measured: 1.54 vs
+        # 1.27 ms/step at the headline shape), so it is opt-in
+        self.erank_warm_start = False
         self.shapes = {}
         self.train_mask = None            # cached train-mode selection (data independent)
         self.drop_seed = 0x5EED

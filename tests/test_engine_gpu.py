@@ -397,6 +397,7 @@ def test_effective_rank_warm_start(oracle_lib):
     model = build_model(fx).eval()
     eng = model.engine()
     eng.erank_weight = lam
+    eng.erank_warm_start = True
     sweeps = []
     for it in range(4):
         eng.forward(d[0], d[1], d[2], "train", training=False)
