@@ -147,7 +147,7 @@ def pmc_traffic(kernel_label):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE
     in separate runs, gfx950 correction applied: tools/pmc_summary.py -> profiles/r01_pmc_hbm.json).  A profiler cannot
     run inside the timed process, so this is the figure of the committed profile of the same command, or None."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")
+    path = os.path.join(ROOT, "profiles", "r02_pmc_hbm.json")
     key = {"adamw_flat": "adamw_kernel", "depth_projection_wgrad (gemm_f32 TN)": "wgrad_panel_kernel",
            "depth_projection_fwd (gemm_f32 NT split-K)": "gemm_f32_kernel<0, 0, 64, 64, 64, 2, 2, 2, true>"}.get(kernel_label)
     try:
