@@ -84,7 +84,8 @@ def kernel_rooflines(eng, c):
     st, a, w = eng.last, eng.arena, eng.last["w"]
     N, H, P = c["B"] * c["S"], c["H"], c["P"]
     out = {}
-    t = time_kernel(lambda: ops.gemm(GEMM_TN, w.d_dep_pre, st["x_dep"], a.g("depth_projection.weight"), ws=eng.ws))
+    t = time_kernel(lambda: ops.gemm(GEMM_TN, w.d_dep_pre, st["x_dep"], a.g("depth_projection.weight"), ws=eng.ws,
+                                     prec=eng.depth_prec))
     out["depth_projection_wgrad (gemm_f32 TN)"] = dict(seconds=t, flops=2.0 * N * P * H, bytes=4.0 * (N * P + N * H + H * P))
 
     def fwd():

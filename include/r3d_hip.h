@@ -84,6 +84,7 @@ typedef struct r3d_gemm_desc {
     int32_t splitk, k_per_split; float* partial;
     int32_t tile;            /* 0 = auto; workgroup tile: 1 = 32x32 (4 k-split waves), 2 = 64x64, 3 = 128x128,
                                 4 = 64x64 with 2 k-split wave groups, 5 = 128x128 with 2 k-split wave groups,
+                                7 = tile 6 on the bf16 matrix cores (prec == 1),
                                 6 = persistent 64-column panels with A^T resident in registers (TN, K <= 128, M <= 128,
                                     plain epilogue: the weight gradient of a wide layer from few rows) */
     int32_t vec;             /* filled by the library: operands allow 16-byte loads */
@@ -94,6 +95,11 @@ typedef struct r3d_gemm_desc {
      * gradient's write and re-read and one pass over the parameter: depth_projection.weight is 86 % of the model. */
     float* adam_m; float* adam_v; const float* adam_lr; const int64_t* adam_step;
     float adam_beta1, adam_beta2, adam_eps, adam_wd, adam_gscale;
+    int32_t prec;            /* 0: v_mfma_f32_32x32x2_f32 (an exact fp32 fma chain).  1: the kernels that have one may take the
+                                 bf16x3 path: every fp32 operand split EXACTLY into three bf16 terms, the six leading
+                                 products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (error per product <= 3 * 2^-24,
+                                 the size of an fp32 rounding; 2.7x less matrix-core time).  Today: tile 7 = tile 6's
+                                 persistent weight-gradient panels, chosen by r3d_gemm_plan when prec == 1 */
 } r3d_gemm_desc;
 
 int r3d_gemm_f32(const r3d_gemm_desc* d, void* stream);

@@ -34,6 +34,7 @@ class GemmDesc(C.Structure):
         ("adam_m", C.c_void_p), ("adam_v", C.c_void_p), ("adam_lr", C.c_void_p), ("adam_step", C.c_void_p),
         ("adam_beta1", C.c_float), ("adam_beta2", C.c_float), ("adam_eps", C.c_float), ("adam_wd", C.c_float),
         ("adam_gscale", C.c_float),
+        ("prec", C.c_int32),
     ]
 
 

@@ -201,6 +201,9 @@ class FusionEngine:
         # of forward() are valid only after losses() in that mode
         self.defer_tail = False
         self.use_paired_launches = True          # one-layer decoder: independent GEMMs of the two chains share launches
+        # the two depth-projection GEMMs (83 % of the step's FLOPs) on the bf16 matrix cores through an exact three-way
+        # operand split (csrc/gemm_bf3.hip; error per product <= 3 * 2^-24); 0 = the fp32 MFMA everywhere
+        self.depth_prec = 1
         self.use_fused_embed = not self.bn       # train mode: projections' slab sums + LN + exchange + norm1 in one launch
         # False: train()-state steps without dropout (parity runs against a reference whose dropout probabilities were
         # set to 0; RNG streams cannot match).  Read from the module so that it survives model.to() re-creating the engine.
@@ -698,7 +701,8 @@ class FusionEngine:
             ops.gemm(GEMM_TN, st["w"].d_dep_pre, st["x_dep"], a.p("depth_projection.weight"), ws=self.ws,
                      adam=dict(adam, m=a.exp_avg[o:o + n].view(shp), v=a.exp_avg_sq[o:o + n].view(shp)))
             return
-        ops.gemm(GEMM_TN, st["w"].d_dep_pre, st["x_dep"], self.arena.g("depth_projection.weight"), ws=self.ws)
+        ops.gemm(GEMM_TN, st["w"].d_dep_pre, st["x_dep"], self.arena.g("depth_projection.weight"), ws=self.ws,
+                 prec=self.depth_prec)
 
     def _build_groups(self, w):
         """Once per shape: every weight gradient whose operands live in the persistent workspace becomes one problem of

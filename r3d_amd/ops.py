@@ -54,7 +54,7 @@ class GemmWorkspace:
 
 def _fill_desc(d, layout, a, b, c, *, bias=None, act=0, pre_out=None, a_add=None, a_add_mod=0, a_row_xor=0, b_add=None,
                b_add_mod=0, drop_mask=None, drop_scale=1.0, aux=None, mul=0, res1=None, res2=None, alpha=1.0,
-               accumulate=False, c_row_xor=0, bias_grad=None):
+               accumulate=False, c_row_xor=0, bias_grad=None, prec=0):
     """Fills the problem and epilogue fields of a GemmDesc (not tile / split).  Returns (M, N, K)."""
     _f32(a, "A"), _f32(b, "B"), _f32(c, "C")
     if layout == GEMM_NT:
@@ -95,6 +95,7 @@ def _fill_desc(d, layout, a, b, c, *, bias=None, act=0, pre_out=None, a_add=None
     if res2 is not None:
         d.res2, d.ldr2 = res2.data_ptr(), _ld(res2)
     d.alpha, d.accumulate = alpha, 1 if accumulate else 0
+    d.prec = prec
     d.c_row_xor = c_row_xor
     if bias_grad is not None:
         assert layout == GEMM_TN and bias_grad.numel() == M

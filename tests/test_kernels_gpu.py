@@ -473,6 +473,36 @@ def test_dropout_mask_statistics(ops):
 
 
 # ----------------------------------------------------------------------------------------------------------
+# bf16x3 matrix-core path (r3d_gemm_desc::prec = 1)
+# ----------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("K,M,N", [(128, 128, 50176), (128, 128, 19200), (100, 96, 4100), (37, 128, 2048), (128, 40, 6272)])
+def test_gemm_bf16x3_weight_gradient_panels(ops, K, M, N):
+    """TN weight-gradient panels on the bf16 matrix cores: every operand split exactly into three bf16 terms, six products.
+    Against an fp64 product: the error must be of fp32-rounding size (the fp32 MFMA path's own error is measured beside
+    it), far inside the 1e-3 budget of BASELINE.json."""
+    from r3d_amd._lib import GEMM_TN
+    a = rnd(K, M, seed=K + M) * 0.05
+    b = torch.rand(K, N, generator=torch.Generator().manual_seed(N))          # depth-like inputs in [0, 1)
+    want = a.double().t() @ b.double()
+    scale = float(want.abs().max())
+    c1, c0 = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
+    ws = ops.GemmWorkspace("cuda")
+    d1 = ops.gemm(GEMM_TN, dev(a), dev(b), c1, ws=ws, prec=1)
+    d0 = ops.gemm(GEMM_TN, dev(a), dev(b), c0, ws=ws, prec=0)
+    torch.cuda.synchronize()
+    assert d1.tile == 7 and d0.tile == 6
+    e1 = float((c1.cpu().double() - want).abs().max()) / scale
+    e0 = float((c0.cpu().double() - want).abs().max()) / scale
+    assert e1 < 2e-6 and e1 < 4 * e0 + 2e-7, (e1, e0)
+    # alpha and a strided output
+    big = torch.zeros(M, N + 8, device="cuda")
+    ops.gemm(GEMM_TN, dev(a), dev(b), big[:, :N], ws=ws, prec=1, alpha=0.5)
+    torch.cuda.synchronize()
+    assert float((big[:, :N].cpu().double() - 0.5 * want).abs().max()) / scale < 2e-6
+    assert float(big[:, N:].abs().max()) == 0.0
+
+
+# ----------------------------------------------------------------------------------------------------------
 # effective rank
 # ----------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("R,Cc", [(128, 128), (40, 24), (256, 128), (33, 64), (64, 512), (1024, 32), (16, 16), (127, 129)])
