@@ -89,7 +89,8 @@ def kernel_rooflines(eng, c):
     out["depth_projection_wgrad (gemm_f32 TN)"] = dict(seconds=t, flops=2.0 * N * P * H, bytes=4.0 * (N * P + N * H + H * P))
 
     def fwd():
-        d = ops.gemm(GEMM_NT, st["x_dep"], a.p("depth_projection.weight"), w.dep_pre, ws=eng.ws, defer_reduce=True)
+        d = ops.gemm(GEMM_NT, st["x_dep"], a.p("depth_projection.weight"), w.dep_pre, ws=eng.ws, defer_reduce=True,
+                     prec=eng.depth_prec)
         return d
     t = time_kernel(fwd)
     out["depth_projection_fwd (gemm_f32 NT split-K)"] = dict(seconds=t, flops=2.0 * N * P * H, bytes=4.0 * (N * P + H * P + N * H))

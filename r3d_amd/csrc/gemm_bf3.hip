@@ -16,16 +16,30 @@ namespace r3d {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// bf16 bit patterns of the three terms, each in the HIGH 16 bits of a dword (low bits zero)
-__device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
-    h = __builtin_bit_cast(unsigned, x) & 0xffff0000u;
-    const float r1 = x - __builtin_bit_cast(float, h);
-    m = __builtin_bit_cast(unsigned, r1) & 0xffff0000u;
-    const float r2 = r1 - __builtin_bit_cast(float, m);
-    l = __builtin_bit_cast(unsigned, r2) & 0xffff0000u;
+// Two consecutive-k values -> the three bf16 terms of each, already packed (element k in the low half of the dword:
+// little-endian vector order).  v_cvt_pk_bf16_f32 rounds to nearest even and packs the pair in ONE instruction; the
+// residuals x - h and (x - h) - m are exact in fp32 (8 + 8 of the 24 mantissa bits are gone each time), the last term
+// rounds the remaining <= 9 bits to 8 (error <= 2^-26 |x|).  4.5 VALU instructions per element including the packing.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    const f32x2_t x = {x0, x1};
+    const bf16x2_t hb = __builtin_convertvector(x, bf16x2_t);
+    const f32x2_t r1 = x - __builtin_convertvector(hb, f32x2_t);
+    const bf16x2_t mb = __builtin_convertvector(r1, bf16x2_t);
+    const f32x2_t r2 = r1 - __builtin_convertvector(mb, f32x2_t);
+    const bf16x2_t lb = __builtin_convertvector(r2, bf16x2_t);
+    h = __builtin_bit_cast(unsigned, hb);
+    m = __builtin_bit_cast(unsigned, mb);
+    l = __builtin_bit_cast(unsigned, lb);
 }
-// two consecutive-k terms -> one dword (element k in the low half: little-endian vector order)
-__device__ __forceinline__ unsigned pack2(unsigned lo_k, unsigned hi_k) { return (lo_k >> 16) | hi_k; }
+// eight consecutive-k values -> one 16-byte MFMA operand per plane
+__device__ __forceinline__ void split3_oct(const float* v, uint4& h, uint4& m, uint4& l) {
+    split3_pair(v[0], v[1], h.x, m.x, l.x);
+    split3_pair(v[2], v[3], h.y, m.y, l.y);
+    split3_pair(v[4], v[5], h.z, m.z, l.z);
+    split3_pair(v[6], v[7], h.w, m.w, l.w);
+}
 
 __device__ __forceinline__ f32x16 mfma_bf3(const uint4 ah, const uint4 am, const uint4 al, const uint4 bh, const uint4 bm,
                                             const uint4 bl, f32x16 acc) {
@@ -97,15 +111,13 @@ __global__ __launch_bounds__(512, 1) void wgrad_panel_bf3_kernel(const r3d_gemm_
             }
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
-                unsigned h[8], m[8], l[8];
+                float v[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int k = 16 * s + 8 * lhi + j;
-                    split3((k < K && m_ok) ? d.alpha * araw[8 * s + j] : 0.f, h[j], m[j], l[j]);
+                    v[j] = (k < K && m_ok) ? d.alpha * araw[8 * s + j] : 0.f;
                 }
-                a_h[s] = make_uint4(pack2(h[0], h[1]), pack2(h[2], h[3]), pack2(h[4], h[5]), pack2(h[6], h[7]));
-                a_m[s] = make_uint4(pack2(m[0], m[1]), pack2(m[2], m[3]), pack2(m[4], m[5]), pack2(m[6], m[7]));
-                a_l[s] = make_uint4(pack2(l[0], l[1]), pack2(l[2], l[3]), pack2(l[4], l[5]), pack2(l[6], l[7]));
+                split3_oct(v, a_h[s], a_m[s], a_l[s]);
             }
         }
         __syncthreads();                                            // B3
@@ -186,19 +198,22 @@ __global__ __launch_bounds__(512, 1) void wgrad_panel_bf3_kernel(const r3d_gemm_
                 const int chunk = (k0 >> 2) ^ ((c4 >> 2) << 1);     // 8-byte chunk index, swizzled by (n >> 4) & 3
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    unsigned h[4], m[4], l[4];
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) split3(v[c][t], h[t], m[t], l[t]);
+                    uint2 h, m, l;
+                    split3_pair(v[c][0], v[c][1], h.x, m.x, l.x);
+                    split3_pair(v[c][2], v[c][3], h.y, m.y, l.y);
                     unsigned short* row = img + (size_t)(4 * c4 + c) * kP3S + 4 * chunk;
-                    *reinterpret_cast<uint2*>(row) = make_uint2(pack2(h[0], h[1]), pack2(h[2], h[3]));
-                    *reinterpret_cast<uint2*>(row + kP3Plane) = make_uint2(pack2(m[0], m[1]), pack2(m[2], m[3]));
-                    *reinterpret_cast<uint2*>(row + 2 * kP3Plane) = make_uint2(pack2(l[0], l[1]), pack2(l[2], l[3]));
+                    *reinterpret_cast<uint2*>(row) = h;
+                    *reinterpret_cast<uint2*>(row + kP3Plane) = m;
+                    *reinterpret_cast<uint2*>(row + 2 * kP3Plane) = l;
                 }
             }
         };
+        // (every load is unconditional, turn indices clamped: a load under a branch makes hipcc wait vmcnt(0) at the next
+        //  use, which exposes the round trip of the loads issued one turn earlier)
+        const int lastt = nturn - 1;
         load_panel(st0, 0);                                         // the first loads go out before anything else
-        if (1 < nturn) load_panel(st1, 1);
-        if (2 < nturn) load_panel(st2, 2);
+        load_panel(st1, min(1, lastt));
+        load_panel(st2, min(2, lastt));
         store_panel(img0, st0, 0);
         __syncthreads();                                            // B3
         // C tile of the previous turn: LDS -> memory, 128 rows x 256 bytes, 8 float4 per thread
@@ -216,7 +231,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_panel_bf3_kernel(const r3d_gemm_
         auto turn = [&](int p, unsigned short* oth, float4* nxt, float4* mine) {
             if (p > 0) drain_c(p - 1);
             if (p + 1 < nturn) store_panel(oth, nxt, p + 1);
-            if (p + 3 < nturn) load_panel(mine, p + 3);
+            load_panel(mine, min(p + 3, lastt));
             __syncthreads();                                        // mid-turn
             __syncthreads();
         };
@@ -231,6 +246,213 @@ __global__ __launch_bounds__(512, 1) void wgrad_panel_bf3_kernel(const r3d_gemm_
         drain_c(nturn - 1);
         __syncthreads();
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Split-K NT product  C_partial[split][M][N] = A[M, k-range] . B[N, k-range]^T  on the bf16 matrix cores: the forward depth
+// projection (model/futr_safuser_tokenfusion.py:194-195: [B S, 50176] x [H, 50176]^T).  Both operands are K-contiguous,
+// which is what the bf16 MFMA wants (8 consecutive k per lane): a producer thread loads 8 consecutive fp32 of one row
+// (two float4), splits them and writes three 16-byte bf16x8 fragments into [row][k] images of row stride BK + 8 bf16
+// (conflict-free for the 16-byte reads of 16 consecutive rows and for the producers' stores).
+// Workgroup = 512 threads: waves 0-3 consume (a 2 x 2 arrangement over the BM x BN tile, TM x TN MFMA tiles each; with a
+// single tile per wave the even and odd k-steps go to two accumulators so that two dependent MFMA chains alternate),
+// waves 4-7 produce (two register stages of loads in flight, LDS images double-buffered, one barrier per k-step).
+// Output: raw fp32 slabs exactly as gemm_f32_kernel leaves them for split-K (the caller's reducer applies bias / LayerNorm /
+// the epilogue), placed XCD-aware (the tiles of one K-split share linear id mod 8).
+// ---------------------------------------------------------------------------------------------------------
+template <int BM, int BN, int BK>
+__global__ __launch_bounds__(512, 1) void gemm_bf3_nt_kernel(const r3d_gemm_desc d, const int G, const int NG) {
+    constexpr int S = BK + 8;                                  // bf16 per image row
+    constexpr int OPR = BK / 8;                                // octets per row
+    constexpr int PLANE_A = BM * S, PLANE_B = BN * S;
+    constexpr int STAGE = 3 * (PLANE_A + PLANE_B);             // bf16 elements per LDS stage
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int NKS = BK / 16;
+    constexpr bool TWO = (TM * TN == 1);                       // one tile per wave: split the k-steps over two chains
+    constexpr int NOCT = (BM + BN) * OPR / 256;                // octets per producer thread and stage
+    static_assert((BM + BN) * OPR % 256 == 0, "producer mapping");
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds16[];     // [2 stages][A planes | B planes]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    // XCD-aware placement (see gemm_f32_kernel): group g = one K-split goes to XCD g % 8, its G tiles sit at stride 8
+    const int p = blockIdx.x, idx = p >> 3;
+    const int split = (idx / G) * 8 + (p & 7), tile = idx % G;
+    if (split >= NG) return;
+    const int tiles_n = (d.N + BN - 1) / BN;
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    const int k_begin = split * d.k_per_split;
+    const int k_end = min(d.K, k_begin + d.k_per_split);
+    const int nk = (k_end - k_begin + BK - 1) / BK;
+    if (wave < 4) {
+        // ================================= consumers =================================
+        const int wm = wave >> 1, wn = wave & 1;
+        f32x16 acc[TM][TN][TWO ? 2 : 1];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int c = 0; c < (TWO ? 2 : 1); ++c)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][c][r] = 0.f;
+        __syncthreads();                                            // stage 0 written
+        for (int kt = 0; kt < nk; ++kt) {
+            const unsigned short* img = lds16 + (kt & 1) * STAGE;
+            const unsigned short* ia = img + (size_t)(wm * (BM / 2) + l31) * S + 8 * lhi;
+            const unsigned short* ib = img + 3 * PLANE_A + (size_t)(wn * (BN / 2) + l31) * S + 8 * lhi;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                uint4 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const unsigned short* q = ia + (size_t)i * 32 * S + 16 * ks;
+                    ah[i] = *reinterpret_cast<const uint4*>(q);
+                    am[i] = *reinterpret_cast<const uint4*>(q + PLANE_A);
+                    al[i] = *reinterpret_cast<const uint4*>(q + 2 * PLANE_A);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const unsigned short* q = ib + (size_t)j * 32 * S + 16 * ks;
+                    bh[j] = *reinterpret_cast<const uint4*>(q);
+                    bm[j] = *reinterpret_cast<const uint4*>(q + PLANE_B);
+                    bl[j] = *reinterpret_cast<const uint4*>(q + 2 * PLANE_B);
+                }
+                const int c = TWO ? (ks & 1) : 0;
+#define R3D_BF(x) __builtin_bit_cast(bf16x8, x)
+#define R3D_TERM(A_, B_)                                                                                                   \
+                _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)               \
+                    acc[i][j][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(R3D_BF(A_[i]), R3D_BF(B_[j]), acc[i][j][c], 0, 0, 0);
+                R3D_TERM(ah, bl)                                    // small terms first; tiles alternate inside a term
+                R3D_TERM(al, bh)
+                R3D_TERM(am, bm)
+                R3D_TERM(ah, bm)
+                R3D_TERM(am, bh)
+                R3D_TERM(ah, bh)
+#undef R3D_TERM
+#undef R3D_BF
+            }
+            __syncthreads();
+        }
+        // raw partial sums -> slab `split` (C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * (BN / 2) + j * 32 + l31;
+                if (n >= d.N) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    float v = acc[i][j][0][r];
+                    if (TWO) v += acc[i][j][TWO ? 1 : 0][r];
+                    if (m < d.M) d.partial[((size_t)split * d.M + m) * d.N + n] = v;
+                }
+            }
+    } else {
+        // ================================= producers =================================
+        const int pt = tid - 256;
+        // Per-thread row pointers, fixed for the whole k-loop (the descriptor fields are read ONCE here: selecting
+        // between d.A and d.B per lane inside the loop turned them into vector-memory loads of the kernel arguments,
+        // whose vmcnt waits serialised with the tile prefetches -- seen in the ISA).
+        const float* rowp[NOCT];
+        bool rok[NOCT];
+#pragma unroll
+        for (int t = 0; t < NOCT; ++t) {
+            const int e = pt + 256 * t, row = e / OPR;
+            const bool isa = row < BM;                               // (compile-time per t when 256 * t is a multiple of BM * OPR)
+            const int gr = isa ? m0 + row : n0 + (row - BM);
+            const int lim = isa ? d.M : d.N;
+            rok[t] = gr < lim;
+            const size_t off = (size_t)(rok[t] ? gr : 0) * (size_t)(isa ? d.lda : d.ldb);
+            rowp[t] = (isa ? d.A : d.B) + off + 8 * (e % OPR);
+        }
+        const int Kt = d.K;
+        float4 s0[2 * NOCT], s1[2 * NOCT];
+        auto load_stage = [&](float4* reg, int kt) {
+            const int k0 = k_begin + kt * BK;
+#pragma unroll
+            for (int t = 0; t < NOCT; ++t) {
+                const int o8 = 8 * ((pt + 256 * t) % OPR);
+                const int k = k0 + o8;
+                const int kc = k + 8 <= Kt ? k : Kt - 8;            // K % 8 == 0 (validated): an octet is all-in or all-out
+                const float* src = rowp[t] + (kc - o8);
+                reg[2 * t] = *reinterpret_cast<const float4*>(src);
+                reg[2 * t + 1] = *reinterpret_cast<const float4*>(src + 4);
+            }
+        };
+        auto store_stage = [&](unsigned short* img, const float4* reg, int kt) {
+            const int k0 = k_begin + kt * BK;
+#pragma unroll
+            for (int t = 0; t < NOCT; ++t) {
+                const int e = pt + 256 * t, row = e / OPR, o = e % OPR;
+                const bool isa = row < BM;
+                const bool ok = rok[t] && (k0 + 8 * o < k_end);
+                const float4 x = reg[2 * t], y = reg[2 * t + 1];
+                float v[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
+                if (!ok) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = 0.f;
+                }
+                uint4 h, m, l;
+                split3_oct(v, h, m, l);
+                unsigned short* dst = img + (isa ? (size_t)row * S : (size_t)3 * PLANE_A + (size_t)(row - BM) * S) + 8 * o;
+                const int plane = isa ? PLANE_A : PLANE_B;
+                *reinterpret_cast<uint4*>(dst) = h;
+                *reinterpret_cast<uint4*>(dst + plane) = m;
+                *reinterpret_cast<uint4*>(dst + 2 * plane) = l;
+            }
+        };
+        // Every load below is UNCONDITIONAL (tile indices are clamped: a surplus load re-reads the last tile and its image
+        // is never consumed): a load under a branch makes hipcc wait vmcnt(0) at the next use, i.e. for the loads issued
+        // one step earlier as well -- measured 1.8 us per k-step (one HBM round trip) instead of 0.7.
+        const int last = nk - 1;
+        load_stage(s0, 0);
+        load_stage(s1, min(1, last));
+        store_stage(lds16, s0, 0);
+        load_stage(s0, min(2, last));
+        __syncthreads();                                            // stage 0 written
+        // step kt: tile kt + 1 (register stage) -> the other image; refill that register stage with tile kt + 3
+        for (int kt = 0; kt < nk; kt += 2) {
+            store_stage(lds16 + STAGE, s1, min(kt + 1, last));
+            load_stage(s1, min(kt + 3, last));
+            __syncthreads();
+            if (kt + 1 < nk) {
+                store_stage(lds16, s0, min(kt + 2, last));
+                load_stage(s0, min(kt + 4, last));
+                __syncthreads();
+            }
+        }
+    }
+}
+
+bool gemm_bf3_nt_ok(const r3d_gemm_desc& d) {
+    if (d.layout != R3D_GEMM_NT || d.splitk <= 1 || !d.partial) return false;
+    if ((d.K & 7) || (d.lda & 3) || (d.ldb & 3) || (d.k_per_split & 63) || d.K < 64) return false;
+    if (d.a_add || d.a_row_xor || d.adam_m || d.alpha != 1.0f) return false;
+    return r3d_aligned16(d.A) && r3d_aligned16(d.B);
+}
+
+template <int BM, int BN, int BK>
+static int launch_bf3_nt_cfg(const r3d_gemm_desc& d, hipStream_t s) {
+    const int tiles = r3d_cdiv(d.M, BM) * r3d_cdiv(d.N, BN);
+    const int ns = r3d_cdiv(d.K, d.k_per_split);
+    const size_t lds = (size_t)2 * 3 * (BM + BN) * (BK + 8) * sizeof(unsigned short);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf3_nt_kernel<BM, BN, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_bf3_nt_kernel<BM, BN, BK>), dim3(8 * tiles * r3d_cdiv(ns, 8)), dim3(512), lds, s, d, tiles, ns);
+    R3D_LAUNCH_CHECK();
+    return R3D_OK;
+}
+
+int launch_gemm_bf3_nt(const r3d_gemm_desc& d, hipStream_t s) {
+    if (!gemm_bf3_nt_ok(d)) return R3D_EINVAL;
+    if (d.tile == 8) return launch_bf3_nt_cfg<64, 64, 64>(d, s);
+    if (d.tile == 9) return launch_bf3_nt_cfg<128, 128, 32>(d, s);
+    return R3D_EINVAL;
 }
 
 int launch_wgrad_panel_bf3(const r3d_gemm_desc& d, hipStream_t s) {

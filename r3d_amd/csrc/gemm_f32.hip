@@ -718,6 +718,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_panel_kernel(const r3d_gemm_desc
 }
 
 int launch_wgrad_panel_bf3(const r3d_gemm_desc& d, hipStream_t s);         // gemm_bf3.hip
+int launch_gemm_bf3_nt(const r3d_gemm_desc& d, hipStream_t s);
+bool gemm_bf3_nt_ok(const r3d_gemm_desc& d);
 
 static bool wgrad_panel_ok(const r3d_gemm_desc& d) {
     if (d.layout != R3D_GEMM_TN || d.K > 128 || d.M > 128 || d.N < 2048 || (d.N & 3) || (d.ldb & 3)) return false;
@@ -729,7 +731,7 @@ static bool wgrad_panel_ok(const r3d_gemm_desc& d) {
 // ---------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------
-static const int kTileSz[8] = {0, 32, 64, 128, 64, 128, 64, 64};
+static const int kTileSz[10] = {0, 32, 64, 128, 64, 128, 64, 64, 64, 128};
 
 template <int LA, int LB, int BM, int BN, int BK, int WM, int WN, int WK>
 static int launch_cfg(const r3d_gemm_desc& d, int nsplit, hipStream_t s) {
@@ -792,7 +794,7 @@ static int gemm_validate(const r3d_gemm_desc* d) {
     if (!d || !d->A || !d->B || !d->C) return R3D_EINVAL;
     if (d->M <= 0 || d->N <= 0 || d->K <= 0) return R3D_EINVAL;
     if (d->layout < 0 || d->layout > 2) return R3D_EINVAL;
-    if (d->tile < 1 || d->tile > 7) return R3D_EINVAL;
+    if (d->tile < 1 || d->tile > 9) return R3D_EINVAL;
     const int a_min = (d->layout == R3D_GEMM_TN) ? d->M : d->K;
     const int b_min = (d->layout == R3D_GEMM_NT) ? d->K : d->N;
     if (d->lda < a_min || d->ldb < b_min || d->ldc < d->N) return R3D_EINVAL;
@@ -868,6 +870,20 @@ R3D_EXPORT int r3d_gemm_plan(r3d_gemm_desc* d) {
     d->tile = bt;
     d->splitk = bs;
     d->k_per_split = (bs > 1) ? bk : d->K;
+    if (d->prec == 1 && d->layout == R3D_GEMM_NT && d->K >= 8192 && (d->K & 7) == 0 && !d->a_add && !d->a_row_xor &&
+        d->alpha == 1.0f && (d->lda & 3) == 0 && (d->ldb & 3) == 0 && r3d_aligned16(d->A) && r3d_aligned16(d->B)) {
+        // long-K NT product on the bf16 matrix cores (gemm_bf3.hip): 64 x 64 tiles while they are few, 128 x 128 beyond;
+        // as many K-splits as fill the chip once (one workgroup per CU), each a multiple of 64 deep
+        const long t64 = (long)r3d_cdiv(d->M, 64) * r3d_cdiv(d->N, 64);
+        const int tl = t64 <= 16 ? 8 : 9;
+        const long tiles = tl == 8 ? t64 : (long)r3d_cdiv(d->M, 128) * r3d_cdiv(d->N, 128);
+        int ns = (int)(256 / (tiles < 256 ? tiles : 256));
+        if (ns < 2) ns = 2;
+        int kps = r3d_cdiv(r3d_cdiv(d->K, ns), 64) * 64;
+        if (kps < 256) kps = 256;
+        ns = r3d_cdiv(d->K, kps);
+        if (ns >= 2) { d->tile = tl; d->splitk = ns; d->k_per_split = kps; return R3D_OK; }
+    }
     {                                    // few-row weight gradient of a wide layer: the persistent panel kernel
         r3d_gemm_desc t = *d;
         t.splitk = 1;
@@ -886,6 +902,7 @@ R3D_EXPORT int r3d_gemm_f32(const r3d_gemm_desc* dp, void* stream) {
     d.vec = gemm_can_vec(d) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     const int ns = nsplits_of(d);
+    if (d.tile == 8 || d.tile == 9) return launch_gemm_bf3_nt(d, s);          // long-K NT split-K on the bf16 matrix cores
     if (d.tile == 7) {                   // the same panel kernel on the bf16 matrix cores (exact 3-way operand split)
         if (!wgrad_panel_ok(d) || (d.ldc & 3) || !r3d_aligned16(d.C)) return R3D_EINVAL;
         return launch_wgrad_panel_bf3(d, s);

@@ -300,7 +300,7 @@ class FusionEngine:
         d = None
         if tp is None:
             d = ops.gemm(GEMM_NT, x_dep, a.p("depth_projection.weight"), w.dep_pre, bias=a.p("depth_projection.bias"),
-                         ws=self.ws, defer_reduce=True)                          # (:194-195)
+                         ws=self.ws, defer_reduce=True, prec=self.depth_prec)    # (:194-195)
         else:
             tp.partial_forward(w, x_dep, self.ws)
         # the split-K slabs of the depth GEMM are consumed by the LayerNorm launch in forward_finish(): keep THIS buffer

@@ -502,6 +502,28 @@ def test_gemm_bf16x3_weight_gradient_panels(ops, K, M, N):
     assert float(big[:, N:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("M,N,K", [(128, 128, 50176), (128, 128, 19200), (512, 512, 50176), (100, 96, 8200), (256, 1024, 16384),
+                                   (8, 40, 8192)])
+def test_gemm_bf16x3_long_k_projection(ops, M, N, K):
+    """NT split-K product on the bf16 matrix cores (tiles 8 / 9: the forward depth projection) with the reducer's epilogue
+    (bias + ReLU) against an fp64 product; the fp32 MFMA path's own error is measured beside it."""
+    from r3d_amd._lib import GEMM_NT
+    a = torch.rand(M, K, generator=torch.Generator().manual_seed(M))             # depth-like inputs in [0, 1)
+    b = rnd(N, K, seed=N) * (3.0 / K) ** 0.5
+    bias = rnd(N, seed=3) * 0.1
+    want = torch.relu(a.double() @ b.double().t() + bias.double())
+    scale = float(want.abs().max())
+    c1, c0 = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
+    ws = ops.GemmWorkspace("cuda")
+    d1 = ops.gemm(GEMM_NT, dev(a), dev(b), c1, ws=ws, prec=1, bias=dev(bias), act=1)
+    d0 = ops.gemm(GEMM_NT, dev(a), dev(b), c0, ws=ws, prec=0, bias=dev(bias), act=1)
+    torch.cuda.synchronize()
+    assert d1.tile in (8, 9) and d0.tile <= 5, (d1.tile, d0.tile)
+    e1 = float((c1.cpu().double() - want).abs().max()) / scale
+    e0 = float((c0.cpu().double() - want).abs().max()) / scale
+    assert e1 < 3e-6 and e1 < 4 * e0 + 3e-7, (e1, e0)
+
+
 # ----------------------------------------------------------------------------------------------------------
 # effective rank
 # ----------------------------------------------------------------------------------------------------------
