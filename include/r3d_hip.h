@@ -84,6 +84,8 @@ typedef struct r3d_gemm_desc {
     int32_t splitk, k_per_split; float* partial;
     int32_t tile;            /* 0 = auto; workgroup tile: 1 = 32x32 (4 k-split waves), 2 = 64x64, 3 = 128x128,
                                 4 = 64x64 with 2 k-split wave groups, 5 = 128x128 with 2 k-split wave groups,
+                                10 = TN product with 128 x 128 tiles on the bf16 matrix cores (prec == 1; M, N, lda, ldb % 4 == 0,
+                                    alpha / accumulate epilogue only: the depth weight gradient beyond tile 7's limits),
                                 8 / 9 = split-K NT product with 64 x 64 / 128 x 128 tiles on the bf16 matrix cores (prec == 1,
                                     K % 8 == 0, 16-byte aligned K-contiguous operands, no prologue: the forward depth projection),
                                 7 = tile 6 on the bf16 matrix cores (prec == 1),

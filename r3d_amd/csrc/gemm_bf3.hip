@@ -455,6 +455,178 @@ int launch_gemm_bf3_nt(const r3d_gemm_desc& d, hipStream_t s) {
     return R3D_EINVAL;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// TN product  C[M, N] = alpha A[K, M]^T . B[K, N] (+ C)  on the bf16 matrix cores for the weight gradient of the depth
+// projection when there are more rows than the persistent panel kernel holds in registers (K > 128 tokens or M > 128
+// hidden units: BASELINE configs[2..4]).  128 x 128 output tiles, 32 k per step, the same consumer / producer split as
+// gemm_bf3_nt_kernel; both operands are M / N-contiguous, so a producer thread loads an 8 (k) x 4 (m or n) block, splits
+// it and writes four k-octets (one per column, three planes each) into [m or n][k] images of row stride 40 bf16, the
+// octet position XOR-swizzled by (row >> 4) & 3 (conflict-free stores and operand reads).
+// Placement: the tiles of one N panel (they share the B operand) get equal linear id mod 8, i.e. one XCD's L2.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 1) void gemm_bf3_tn_kernel(const r3d_gemm_desc d, const int G, const int NG) {
+    constexpr int BM = 128, BN = 128, BK = 32, S = BK + 8;
+    constexpr int PLANE = BM * S;                               // BM == BN: same plane size for both operands
+    constexpr int STAGE = 6 * PLANE;
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds16[];     // [2 stages][A planes | B planes]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int p = blockIdx.x, idx = p >> 3;
+    const int tn = (idx / G) * 8 + (p & 7), tm = idx % G;
+    if (tn >= NG) return;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int K = d.K, M = d.M, N = d.N;
+    const int nk = (K + BK - 1) / BK;
+    if (wave < 4) {
+        // ================================= consumers: wave quadrant 64 x 64 = 2 x 2 MFMA tiles, four chains =============
+        const int wm = wave >> 1, wn = wave & 1;
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        const int ra = wm * 64 + l31, rb = wn * 64 + l31;       // rows of tile i = 0 / j = 0; i, j = 1: + 32
+        const int xa0 = (ra >> 4) & 3, xa1 = ((ra + 32) >> 4) & 3, xb0 = (rb >> 4) & 3, xb1 = ((rb + 32) >> 4) & 3;
+        __syncthreads();                                            // stage 0 written
+        for (int kt = 0; kt < nk; ++kt) {
+            const unsigned short* ia = lds16 + (kt & 1) * STAGE;
+            const unsigned short* ib = ia + 3 * PLANE;
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                const int o = 2 * ks + lhi;
+                uint4 ah[2], am[2], al[2], bh[2], bm[2], bl[2];
+                const unsigned short* qa0 = ia + (size_t)ra * S + 8 * (o ^ xa0);
+                const unsigned short* qa1 = ia + (size_t)(ra + 32) * S + 8 * (o ^ xa1);
+                const unsigned short* qb0 = ib + (size_t)rb * S + 8 * (o ^ xb0);
+                const unsigned short* qb1 = ib + (size_t)(rb + 32) * S + 8 * (o ^ xb1);
+                ah[0] = *reinterpret_cast<const uint4*>(qa0); am[0] = *reinterpret_cast<const uint4*>(qa0 + PLANE);
+                al[0] = *reinterpret_cast<const uint4*>(qa0 + 2 * PLANE);
+                ah[1] = *reinterpret_cast<const uint4*>(qa1); am[1] = *reinterpret_cast<const uint4*>(qa1 + PLANE);
+                al[1] = *reinterpret_cast<const uint4*>(qa1 + 2 * PLANE);
+                bh[0] = *reinterpret_cast<const uint4*>(qb0); bm[0] = *reinterpret_cast<const uint4*>(qb0 + PLANE);
+                bl[0] = *reinterpret_cast<const uint4*>(qb0 + 2 * PLANE);
+                bh[1] = *reinterpret_cast<const uint4*>(qb1); bm[1] = *reinterpret_cast<const uint4*>(qb1 + PLANE);
+                bl[1] = *reinterpret_cast<const uint4*>(qb1 + 2 * PLANE);
+#define R3D_BF(x) __builtin_bit_cast(bf16x8, x)
+#define R3D_TERM(A_, B_)                                                                                                   \
+                _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                 \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(R3D_BF(A_[i]), R3D_BF(B_[j]), acc[i][j], 0, 0, 0);
+                R3D_TERM(ah, bl)                                    // small terms first; the four tiles alternate inside a term
+                R3D_TERM(al, bh)
+                R3D_TERM(am, bm)
+                R3D_TERM(ah, bm)
+                R3D_TERM(am, bh)
+                R3D_TERM(ah, bh)
+#undef R3D_TERM
+#undef R3D_BF
+            }
+            __syncthreads();
+        }
+        // C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+        const float alpha = d.alpha;
+        const bool accum = d.accumulate != 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + wn * 64 + j * 32 + l31;
+                if (n >= N) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    if (m < M) {
+                        float* c = d.C + (size_t)m * d.ldc + n;
+                        float v = alpha * acc[i][j][r];
+                        if (accum) v += *c;
+                        *c = v;
+                    }
+                }
+            }
+    } else {
+        // ================================= producers: one 8 (k) x 4 (m | n) block per thread and k-step ===================
+        const int pt = tid - 256;
+        const bool isa = pt < 128;
+        const int b = isa ? pt : pt - 128;
+        const int ko = b >> 5, x4 = b & 31;                        // k-octet 0..3, column group
+        const int xg = (isa ? m0 : n0) + 4 * x4;                   // global column of the block
+        const bool x_ok = xg < (isa ? M : N);                      // M % 4 == 0, N % 4 == 0 (validated)
+        const float* colp = (isa ? d.A : d.B) + (x_ok ? xg : 0);
+        const size_t ld = (size_t)(isa ? d.lda : d.ldb);
+        unsigned short* imgrow = lds16 + (isa ? 0 : 3 * PLANE) + (size_t)(4 * x4) * S;
+        const int sw = (x4 >> 2) & 3;                              // (row >> 4) & 3 for rows 4 x4 .. 4 x4 + 3
+        float4 s0[8], s1[8];
+        // (unconditional loads from clamped rows: see gemm_bf3_nt_kernel)
+        auto load_stage = [&](float4* reg, int kt) {
+            const int kb = kt * BK + 8 * ko;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = kb + j < K ? kb + j : K - 1;
+                reg[j] = *reinterpret_cast<const float4*>(colp + (size_t)k * ld);
+            }
+        };
+        auto store_stage = [&](unsigned short* img, const float4* reg, int kt) {
+            const int kb = kt * BK + 8 * ko;
+            float v[4][8];                                          // [column][k]
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bool ok = x_ok && (kb + j < K);
+                v[0][j] = ok ? reg[j].x : 0.f; v[1][j] = ok ? reg[j].y : 0.f;
+                v[2][j] = ok ? reg[j].z : 0.f; v[3][j] = ok ? reg[j].w : 0.f;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                uint4 h, m, l;
+                split3_oct(v[c], h, m, l);
+                unsigned short* dst = img + (imgrow - lds16) + (size_t)c * S + 8 * (ko ^ sw);
+                *reinterpret_cast<uint4*>(dst) = h;
+                *reinterpret_cast<uint4*>(dst + PLANE) = m;
+                *reinterpret_cast<uint4*>(dst + 2 * PLANE) = l;
+            }
+        };
+        const int last = nk - 1;
+        load_stage(s0, 0);
+        load_stage(s1, min(1, last));
+        store_stage(lds16, s0, 0);
+        load_stage(s0, min(2, last));
+        __syncthreads();                                            // stage 0 written
+        for (int kt = 0; kt < nk; kt += 2) {
+            store_stage(lds16 + STAGE, s1, min(kt + 1, last));
+            load_stage(s1, min(kt + 3, last));
+            __syncthreads();
+            if (kt + 1 < nk) {
+                store_stage(lds16, s0, min(kt + 2, last));
+                load_stage(s0, min(kt + 4, last));
+                __syncthreads();
+            }
+        }
+    }
+}
+
+bool gemm_bf3_tn_ok(const r3d_gemm_desc& d) {
+    if (d.layout != R3D_GEMM_TN || d.splitk > 1 || d.K < 16) return false;
+    if ((d.M & 3) || (d.N & 3) || (d.lda & 3) || (d.ldb & 3)) return false;
+    if (d.b_add || d.bias || d.pre_out || d.act || d.drop_mask || d.mul || d.res1 || d.res2) return false;
+    if (d.bias_grad || d.c_row_xor || d.adam_m) return false;
+    return r3d_aligned16(d.A) && r3d_aligned16(d.B);
+}
+
+int launch_gemm_bf3_tn(const r3d_gemm_desc& d, hipStream_t s) {
+    if (!gemm_bf3_tn_ok(d)) return R3D_EINVAL;
+    const int tm = r3d_cdiv(d.M, 128), tn = r3d_cdiv(d.N, 128);
+    const size_t lds = (size_t)2 * 6 * 128 * 40 * sizeof(unsigned short);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf3_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_bf3_tn_kernel, dim3(8 * tm * r3d_cdiv(tn, 8)), dim3(512), lds, s, d, tm, tn);
+    R3D_LAUNCH_CHECK();
+    return R3D_OK;
+}
+
 int launch_wgrad_panel_bf3(const r3d_gemm_desc& d, hipStream_t s) {
     const int npanels = r3d_cdiv(d.N, kP3N);
     const int per = r3d_cdiv(npanels, 256);                 // panels per workgroup: balanced over <= 256 workgroups

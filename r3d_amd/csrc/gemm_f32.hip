@@ -720,6 +720,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_panel_kernel(const r3d_gemm_desc
 int launch_wgrad_panel_bf3(const r3d_gemm_desc& d, hipStream_t s);         // gemm_bf3.hip
 int launch_gemm_bf3_nt(const r3d_gemm_desc& d, hipStream_t s);
 bool gemm_bf3_nt_ok(const r3d_gemm_desc& d);
+int launch_gemm_bf3_tn(const r3d_gemm_desc& d, hipStream_t s);
+bool gemm_bf3_tn_ok(const r3d_gemm_desc& d);
 
 static bool wgrad_panel_ok(const r3d_gemm_desc& d) {
     if (d.layout != R3D_GEMM_TN || d.K > 128 || d.M > 128 || d.N < 2048 || (d.N & 3) || (d.ldb & 3)) return false;
@@ -731,7 +733,7 @@ static bool wgrad_panel_ok(const r3d_gemm_desc& d) {
 // ---------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------
-static const int kTileSz[10] = {0, 32, 64, 128, 64, 128, 64, 64, 64, 128};
+static const int kTileSz[11] = {0, 32, 64, 128, 64, 128, 64, 64, 64, 128, 128};
 
 template <int LA, int LB, int BM, int BN, int BK, int WM, int WN, int WK>
 static int launch_cfg(const r3d_gemm_desc& d, int nsplit, hipStream_t s) {
@@ -794,7 +796,7 @@ static int gemm_validate(const r3d_gemm_desc* d) {
     if (!d || !d->A || !d->B || !d->C) return R3D_EINVAL;
     if (d->M <= 0 || d->N <= 0 || d->K <= 0) return R3D_EINVAL;
     if (d->layout < 0 || d->layout > 2) return R3D_EINVAL;
-    if (d->tile < 1 || d->tile > 9) return R3D_EINVAL;
+    if (d->tile < 1 || d->tile > 10) return R3D_EINVAL;
     const int a_min = (d->layout == R3D_GEMM_TN) ? d->M : d->K;
     const int b_min = (d->layout == R3D_GEMM_NT) ? d->K : d->N;
     if (d->lda < a_min || d->ldb < b_min || d->ldc < d->N) return R3D_EINVAL;
@@ -887,6 +889,11 @@ R3D_EXPORT int r3d_gemm_plan(r3d_gemm_desc* d) {
     {                                    // few-row weight gradient of a wide layer: the persistent panel kernel
         r3d_gemm_desc t = *d;
         t.splitk = 1;
+        // ... and beyond its 128 x 128 limit, the tiled kernel on the bf16 matrix cores (wide N, enough rows to amortise the split)
+        if (d->prec == 1 && !wgrad_panel_ok(t) && d->N >= 2048 && d->K >= 64 && (long)d->M * d->K >= 128 * 128 && gemm_bf3_tn_ok(t)) {
+            d->tile = 10; d->splitk = 1; d->k_per_split = d->K;
+            return R3D_OK;
+        }
         if (wgrad_panel_ok(t)) {
             const bool bf3 = d->prec == 1 && (d->ldc & 3) == 0 && r3d_aligned16(d->C);    // (its C tiles leave as float4)
             d->tile = bf3 ? 7 : 6; d->splitk = 1; d->k_per_split = d->K;
@@ -903,6 +910,7 @@ R3D_EXPORT int r3d_gemm_f32(const r3d_gemm_desc* dp, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const int ns = nsplits_of(d);
     if (d.tile == 8 || d.tile == 9) return launch_gemm_bf3_nt(d, s);          // long-K NT split-K on the bf16 matrix cores
+    if (d.tile == 10) return launch_gemm_bf3_tn(d, s);                        // wide TN (weight gradient) on the same
     if (d.tile == 7) {                   // the same panel kernel on the bf16 matrix cores (exact 3-way operand split)
         if (!wgrad_panel_ok(d) || (d.ldc & 3) || !r3d_aligned16(d.C)) return R3D_EINVAL;
         return launch_wgrad_panel_bf3(d, s);

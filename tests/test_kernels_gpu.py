@@ -502,6 +502,26 @@ def test_gemm_bf16x3_weight_gradient_panels(ops, K, M, N):
     assert float(big[:, N:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("K,M,N", [(512, 512, 50176), (256, 128, 19200), (2048, 1024, 4096), (100, 384, 4100), (130, 132, 2052)])
+def test_gemm_bf16x3_weight_gradient_tiled(ops, K, M, N):
+    """TN product beyond the panel kernel's 128 x 128 limit (tile 10), with alpha and accumulate, against fp64."""
+    from r3d_amd._lib import GEMM_TN
+    a = rnd(K, M, seed=K + M) * 0.05
+    b = torch.rand(K, N, generator=torch.Generator().manual_seed(N))
+    c_init = rnd(M, N, seed=9)
+    want = 0.5 * (a.double().t() @ b.double()) + c_init.double()
+    scale = float(want.abs().max())
+    c1, c0 = dev(c_init.clone()), dev(c_init.clone())
+    ws = ops.GemmWorkspace("cuda")
+    d1 = ops.gemm(GEMM_TN, dev(a), dev(b), c1, ws=ws, prec=1, alpha=0.5, accumulate=True)
+    d0 = ops.gemm(GEMM_TN, dev(a), dev(b), c0, ws=ws, prec=0, alpha=0.5, accumulate=True)
+    torch.cuda.synchronize()
+    assert d1.tile == 10 and d0.tile <= 5, (d1.tile, d0.tile)
+    e1 = float((c1.cpu().double() - want).abs().max()) / scale
+    e0 = float((c0.cpu().double() - want).abs().max()) / scale
+    assert e1 < 3e-6 and e1 < 4 * e0 + 3e-7, (e1, e0)
+
+
 @pytest.mark.parametrize("M,N,K", [(128, 128, 50176), (128, 128, 19200), (512, 512, 50176), (100, 96, 8200), (256, 1024, 16384),
                                    (8, 40, 8192)])
 def test_gemm_bf16x3_long_k_projection(ops, M, N, K):
