@@ -317,7 +317,7 @@ def cm_fuser(p, rgb, dep, mode, n_head):
     return fused, dict(idx_rgb=idx_rgb, idx_dep=idx_dep, score_rgb=s_rgb, score_dep=s_dep)
 
 
-def decoder(p, memory, pos, query_pos, key_padding_mask, n_head, n_layers):
+def decoder(p, memory, pos, query_pos, key_padding_mask, n_head, n_layers, capture=None):
     """Transformer.forward with the encoder bypassed (model/extras/transformer.py:75-128) ->
     TransformerDecoder (:161-191) -> TransformerDecoderLayer.forward_post (:281-330), post-norm.
     All tensors batch-first here: memory [B,S,H], pos [1,S,H], query_pos [1,Q,H]."""
@@ -332,8 +332,10 @@ def decoder(p, memory, pos, query_pos, key_padding_mask, n_head, n_layers):
         tgt = layer_norm(tgt + sa, p[pre + "norm1.weight"], p[pre + "norm1.bias"])
         ca = mha(p, pre + "multihead_attn.", tgt + qp, kv, kv, n_head, key_padding_mask)
         tgt = layer_norm(tgt + ca, p[pre + "norm2.weight"], p[pre + "norm2.bias"])
-        ff = F.linear(F.relu(F.linear(tgt, p[pre + "linear1.weight"], p[pre + "linear1.bias"])),
-                      p[pre + "linear2.weight"], p[pre + "linear2.bias"])
+        ff_pre = F.linear(tgt, p[pre + "linear1.weight"], p[pre + "linear1.bias"])
+        if capture is not None:                                       # (tests: which ReLU units sit on the kink)
+            capture.setdefault("ffn_pre", []).append(ff_pre.detach())
+        ff = F.linear(F.relu(ff_pre), p[pre + "linear2.weight"], p[pre + "linear2.bias"])
         tgt = layer_norm(tgt + ff, p[pre + "norm3.weight"], p[pre + "norm3.bias"])
     return layer_norm(tgt, p["transformer.decoder.norm.weight"], p["transformer.decoder.norm.bias"])
 
@@ -357,7 +359,7 @@ def forward(p, inputs, depth, mode, pad_idx, n_head=8, n_layers=1, want_seg=True
     else:
         fused, aux = cm_fuser(p, rgb, d, mode, n_head)                               # :199
     qpos = p["query_embed.weight"].unsqueeze(0)                                      # :205-209
-    tgt = decoder(p, fused, pos, qpos, kpm, n_head, n_layers)                        # :211
+    tgt = decoder(p, fused, pos, qpos, kpm, n_head, n_layers, capture=aux)          # :211
     out = {}
     if want_anticipate:                                                              # :219-226
         out["action"] = F.linear(tgt, p["fc.weight"], p["fc.bias"])

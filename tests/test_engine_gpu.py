@@ -195,7 +195,8 @@ def test_fused_decoder_equals_composed_decoder(tag, training):
             close_rel(lb[k], la[k], f"{tag}/act {k}", rtol=5e-5)
 
 
-@pytest.mark.parametrize("B,S,H,K,n_dec", [(8, 64, 512, 17, 1), (8, 16, 1024, 17, 1), (8, 32, 128, 17, 1), (16, 16, 256, 122, 2)])
+@pytest.mark.parametrize("B,S,H,K,n_dec", [(8, 64, 512, 17, 1), (8, 16, 1024, 17, 1), (16, 16, 1024, 17, 1), (8, 32, 128, 17, 1),
+                                           (16, 16, 256, 122, 2)])
 def test_step_parity_baseline_sizes(B, S, H, K, n_dec, oracle_lib):
     """BASELINE.json's other configurations at their per-GPU shapes (cfg4: B=8,S=64,H=512; cfg5: H=1024; cfg3: S=32)
     and an NTU-sized head: one training step against the oracle on the same hash-filled parameters and inputs.
@@ -224,19 +225,32 @@ def test_step_parity_baseline_sizes(B, S, H, K, n_dec, oracle_lib):
     close_rel(eng.last["w"].fused.view(B, S, H), oaux["fused"].detach(), f"H{H}/fused")
     assert_close(loss[3].cpu(), float(ores["loss"]), 1e-3, 1e-6, "total loss")
     assert torch.equal(eng.last["idx"][0].cpu(), oaux["idx_rgb"]) and torch.equal(eng.last["idx"][1].cpu(), oaux["idx_dep"])
+    # ReLU units of the decoder FFN whose pre-activation is within rounding of zero in the oracle: the fp32 product here may
+    # land on the other side of the kink, which flips that unit's contribution (its row of linear1's gradient entirely,
+    # everything upstream by the unit's share).  They are identified BY CONSTRUCTION from the oracle's pre-activations
+    # (|u| <= 2e-6 max|u|: the size of the fp32 accumulation error of a K = H dot product), must be few, and only they get
+    # a different treatment: their rows of linear1's gradient are excluded, and -- only if such a unit exists -- the
+    # other gradients get the bound of one flipped unit (4e-3) instead of 2e-3.
+    kink_units = set()
+    for l, u in enumerate(oaux["ffn_pre"]):
+        near = (u.abs() <= 2e-6 * float(u.abs().max())).reshape(-1, u.shape[-1])
+        kink_units |= {(l, int(j)) for j in near.any(dim=0).nonzero().flatten()}
+    assert len(kink_units) <= 4, f"H{H}: {len(kink_units)} FFN units on the ReLU kink"
+    rtol = 2e-3 if not kink_units else 4e-3
     for n, p in tr.p.items():
-        if p.grad is not None:
-            if H < 1024:
-                close_rel(eng.arena.g(n), p.grad, f"H{H}/grad {n}", rtol=2e-3)
-            else:
-                # 262144 ReLU units in the decoder FFN: a pre-activation within rounding of zero takes a different
-                # side of the kink here and in the oracle (seen: exactly one unit, which moves that unit's row of
-                # linear1's gradient by 4 % and everything upstream by 1-2e-3).  Bound the bulk tightly, the tail loosely.
-                g, r = eng.arena.g(n).double().cpu(), p.grad.double()
-                sc = max(float(r.abs().max()), 1e-5)
-                err = (g - r).abs()
-                assert float(err.max()) <= 0.1 * sc, (n, float(err.max()) / sc)
-                assert float((err <= 4e-3 * sc).double().mean()) >= 0.999, n
+        if p.grad is None:
+            continue
+        g, r = eng.arena.g(n).cpu(), p.grad
+        for (l, j) in kink_units:
+            if n in (f"transformer.decoder.layers.{l}.linear1.weight", f"transformer.decoder.layers.{l}.linear1.bias"):
+                keep = torch.ones(r.shape[0], dtype=torch.bool)
+                keep[j] = False
+                g, r = g[keep], r[keep]
+            elif n == f"transformer.decoder.layers.{l}.linear2.weight":
+                keep = torch.ones(r.shape[1], dtype=torch.bool)
+                keep[j] = False
+                g, r = g[:, keep], r[:, keep]
+        close_rel(g, r, f"H{H}/grad {n}" + (f" (kink units {sorted(kink_units)} excluded)" if kink_units else ""), rtol=rtol)
 
 
 @pytest.mark.parametrize("tag,training", [("step_tiny", False), ("step_cfg2", False), ("step_cfg2", True), ("step_k122_dec2", True)])
