@@ -21,8 +21,6 @@ __device__ __forceinline__ void adamw_body(float4* __restrict__ p, const float4*
     const float decay = 1.0f - lr * wd;
     const float step_size = lr / bc1;
     const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
-    for (size_t i = (size_t)bid * 256 + threadIdx.x; i < n4; i += (size_t)nb * 256) {
-        float4 pp = p[i], gg = g[i], mm = m[i], vv = v[i];
 #define R3D_ADAM1(c)                                               \
         {                                                          \
             const float gr = gg.c * gscale;                        \
@@ -32,10 +30,26 @@ __device__ __forceinline__ void adamw_body(float4* __restrict__ p, const float4*
             const float den = sqrtf(vv.c) / bc2_sqrt + eps;        \
             pp.c -= step_size * (mm.c / den);                      \
         }
+    // two grid-strides per iteration: eight 16-byte loads in flight per lane before the first use (arenas beyond the
+    // 256 MiB Infinity Cache are a pure HBM stream: more bytes in flight per CU, measured at the cfg4 / cfg5 arena sizes)
+    const size_t stride = (size_t)nb * 256;
+    size_t i = (size_t)bid * 256 + threadIdx.x;
+    for (; i + stride < n4; i += 2 * stride) {
+        const size_t j = i + stride;
+        float4 pp = p[i], gg = g[i], mm = m[i], vv = v[i];
+        float4 pq = p[j], gq = g[j], mq = m[j], vq = v[j];
         R3D_ADAM1(x) R3D_ADAM1(y) R3D_ADAM1(z) R3D_ADAM1(w)
-#undef R3D_ADAM1
+        p[i] = pp; m[i] = mm; v[i] = vv;
+        pp = pq; gg = gq; mm = mq; vv = vq;
+        R3D_ADAM1(x) R3D_ADAM1(y) R3D_ADAM1(z) R3D_ADAM1(w)
+        p[j] = pp; m[j] = mm; v[j] = vv;
+    }
+    if (i < n4) {
+        float4 pp = p[i], gg = g[i], mm = m[i], vv = v[i];
+        R3D_ADAM1(x) R3D_ADAM1(y) R3D_ADAM1(z) R3D_ADAM1(w)
         p[i] = pp; m[i] = mm; v[i] = vv;
     }
+#undef R3D_ADAM1
 }
 
 __global__ __launch_bounds__(256) void adamw_kernel(float4* __restrict__ p, const float4* __restrict__ g,

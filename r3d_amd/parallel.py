@@ -404,15 +404,15 @@ class RcclStep:
             N = x_dep2d.shape[1] if blocked else x_dep2d.shape[0]
             recv = tp._buf(("recv", W * N, slot), (W * N, tp.Pr))
             send = x_dep2d if blocked else tp._buf(("send", N, slot), (W, N, tp.Pr))
-            if W > 1:
-                if not blocked:
-                    send.copy_(x_dep2d.view(N, W, tp.Pr).transpose(0, 1))
-                self.side_comm.all_to_all(recv, send)
-            else:       # (one-rank rehearsal: the same passes as kernels -- hipGraph instantiation crashes on the
-                        #  25.7 MB memcpy nodes that a contiguous copy_ and a self-addressed all-to-all turn into)
-                if not blocked:
-                    torch.mul(x_dep2d.view(W, N, tp.Pr), 1.0, out=send)
-                torch.mul(send.view(W * N, tp.Pr), 1.0, out=recv)
+            # One code path for every world size (a one-rank rehearsal captures a memcpy node for the contiguous copy_ and a
+            # kernel node for the self-addressed all-to-all).  Round 1 replaced these two by multiply-by-one kernels at W == 1
+            # after a segfault in capture_end, blaming "25.7 MB memcpy nodes"; tools/capture_probe.py (round 2) shows memcpy
+            # nodes of 1-64 MB, on the capture stream or a side stream, alone or chained, and every one-rank RCCL collective
+            # (captured as kernel / memcpy / nothing) instantiate and replay, and this very flow runs with the copies
+            # restored -- the abort does not reproduce and was not caused by the node type.
+            if not blocked:
+                send.copy_(x_dep2d.view(N, W, tp.Pr).transpose(0, 1))
+            self.side_comm.all_to_all(recv, send)
             self.shards[slot] = dict(x=recv, rows=[N] * W, off=tp.rank * N, n=N, work=None)
 
     def run(self, feats, depth, lab, dur, tgt, pad_idx, training, slot=0, lr=None, hyper=None, after_losses=None,
