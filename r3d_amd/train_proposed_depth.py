@@ -163,6 +163,128 @@ class _GraphedSteps:
         self.acc_cnt += counts
 
 
+class _ShardedSteps:
+    """--pixel_shard training steps on parallel.RcclStep with a ONE-BATCH LOOK-AHEAD: while step t runs (one hipGraph,
+    RCCL exchanges captured in it), batch t + 1 is copied into the other slot's static buffers on a side stream and its
+    depth all-to-all + loss denominator are staged there (a second small graph), so nothing step t + 1 needs from the other
+    ranks sits on its critical path.  The reference has no counterpart (nn.DataParallel scatters inside the step,
+    main_darai.py:133; the loop sees one batch at a time, train_proposed_depth.py:127-138).
+
+    Requirements of the static exchange: every rank feeds batches of the same shape in the same order (a
+    DistributedSampler with drop_last); a batch that was not pre-staged (first of an epoch, first of a new shape) is
+    staged on the spot.  Ordering between the streams is as in bench.py: the step waits for its slot's staging event (long
+    complete); the staging of slot s^1 may only overwrite it when the step that last read it is done -- that
+    dependency is kept on the host (an event synchronize of step t - 1 after step t has been queued)."""
+
+    def __init__(self, eng, dp, rs, acc_loss, acc_cnt, pad_idx, use_graphs=True):
+        self.eng, self.dp, self.rs, self.pad_idx = eng, dp, rs, pad_idx
+        self.acc_loss, self.acc_cnt = acc_loss, acc_cnt
+        self.use_graphs = use_graphs
+        self.shapes = {}
+        self.side = torch.cuda.Stream(eng.device)
+        self.t = 0
+        self.ev_step = [torch.cuda.Event() for _ in range(4)]
+        for e in self.ev_step:
+            e.record()
+
+    def _accumulate(self, loss, counts):
+        self.acc_loss += loss
+        self.acc_cnt += counts
+
+    @staticmethod
+    def _key(batch, training):
+        return tuple((tuple(t.shape), str(t.dtype)) for t in batch) + (bool(training),)
+
+    def _state(self, batch, training):
+        key = self._key(batch, training)
+        st = self.shapes.get(key)
+        if st is None:
+            dev = self.eng.device
+            mk = lambda: [torch.empty(t.shape, dtype=t.dtype, device=dev) for t in batch]      # noqa: E731
+            st = self.shapes[key] = dict(buf=[mk(), mk()], slot=0, staged=[None, None], runs=[0, 0], G=[None, None],
+                                         S=[None, None], ev_side=[torch.cuda.Event(), torch.cuda.Event()], hyper=None,
+                                         feats=torch.empty(batch[0].shape, dtype=batch[0].dtype, device=dev))
+            for e in st["ev_side"]:
+                e.record()
+        return st
+
+    def _stage(self, st, s):
+        buf = st["buf"][s]
+        x2d = buf[1].reshape(buf[1].shape[0] * buf[1].shape[1], -1)
+        self.rs.stage(x2d, buf[3], self.pad_idx, s)
+
+    def _fill(self, st, s, batch, token):
+        """(current stream) batch -> slot s buffers (host-to-device or device-to-device), then its staging."""
+        for dst, src in zip(st["buf"][s], batch):
+            dst.copy_(src, non_blocking=True)
+        if self.use_graphs and st["S"][s] is None and st["staged"][s] is not None:
+            # second staging of this slot: capture it (the first one sized the exchange buffers)
+            g = torch.cuda.CUDAGraph()
+            torch.cuda.current_stream().synchronize()
+            with torch.cuda.graph(g, stream=torch.cuda.current_stream()):
+                self._stage(st, s)
+            st["S"][s] = g
+        if st["S"][s] is not None:
+            st["S"][s].replay()
+        else:
+            self._stage(st, s)
+        st["staged"][s] = token
+
+    def step(self, cur, cur_token, nxt, nxt_token, lr, hyper, training):
+        """cur / nxt: 5-tuples of tensors (host or device; nxt may be None); tokens identify batches (any hashable)."""
+        eng, rs = self.eng, self.rs
+        st = self._state(cur, training)
+        s = st["slot"]
+        main = torch.cuda.current_stream()
+        ev_pre = torch.cuda.Event()
+        ev_pre.record(main)                                 # everything the caller produced so far (device-resident batches)
+        eng.set_lr(lr)
+        if st["staged"][s] != cur_token:                    # not pre-staged: first batch of an epoch / of this shape
+            self.ev_step[(self.t - 1) % 4].synchronize()    # (the step that last read this slot is long done; be safe)
+            self._fill(st, s, cur, cur_token)
+        else:
+            main.wait_event(st["ev_side"][s])
+        buf = st["buf"][s]
+
+        def run():
+            # the RGB features go through ONE static buffer: the engine's grouped weight-gradient launch keeps their
+            # address in a device-side descriptor table (ops.GemmGroup), which a captured step cannot re-point per slot
+            st["feats"].copy_(buf[0])
+            rs.run(st["feats"], *buf[1:], self.pad_idx, training, slot=s, lr=lr, hyper=hyper, after_losses=self._accumulate,
+                   stage_den=False, prefill_dropout=False)
+        eng._drop_ready = None
+        if not self.use_graphs:
+            run()
+        elif st["G"][s] is not None and st["hyper"] == hyper:
+            st["G"][s].replay()
+        elif st["runs"][s] == 0 or st["hyper"] not in (None, hyper):
+            run()                                           # eager: sizes every workspace of this slot
+            st["G"] = [None, None]
+            st["hyper"] = hyper
+        else:
+            g = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g):
+                run()
+            st["G"][s] = g
+            g.replay()
+        st["runs"][s] += 1
+        self.ev_step[self.t % 4].record(main)
+        # ---- look-ahead: the next batch into the other slot, on the side stream, under this step
+        if nxt is not None and self._key(nxt, training) == self._key(cur, training):
+            self.ev_step[(self.t - 1) % 4].synchronize()    # slot s^1 was last read by step t - 1
+            self.side.wait_event(ev_pre)                    # (not the step just queued: the staging runs under it)
+            with torch.cuda.stream(self.side):
+                self._fill(st, s ^ 1, nxt, nxt_token)
+                st["ev_side"][s ^ 1].record(self.side)
+        st["slot"] = s ^ 1
+        self.t += 1
+
+    def drain(self):
+        """End of an epoch: nothing staged is left pending on the side stream."""
+        self.side.synchronize()
+
+
 def validate(model, val_loader, criterion, pad_idx, device):
     core = _unwrap(model)
     model.eval()
@@ -222,26 +344,57 @@ def train(args, model, train_loader, optimizer, scheduler, criterion, model_save
     acc_loss = torch.zeros(4, dtype=torch.float64, device=eng.device)
     acc_cnt = torch.zeros(4, dtype=torch.int64, device=eng.device)
     # one-GPU steps with the fused optimiser replay as hipGraphs (--no_graph_steps / args.graph_steps=False: eager)
-    graphed = None
-    if getattr(args, "graph_steps", True) and (dp is None or dp.tp is None):
-        rs = None
-        if dp is not None and dp.active and dist.get_backend() == "nccl" and not getattr(args, "torch_collectives", False):
+    graphed = sharded = None
+    rs = None
+    if dp is not None and dp.active and getattr(args, "graph_steps", True) and not getattr(args, "torch_collectives", False):
+        g0 = optimizer.param_groups[0]
+        make_comm = getattr(args, "comm_factory", None)     # (tests: a torch.distributed stand-in for the RCCL binding)
+        if make_comm is not None or dist.get_backend() == "nccl":
             try:                                    # RCCL on the launch stream: the data-parallel step stays one graph
                 from .parallel import RcclStep
-                from .rccl import RcclComm
-                g0 = optimizer.param_groups[0]
-                rs = RcclStep(dp, RcclComm(), RcclComm(), g0["lr"], g0["weight_decay"])
+                if make_comm is None:
+                    from .rccl import RcclComm
+                    make_comm = RcclComm
+                rs = RcclStep(dp, make_comm(), make_comm(), g0["lr"], g0["weight_decay"])
                 if dp.rank == 0:
                     print("Data-parallel step: RCCL on the launch stream, one hipGraph per step")
             except Exception as e:                  # noqa: BLE001  (no librccl beside torch, communicator refused, ...)
                 print(f"RCCL step unavailable ({type(e).__name__}: {e}); using torch.distributed all-reduces")
                 rs = None
+    if getattr(args, "graph_steps", True) and (dp is None or dp.tp is None):
         graphed = _GraphedSteps(eng, acc_loss, acc_cnt, dp, pad_idx, rs)
+    elif rs is not None and dp.tp is not None and isinstance(optimizer, FlatAdamW):
+        # --pixel_shard: the sharded one-graph step with a one-batch look-ahead (equal batch shapes on every rank)
+        sharded = _ShardedSteps(eng, dp, rs, acc_loss, acc_cnt, pad_idx, use_graphs=getattr(args, "sharded_graphs", True))
+        dp.tp.equal_batches = True
     for epoch in range(args.epochs):
         acc_loss.zero_()
         acc_cnt.zero_()
         n_steps, i = 0, -1
-        for i, data in enumerate(train_loader):
+        if sharded is not None:
+            # one-batch look-ahead over the VALID batches (the reference's skip rules, :128,148, applied first)
+            def valid(it):
+                for j, data in it:
+                    if data is None or len(data[0]) < min_batch:
+                        continue
+                    yield j, data
+            it = valid(enumerate(train_loader))
+            cur = next(it, None)
+            last_i = -1
+            while cur is not None:
+                nxt = next(it, None)
+                g = optimizer.param_groups[0]
+                prep = lambda d: (d[0].float().contiguous(), d[1].float().contiguous(), d[2].long().contiguous(),     # noqa: E731
+                                  d[3].float().contiguous(), d[4].long().contiguous())
+                sharded.step(prep(cur[1]), (epoch, cur[0]), prep(nxt[1]) if nxt is not None else None,
+                             (epoch, nxt[0]) if nxt is not None else None, g["lr"],
+                             (g["weight_decay"], tuple(g["betas"]), g["eps"]), model.training)
+                n_steps += 1
+                last_i = cur[0]
+                cur = nxt
+            sharded.drain()
+            i = max(last_i, len(train_loader) - 1) if hasattr(train_loader, "__len__") else last_i
+        for i, data in (enumerate(train_loader) if sharded is None else ()):
             if data is None:
                 continue
             features, depth_features, past_label, trans_dur_future, trans_future_target = _to_dev(data, eng.device)

@@ -353,3 +353,132 @@ def test_train_loop_rccl_step_one_rank_equals_single_gpu():
     rank, status, info = q.get(timeout=600)
     p.join(timeout=60)
     assert status == "ok", info
+
+
+# ----------------------------------------------------------------------------------------------------------
+# train(--pixel_shard) on the sharded RcclStep with a one-batch look-ahead
+# ----------------------------------------------------------------------------------------------------------
+def _train_sharded_worker(rank, world, port, q):
+    """2 ranks sharing the GPU, gloo: train() with pixel_shard through _ShardedSteps (look-ahead staging, two slots; the
+    RCCL binding replaced by the torch.distributed stand-in, so steps are enqueued, not captured) must end with the
+    parameters of the launch-by-launch sharded loop (graph_steps=False) on the same batches."""
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        import contextlib
+        import io
+        import tempfile
+        from r3d_amd.train_proposed_depth import train
+        from r3d_amd.optim import FlatAdamW
+        fx = load_fixture("step_tiny")
+        m = fx["meta"]
+        batches = [fixture_batch(fx, seed=500 + 10 * s + rank) for s in range(5)]
+        batches.insert(2, None)                                   # the loader's None items are skipped (:128)
+        val = [[t[:1] for t in fixture_batch(fx, seed=999)]]
+        finals, logs = [], []
+        for lookahead in (False, True):
+            model = _model(fx)
+            args = argparse.Namespace(epochs=2, input_type="i3d_transcript", seg=True, anticipate=True, task="long",
+                                      min_batch=1, pixel_shard=True, graph_steps=lookahead, sharded_graphs=False,
+                                      comm_factory=_DistAsRccl if lookahead else None)
+
+            class NoSched:
+                def step(self):
+                    pass
+            opt = FlatAdamW(model.parameters(), 1e-3, weight_decay=5e-3)
+            out = io.StringIO()
+            with tempfile.TemporaryDirectory() as d, contextlib.redirect_stdout(out):
+                train(args, model, batches, opt, NoSched(), None, d, m["pad_idx"], torch.device("cuda"), val, seed=0)
+            torch.cuda.synchronize()
+            finals.append(model.engine().arena.params.clone())
+            logs.append(out.getvalue())
+        assert "one hipGraph per step" in logs[1] or rank != 0
+        a = model.engine().arena
+        d = (finals[0][:a.n_live] - finals[1][:a.n_live]).abs()
+        assert float(d.max()) <= 10 * 2.1e-3, float(d.max())       # (ill-conditioned AdamW elements move by +-lr per step)
+        assert float((d <= 1e-5 * (1 + finals[0][:a.n_live].abs())).double().mean()) > 0.95
+        ep = [ln for ln in logs[0].splitlines() if ln.startswith("Epoch")]
+        eq = [ln for ln in logs[1].splitlines() if ln.startswith("Epoch")]
+        assert ep == eq or rank != 0, (ep, eq)
+        q.put((rank, "ok", ""))
+    except Exception as e:          # noqa: BLE001
+        import traceback
+        q.put((rank, "fail", traceback.format_exc() + repr(e)))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_train_loop_pixel_shard_lookahead_equals_eager_two_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, status, info in res:
+        assert status == "ok", f"rank {rank}: {info}"
+
+
+def _train_sharded_graph_worker(port, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+        torch.cuda.set_device(0)
+        import contextlib
+        import io
+        import tempfile
+        from r3d_amd.train_proposed_depth import train
+        from r3d_amd.optim import FlatAdamW
+        fx = load_fixture("step_tiny")
+        m = fx["meta"]
+        batches = [fixture_batch(fx, seed=300 + 10 * s) for s in range(6)]
+        val = [[t[:1] for t in fixture_batch(fx, seed=999)]]
+        finals = []
+        for rehearse in (False, True):
+            if rehearse:                     # one-rank RCCL group: train(--pixel_shard) takes the graphed look-ahead path
+                dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+                os.environ["R3D_REHEARSE_DIST"] = "1"
+            model = _model(fx)
+            args = argparse.Namespace(epochs=2, input_type="i3d_transcript", seg=True, anticipate=True, task="long",
+                                      min_batch=1, graph_steps=True, pixel_shard=rehearse)
+
+            class NoSched:
+                def step(self):
+                    pass
+            opt = FlatAdamW(model.parameters(), 1e-3, weight_decay=5e-3)
+            out = io.StringIO()
+            with tempfile.TemporaryDirectory() as d, contextlib.redirect_stdout(out):
+                train(args, model, batches, opt, NoSched(), None, d, m["pad_idx"], torch.device("cuda"), val, seed=0)
+            torch.cuda.synchronize()
+            finals.append(model.engine().arena.params.clone())
+        os.environ.pop("R3D_REHEARSE_DIST", None)
+        # (the sharded projection takes other GEMM routes -- other roundings -- than the one-GPU step: elements whose gradient
+        #  is rounding noise move by +-lr per step in either, so the criterion is the one of the other sharded tests)
+        a = model.engine().arena
+        dd = (finals[0][:a.n_live] - finals[1][:a.n_live]).abs()
+        assert float(dd.max()) <= 12 * 2.1e-3, float(dd.max())
+        frac = float((dd <= 1e-5 * (1 + finals[0][:a.n_live].abs())).double().mean())
+        assert frac > 0.95, frac
+        q.put((0, "ok", frac))
+    except Exception as e:          # noqa: BLE001
+        import traceback
+        q.put((0, "fail", traceback.format_exc() + repr(e)))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_train_loop_pixel_shard_graphed_one_rank_equals_single_gpu():
+    """train(--pixel_shard) on the sharded one-graph RcclStep (step graphs + staging graphs, two slots, look-ahead),
+    rehearsed with a one-rank RCCL communicator, ends with the parameters of the plain one-GPU loop."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_train_sharded_graph_worker, args=(_free_port(), q))
+    p.start()
+    rank, status, info = q.get(timeout=600)
+    p.join(timeout=60)
+    assert status == "ok", info
