@@ -17,21 +17,20 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // Two consecutive-k values -> the three bf16 terms of each, already packed (element k in the low half of the dword:
-// little-endian vector order).  v_cvt_pk_bf16_f32 rounds to nearest even and packs the pair in ONE instruction; the
-// residuals x - h and (x - h) - m are exact in fp32 (8 + 8 of the 24 mantissa bits are gone each time), the last term
-// rounds the remaining <= 9 bits to 8 (error <= 2^-26 |x|).  4.5 VALU instructions per element including the packing.
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+// little-endian vector order).  Truncation split: h = the top 16 bits of x (v_perm_b32 takes the high halves of the pair
+// in ONE full-rate instruction), x - h and (x - h) - m are exact in fp32 (8 of the 24 mantissa bits leave each time), so
+// x = h + m + l EXACTLY.  4 full-rate VALU instructions per pair and level (perm, 2 x and, packed subtract).
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
-    const f32x2_t x = {x0, x1};
-    const bf16x2_t hb = __builtin_convertvector(x, bf16x2_t);
-    const f32x2_t r1 = x - __builtin_convertvector(hb, f32x2_t);
-    const bf16x2_t mb = __builtin_convertvector(r1, bf16x2_t);
-    const f32x2_t r2 = r1 - __builtin_convertvector(mb, f32x2_t);
-    const bf16x2_t lb = __builtin_convertvector(r2, bf16x2_t);
-    h = __builtin_bit_cast(unsigned, hb);
-    m = __builtin_bit_cast(unsigned, mb);
-    l = __builtin_bit_cast(unsigned, lb);
+    const unsigned u0 = __builtin_bit_cast(unsigned, x0), u1 = __builtin_bit_cast(unsigned, x1);
+    h = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+    const float r0 = x0 - __builtin_bit_cast(float, u0 & 0xffff0000u);
+    const float r1 = x1 - __builtin_bit_cast(float, u1 & 0xffff0000u);
+    const unsigned v0 = __builtin_bit_cast(unsigned, r0), v1 = __builtin_bit_cast(unsigned, r1);
+    m = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+    const float q0 = r0 - __builtin_bit_cast(float, v0 & 0xffff0000u);
+    const float q1 = r1 - __builtin_bit_cast(float, v1 & 0xffff0000u);
+    l = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, q1), __builtin_bit_cast(unsigned, q0), 0x07060302u);
 }
 // eight consecutive-k values -> one 16-byte MFMA operand per plane
 __device__ __forceinline__ void split3_oct(const float* v, uint4& h, uint4& m, uint4& l) {
