@@ -394,6 +394,12 @@ int r3d_posenc_bwd(const float* dy, int lddy, const uint8_t* drop, float drop_sc
                    int lddx, int rows, int H, void* stream);
 int r3d_avgpool_rows_fwd(const float* x, int ldx, float* y, int ldy, int B, int S, int Q, int H, void* stream);
 int r3d_avgpool_rows_bwd(const float* dy, int lddy, float* dx, int lddx, int B, int S, int Q, int H, void* stream);
+/* Label-index queries of model/futr_proposed.py:103-106: out[r, :] = weight[idx[r], :] + table[r % S, :] (nn.Embedding +
+ * the sinusoidal table) and the lookup's adjoint d_weight[e, :] = sum_{r : idx[r] == e} d_out[r, :] (deterministic). */
+int r3d_embed_gather_fwd(const float* weight, int n_embed, const int64_t* idx, const float* table, int ldt, int S, float* out,
+                         int ldo, int rows, int H, void* stream);
+int r3d_embed_gather_bwd(const float* d_out, int ldd, const int64_t* idx, float* d_weight, int n_embed, int rows, int H,
+                         void* stream);
 
 #ifdef __cplusplus
 }

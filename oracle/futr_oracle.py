@@ -415,6 +415,29 @@ def forward_unsup_depth(p, inputs, depth, mode, pad_idx, n_head=8, n_layers=1, n
     return out, dict(memory=mem, query=query, tgt=tgt, pooled=pooled)
 
 
+def forward_proposed(p, inputs, query, mode, pad_idx, n_head=8, n_layers=1, n_query=8):
+    """FUTR.forward of model/futr_proposed.py:70-139 (input_type 'i3d_transcript'): memory = relu(input_embed(x)) with no
+    positional encoding (:92-97), per-clip query = query_embed(label indices) + sinusoidal table (:103-106), decoder with the
+    encoder bypassed (:118), adaptive average pooling to n_query rows (:124), heads; fc_seg has n_class - 1 outputs (:38)."""
+    if mode == "train":
+        src, src_label = inputs
+        kpm = (src_label == pad_idx)
+    else:
+        src = inputs[0] if isinstance(inputs, (tuple, list)) else inputs
+        kpm = None
+    B, S, _ = src.shape
+    H = p["input_embed.weight"].shape[0]
+    mem = F.relu(F.linear(src, p["input_embed.weight"], p["input_embed.bias"]))
+    q = F.embedding(query.long(), p["query_embed.weight"]) + sinusoid_table(S, H)     # positional_embedding_l3[:S] (:63-69,104-106)
+    pos = p["pos_embedding"][:, :S]
+    tgt = decoder(p, mem, pos, q, kpm, n_head, n_layers)
+    pooled = F.adaptive_avg_pool1d(tgt.permute(0, 2, 1), n_query).permute(0, 2, 1)
+    out = {"action": F.linear(pooled, p["fc.weight"], p["fc.bias"]),
+           "duration": F.linear(pooled, p["fc_len.weight"], p["fc_len.bias"]).squeeze(2),
+           "seg": F.linear(mem, p["fc_seg.weight"], p["fc_seg.bias"])}
+    return out, dict(memory=mem, query=q, tgt=tgt, pooled=pooled)
+
+
 UNSUP_LIVE_PREFIXES = ("input_embed.", "depth_projection.", "depth_layernorm.", "pos_embedding", "transformer.decoder.",
                        "fc_seg.", "fc.", "fc_len.")
 

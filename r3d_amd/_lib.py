@@ -148,6 +148,8 @@ _SIGNATURES = {
     "r3d_posenc_bwd": ([_P, _I, _P, _F, _P, _I, _P, _I, _I, _I, _P], C.c_int),
     "r3d_avgpool_rows_fwd": ([_P, _I, _P, _I, _I, _I, _I, _I, _P], C.c_int),
     "r3d_avgpool_rows_bwd": ([_P, _I, _P, _I, _I, _I, _I, _I, _P], C.c_int),
+    "r3d_embed_gather_fwd": ([_P, _I, _P, _P, _I, _I, _P, _I, _I, _I, _P], C.c_int),
+    "r3d_embed_gather_bwd": ([_P, _I, _P, _P, _I, _I, _I, _P], C.c_int),
     "r3d_erank_lds_bytes_v": ([_I, _I], C.c_int64),
     "r3d_erank_jacobi_warm": ([_P, _I, _L, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P], C.c_int),
     "r3d_erank_vt_polish": ([_P, _P, _P, _L, _P], C.c_int),

@@ -69,6 +69,32 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restric
     }
 }
 
+// Label-index queries of model/futr_proposed.py:103-106: out[r, :] = weight[idx[r], :] + table[r % S, :] (nn.Embedding lookup +
+// the sinusoidal table), and the lookup's adjoint d_weight[e, :] = sum over rows with idx[r] == e of d_out[r, :] -- one
+// workgroup per embedding row scanning the (few hundred) indices: deterministic, no atomics.
+__global__ __launch_bounds__(256) void embed_gather_fwd_kernel(const float* __restrict__ weight, int n_embed, const int64_t* __restrict__ idx,
+                                                               const float* __restrict__ table, int ldt, int S, float* __restrict__ out,
+                                                               int ldo, int rows, int H) {
+    const size_t total = (size_t)rows * H;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int r = (int)(e / H), c = (int)(e - (size_t)r * H);
+        int64_t i = idx[r];
+        i = i < 0 ? 0 : (i >= n_embed ? n_embed - 1 : i);
+        out[(size_t)r * ldo + c] = weight[(size_t)i * H + c] + table[(size_t)(r % S) * ldt + c];
+    }
+}
+
+__global__ __launch_bounds__(256) void embed_gather_bwd_kernel(const float* __restrict__ d_out, int ldd, const int64_t* __restrict__ idx,
+                                                               float* __restrict__ d_weight, int rows, int H) {
+    const int e = blockIdx.x;
+    for (int c = threadIdx.x; c < H; c += 256) {
+        float acc = 0.f;
+        for (int r = 0; r < rows; ++r)
+            if (idx[r] == (int64_t)e) acc += d_out[(size_t)r * ldd + c];
+        d_weight[(size_t)e * H + c] = acc;
+    }
+}
+
 static inline int ew_blocks(size_t total) { return (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048); }
 
 }  // namespace r3d
@@ -109,6 +135,26 @@ R3D_EXPORT int r3d_avgpool_rows_bwd(const float* dy, int lddy, float* dx, int ld
     R3D_REQUIRE(dy && dx && B > 0 && S > 0 && Q > 0 && H > 0 && lddy >= H && lddx >= H);
     hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(ew_blocks((size_t)B * S * H)), dim3(256), 0, (hipStream_t)stream, dy, lddy, dx,
                        lddx, B, S, Q, H);
+    R3D_LAUNCH_CHECK();
+    return R3D_OK;
+}
+
+/* out[r, :] = weight[idx[r], :] + table[r % S, :] -- nn.Embedding lookup + sinusoidal table (futr_proposed.py:103-106);
+ * indices are clamped into [0, n_embed). */
+R3D_EXPORT int r3d_embed_gather_fwd(const float* weight, int n_embed, const int64_t* idx, const float* table, int ldt, int S,
+                                    float* out, int ldo, int rows, int H, void* stream) {
+    R3D_REQUIRE(weight && idx && table && out && n_embed > 0 && rows > 0 && H > 0 && S > 0 && ldt >= H && ldo >= H);
+    hipLaunchKernelGGL(embed_gather_fwd_kernel, dim3(ew_blocks((size_t)rows * H)), dim3(256), 0, (hipStream_t)stream, weight,
+                       n_embed, idx, table, ldt, S, out, ldo, rows, H);
+    R3D_LAUNCH_CHECK();
+    return R3D_OK;
+}
+
+/* d_weight[e, :] = sum_{r : idx[r] == e} d_out[r, :]  for every embedding row e (rows never looked up get zeros). */
+R3D_EXPORT int r3d_embed_gather_bwd(const float* d_out, int ldd, const int64_t* idx, float* d_weight, int n_embed, int rows,
+                                    int H, void* stream) {
+    R3D_REQUIRE(d_out && idx && d_weight && n_embed > 0 && rows > 0 && H > 0 && ldd >= H);
+    hipLaunchKernelGGL(embed_gather_bwd_kernel, dim3(n_embed), dim3(256), 0, (hipStream_t)stream, d_out, ldd, idx, d_weight, rows, H);
     R3D_LAUNCH_CHECK();
     return R3D_OK;
 }

@@ -72,8 +72,9 @@ class ParamArena:
             self.offsets[n] = (off, p.numel(), tuple(p.shape))
             off += p.numel()
         self.n_total = (off + 3) // 4 * 4
-        self.bucket_small = (0, self.offsets["depth_projection.weight"][0])
-        self.bucket_big = (self.offsets["depth_projection.weight"][0], self.n_live)
+        big0 = self.offsets["depth_projection.weight"][0] if "depth_projection.weight" in self.offsets else self.n_live
+        self.bucket_small = (0, big0)           # (models without a depth projection: everything is the small bucket)
+        self.bucket_big = (big0, self.n_live)
         self.params = torch.zeros(self.n_total, dtype=torch.float32, device=device)
         self.grads = torch.zeros(self.n_live, dtype=torch.float32, device=device)
         self.exp_avg = torch.zeros(self.n_live, dtype=torch.float32, device=device)

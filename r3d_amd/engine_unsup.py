@@ -20,7 +20,7 @@ from ._lib import GEMM_NT, GEMM_NN, GEMM_TN
 from .engine import ParamArena, DROP_P, EXCLUDE_CLASS_IDX
 
 LIVE_PREFIXES = ("input_embed.", "depth_projection.", "depth_layernorm.", "pos_embedding", "transformer.decoder.",
-                 "fc_seg.", "fc.", "fc_len.")
+                 "fc_seg.", "fc.", "fc_len.", "query_embed.")     # (query_embed: the label-query variant, model/futr_proposed.py)
 
 
 class _Arena(ParamArena):
@@ -48,12 +48,12 @@ class _Shape:
         self.tgtF, self.mF, self.rF = f(N, H), f(N), f(N)
         self.pooled = f(BQ, H)
         self.actdur = f(BQ, K + 1)
-        self.seg = f(N, K)
+        self.seg = f(N, eng.Kseg)
         self.loss = f(4)
         self.loss_ws = torch.zeros(ops.losses_ws_floats(B, S, Q), dtype=torch.float32, device=dev)
         self.counts = torch.zeros(4, dtype=torch.int64, device=dev)
         if train:
-            self.d_actdur, self.d_seg = torch.zeros(BQ, K + 1, dtype=torch.float32, device=dev), f(N, K)
+            self.d_actdur, self.d_seg = torch.zeros(BQ, K + 1, dtype=torch.float32, device=dev), f(N, eng.Kseg)
             self.d_pooled, self.d_tgtF, self.d_t = f(BQ, H), f(N, H), f(N, H)
             self.glayers = [dict(t3pre=f(N, H), ff2=f(N, H), ff1=f(N, 4 * H), t2=f(N, H), t2pre=f(N, H), cap=f(N, H),
                                  cao=f(N, H), caq=f(N, H), cakv=f(N, 2 * H), caqin=f(N, H), t1pre=f(N, H), sap=f(N, H),
@@ -82,11 +82,17 @@ class UnsupDepthEngine:
         self.heads, self.L = module.n_head, module.num_decoder_layers
         self.dh = self.H // self.heads
         self.pad_idx = module.src_pad_idx
-        self.P, self.D = module.depth_projection.in_features, module.input_embed.in_features
+        # label_query: model/futr_proposed.py -- the decoder query is nn.Embedding(label indices) + a sinusoidal table
+        # (:103-106), the memory carries no positional encoding (:92-97) and fc_seg has n_class - 1 outputs (:38)
+        self.label_query = not hasattr(module, "depth_projection")
+        self.D = module.input_embed.in_features
+        self.P = None if self.label_query else module.depth_projection.in_features
+        self.Kseg = module.fc_seg.out_features
         assert self.H % 8 == 0 and self.H % self.heads == 0
         self.arena = _Arena(list(module.named_parameters()), self.device)
         self.pe = module.pos_enc.pos_table[0]                     # [3000, H] sinusoid buffer (position.py:19-27)
-        self.pe_depth = module.pos_enc_depth.pos_table[0]
+        self.pe_depth = None if self.label_query else module.pos_enc_depth.pos_table[0]
+        self.pe_l3 = module.positional_embedding_l3.to(self.device).contiguous() if self.label_query else None
         self.ws = ops.GemmWorkspace(self.device)
         self.dropout_enabled = bool(getattr(module, "r3d_dropout_enabled", True))
         self.erank_weight = 0.0                # (the rank penalty is defined on the fuser's tokens; this model has no fuser)
@@ -128,10 +134,16 @@ class UnsupDepthEngine:
         a, H, Q, K, heads, dh = self.arena, self.H, self.Q, self.K, self.heads, self.dh
         B, S = feats.shape[0], feats.shape[1]
         N, BQ = B * S, B * Q
-        assert feats.is_cuda and depth.is_cuda and feats.dtype == torch.float32 and depth.dtype == torch.float32
-        x_rgb, x_dep = feats.reshape(N, -1), depth.reshape(N, -1)
-        assert x_rgb.shape[1] == self.D and x_dep.shape[1] == self.P, (x_rgb.shape, x_dep.shape, self.D, self.P)
-        assert x_rgb.is_contiguous() and x_dep.is_contiguous()
+        assert feats.is_cuda and depth.is_cuda and feats.dtype == torch.float32
+        x_rgb = feats.reshape(N, -1)
+        assert x_rgb.shape[1] == self.D and x_rgb.is_contiguous()
+        if self.label_query:                                       # `depth` holds the label indices of the queries [B, S]
+            assert depth.dtype == torch.int64 and depth.numel() == N and depth.is_contiguous()
+            x_dep = depth.reshape(N)
+        else:
+            assert depth.dtype == torch.float32
+            x_dep = depth.reshape(N, -1)
+            assert x_dep.shape[1] == self.P and x_dep.is_contiguous(), (x_dep.shape, self.P)
         w = self._shape(B, S, need_grad)
         drop = training and need_grad and self.dropout_enabled
         if drop:
@@ -145,17 +157,24 @@ class UnsupDepthEngine:
         ws = self.ws
         # ---- RGB embedding: relu(x W^T + b) + pos_table, dropout (:93-99) -> decoder memory
         ops.gemm(GEMM_NT, x_rgb, a.p("input_embed.weight"), w.rgb, bias=a.p("input_embed.bias"), act=1, ws=ws)
-        ops.posenc_fwd(w.rgb, self.pe, S, w.mem, drop_mask=dm("pe_rgb"), drop_scale=dsc)
+        if self.label_query:
+            w.mem = w.rgb                                          # (futr_proposed.py:92-97: no encoding on the memory)
+            ops.embed_gather_fwd(a.p("query_embed.weight"), x_dep, self.pe_l3, S, w.qpos)      # (:103-106)
+        else:
+            ops.posenc_fwd(w.rgb, self.pe, S, w.mem, drop_mask=dm("pe_rgb"), drop_scale=dsc)
         # ---- depth embedding: relu(LN(x W^T + b)) + pos_table, dropout (:107-115) -> decoder query
-        d = ops.gemm(GEMM_NT, x_dep, a.p("depth_projection.weight"), w.dep_pre, bias=a.p("depth_projection.bias"), ws=ws,
+        d = None if self.label_query else ops.gemm(GEMM_NT, x_dep, a.p("depth_projection.weight"), w.dep_pre, bias=a.p("depth_projection.bias"), ws=ws,
                      defer_reduce=True)                      # (split-K: raw slabs, the LayerNorm launch sums them + bias)
-        if d.splitk > 1:
+        if d is None:
+            pass
+        elif d.splitk > 1:
             ops.layernorm_fwd(ws.buf, a.p("depth_layernorm.weight"), a.p("depth_layernorm.bias"), w.dep, w.mean_d, w.rstd_d,
                               relu=True, nsplit=d.splitk, bias=a.p("depth_projection.bias"), pre_out=w.dep_pre, rows=N, H=H)
         else:
             ops.layernorm_fwd(w.dep_pre, a.p("depth_layernorm.weight"), a.p("depth_layernorm.bias"), w.dep, w.mean_d,
                               w.rstd_d, relu=True)
-        ops.posenc_fwd(w.dep, self.pe_depth, S, w.qpos, drop_mask=dm("pe_dep"), drop_scale=dsc)
+        if not self.label_query:
+            ops.posenc_fwd(w.dep, self.pe_depth, S, w.qpos, drop_mask=dm("pe_dep"), drop_scale=dsc)
         # ---- segmentation head on the memory (:148; transformer.py:128 returns it untouched)
         ops.gemm(GEMM_NT, w.mem, a.p("fc_seg.weight"), w.seg, bias=a.p("fc_seg.bias"), ws=ws)
         # ---- decoder, post-norm (transformer.py:281-330): S queries per clip, query_pos = w.qpos (an activation)
@@ -192,12 +211,15 @@ class UnsupDepthEngine:
         ops.avgpool_rows_fwd(w.tgtF, w.pooled, B, S, Q)
         ops.gemm(GEMM_NT, w.pooled, self.w_head, w.actdur, bias=self.b_head, ws=ws)
         self.last = dict(w=w, x_rgb=x_rgb, x_dep=x_dep, drop=drop, mode=mode, tp=None)
-        return dict(seg=w.seg.view(B, S, K), action=w.actdur[:, :K].view(B, Q, K), duration=w.actdur[:, K].view(B, Q))
+        return dict(seg=w.seg.view(B, S, self.Kseg), action=w.actdur[:, :K].view(B, Q, K), duration=w.actdur[:, K].view(B, Q))
 
     # ------------------------------------------------------------------------------------------------------
     def losses(self, past_label, target, target_dur, with_grad=True, val_mode=False, tick=False):
         """The 3 losses + counters of train_proposed_depth.py:171-213 in one launch; fills d_seg / d_actdur."""
         w, K = self.last["w"], self.K
+        if self.label_query:
+            raise NotImplementedError("the fused loss kernel belongs to train_proposed_depth.py's composition; the label-query "
+                                      "model's loop (train/train_unsupervised.py) is out of scope -- use the autograd bridge")
         ta = self.step_t if tick else None
         tb = self.drop_offset if (tick and self.last["drop"]) else None
         ops.losses_fwd_bwd(None if val_mode else w.seg, w.actdur[:, :K], w.actdur[:, K:], K + 1, past_label, target,
@@ -282,8 +304,11 @@ class UnsupDepthEngine:
         # ---- memory: decoder part + segmentation head part; through the encoding's dropout and the ReLU (:97-99)
         wgrad(w.d_seg, w.mem, a.g("fc_seg.weight"), a.g("fc_seg.bias"))
         ops.gemm(GEMM_NN, w.d_seg, a.p("fc_seg.weight"), w.d_mem, res1=w.d_mp, ws=ws)
-        ops.posenc_bwd(w.d_mem, w.d_rgb_pre, drop_mask=dmf("pe_rgb"), drop_scale=dsc, gate=w.rgb)
+        ops.posenc_bwd(w.d_mem, w.d_rgb_pre, drop_mask=None if self.label_query else dmf("pe_rgb"), drop_scale=dsc, gate=w.rgb)
         wgrad(w.d_rgb_pre, st["x_rgb"], a.g("input_embed.weight"), a.g("input_embed.bias"))
+        if self.label_query:                                       # the lookup's adjoint (futr_proposed.py:103)
+            ops.embed_gather_bwd(w.d_qpos, st["x_dep"], a.g("query_embed.weight"))
+            return
         # ---- query: through the encoding's dropout, ReLU + LayerNorm (:110-115), into the depth projection (:109)
         ops.posenc_bwd(w.d_qpos, w.d_dep, drop_mask=dmf("pe_dep"), drop_scale=dsc)
         ln_bwd(w.d_dep, w.dep_pre, w.mean_d, w.rstd_d, "depth_layernorm.weight", "depth_layernorm.bias", w.d_dep_pre,

@@ -127,7 +127,7 @@ class _Forward(torch.autograd.Function):
         if d_seg is None:
             w.d_seg.zero_()
         else:
-            w.d_seg.copy_(d_seg.reshape(-1, K))
+            w.d_seg.copy_(d_seg.reshape(w.d_seg.shape))
         eng.backward()
         grads = [eng.arena.g(n).clone() if eng.arena.is_live(n) else None for n in ctx.names]
         return (None,) * 7 + tuple(grads)

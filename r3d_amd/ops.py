@@ -679,3 +679,18 @@ def avgpool_rows_bwd(dy, dx, B, S, Q):
     H = dy.shape[1]
     assert dy.shape[0] == B * Q and tuple(dx.shape) == (B * S, H)
     check(_lib.load().r3d_avgpool_rows_bwd(_p(dy), _ld(dy), _p(dx), _ld(dx), B, S, Q, H, _stream()), "r3d_avgpool_rows_bwd")
+
+
+def embed_gather_fwd(weight, idx, table, S, out):
+    """out[r] = weight[idx[r]] + table[r % S] (model/futr_proposed.py:103-106)."""
+    rows, H = out.shape
+    assert idx.dtype == torch.int64 and idx.is_contiguous() and idx.numel() == rows and weight.is_contiguous()
+    check(_lib.load().r3d_embed_gather_fwd(_p(weight), weight.shape[0], _p(idx), _p(table), _ld(table), S, _p(out), _ld(out), rows,
+                                           H, _stream()), "r3d_embed_gather_fwd")
+
+
+def embed_gather_bwd(d_out, idx, d_weight):
+    rows, H = d_out.shape
+    assert idx.dtype == torch.int64 and idx.is_contiguous() and d_weight.is_contiguous() and d_weight.shape[1] == H
+    check(_lib.load().r3d_embed_gather_bwd(_p(d_out), _ld(d_out), _p(idx), _p(d_weight), d_weight.shape[0], rows, H, _stream()),
+          "r3d_embed_gather_bwd")
