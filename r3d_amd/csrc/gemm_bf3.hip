@@ -332,6 +332,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf3_nt_kernel(const r3d_gemm_desc
             }
             __syncthreads();
         }
+        if (nk & 1) __syncthreads();                                // (the producers' loop runs whole pairs of k-steps)
         // raw partial sums -> slab `split` (C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -411,15 +412,19 @@ __global__ __launch_bounds__(512, 1) void gemm_bf3_nt_kernel(const r3d_gemm_desc
         load_stage(s0, min(2, last));
         __syncthreads();                                            // stage 0 written
         // step kt: tile kt + 1 (register stage) -> the other image; refill that register stage with tile kt + 3
+        // (straight-line body: with an exit between the two halves the compiler re-rolls the loop, rotates the two register
+        //  stages through copies and has to wait for the NEWEST loads at every copy -- s_waitcnt vmcnt(0) once per k-step,
+        //  the whole prefetch distance lost.  An odd nk runs one surplus half whose image nobody reads; the consumers
+        //  match its barrier.)
         for (int kt = 0; kt < nk; kt += 2) {
             store_stage(lds16 + STAGE, s1, min(kt + 1, last));
             load_stage(s1, min(kt + 3, last));
+            __builtin_amdgcn_sched_barrier(0);                      // (keeps the other stage's split below these loads)
             __syncthreads();
-            if (kt + 1 < nk) {
-                store_stage(lds16, s0, min(kt + 2, last));
-                load_stage(s0, min(kt + 4, last));
-                __syncthreads();
-            }
+            store_stage(lds16, s0, min(kt + 2, last));
+            load_stage(s0, min(kt + 4, last));
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
         }
     }
 }
@@ -523,6 +528,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf3_tn_kernel(const r3d_gemm_desc
             }
             __syncthreads();
         }
+        if (nk & 1) __syncthreads();                                // (the producers' loop runs whole pairs of k-steps)
         // C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
         const float alpha = d.alpha;
         const bool accum = d.accumulate != 0;
@@ -590,15 +596,15 @@ __global__ __launch_bounds__(512, 1) void gemm_bf3_tn_kernel(const r3d_gemm_desc
         store_stage(lds16, s0, 0);
         load_stage(s0, min(2, last));
         __syncthreads();                                            // stage 0 written
-        for (int kt = 0; kt < nk; kt += 2) {
+        for (int kt = 0; kt < nk; kt += 2) {                        // (straight-line pairs: see gemm_bf3_nt_kernel)
             store_stage(lds16 + STAGE, s1, min(kt + 1, last));
             load_stage(s1, min(kt + 3, last));
+            __builtin_amdgcn_sched_barrier(0);                      // (keeps the other stage's split below these loads)
             __syncthreads();
-            if (kt + 1 < nk) {
-                store_stage(lds16, s0, min(kt + 2, last));
-                load_stage(s0, min(kt + 4, last));
-                __syncthreads();
-            }
+            store_stage(lds16, s0, min(kt + 2, last));
+            load_stage(s0, min(kt + 4, last));
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
         }
     }
 }
