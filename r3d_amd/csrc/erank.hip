@@ -12,8 +12,9 @@
 // G = 64 when there are fewer pairs than that).  Each lane keeps its rows of both columns in registers between the dot
 // product and the rotation; the squared column norms are cached in LDS and updated by the rotation
 // (alpha' = alpha - t gamma, beta' = beta + t gamma; recomputed exactly at the start of every sweep), so a pair costs ONE
-// reduction (gamma), done with v_add_f32_dpp row_ror butterflies -- no LDS crossbar traffic.  Sweeps repeat until no
-// pair exceeds |gamma| > tol * sqrt(alpha * beta), tol = sqrt(R) * eps_f32 (the sgesvj criterion), or max_sweeps.
+// reduction (gamma), done with v_add_f32_dpp row_ror butterflies -- no LDS crossbar traffic.  A pair is rotated when
+// |gamma| > tol * sqrt(alpha * beta), tol = sqrt(R) * eps_f32 (the sgesvj criterion); sweeps repeat until one starts with
+// every coupling below kStop (see there), or max_sweeps.
 // Outputs: singular values (unsorted), entropy, erank, sweep count and optionally the rotated columns
 // Af^T = (X V)^T [C][R], from which the backward  dX = Af diag(g / sigma^3) (Af^T X)  is two MFMA GEMMs
 // (U diag(g) V^T with V^T = Sigma^-2 Af^T X; no accumulation of V in the sweep).
@@ -25,6 +26,15 @@
 namespace r3d {
 
 constexpr int kJacThreads = 1024;
+// Sweeps stop after the first sweep in which no pair's coupling |gamma| / sqrt(alpha beta) exceeded kStop (measured before
+// its rotation; every pair above tol is still rotated in that sweep).  Jacobi converges quadratically at the end: a sweep
+// that starts below kStop leaves couplings of order kStop^2, i.e. singular values good to ~kStop^4 and singular
+// directions to ~kStop^2 -- the sweep that would only confirm "nothing left to rotate" (and the one before it, whose
+// rotations are below what erank, +-0.5, and its gradient, 1e-2, can see) is not run.
+#ifndef R3D_ERANK_STOP
+#define R3D_ERANK_STOP 1e-2f
+#endif
+constexpr float kStop2 = R3D_ERANK_STOP * R3D_ERANK_STOP;
 
 template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
@@ -69,10 +79,11 @@ template <int G> __device__ __forceinline__ float col_norm2(const float4* col, i
 // holds the column's slice of the accumulated right singular basis V when a warm start is kept, see ErankArgs::vt_out).
 // NCH > 0: every lane holds its NCH chunks of both columns in registers (needs NCH * G >= S4; EXACT: NCH * G == S4 and
 // D4 == nchd * G, no bounds checks, all LDS reads issued before the first use); NCH == 0: any length, two passes over
-// LDS.  Returns true when the pair was rotated.
+// LDS.  Returns true when the pair's coupling exceeded the CONTINUE threshold gamma^2 > stop2 alpha beta (it is rotated
+// whenever it exceeds the much smaller tol2).
 template <int G, int NCH, bool EXACT>
 __device__ __forceinline__ bool jac_pair(float4* A4, float* nrm, int S4, int D4, int nchd, int i, int j, int lg, float tol2,
-                                         float negl) {
+                                         float negl, float stop2) {
     float4* ai = A4 + (size_t)i * S4;
     float4* aj = A4 + (size_t)j * S4;
     float4 u[NCH > 0 ? NCH : 1], v[NCH > 0 ? NCH : 1];
@@ -120,7 +131,7 @@ __device__ __forceinline__ bool jac_pair(float4* A4, float* nrm, int S4, int D4,
         }
         if (lg == 0) { nrm[i] = fmaxf(al - t * ga, 0.f); nrm[j] = be + t * ga; }
     }
-    return rot;
+    return rot && ga * ga > stop2 * al * be;
 }
 
 struct ErankArgs {
@@ -219,7 +230,7 @@ __global__ __launch_bounds__(kJacThreads) void erank_jacobi_kernel(const ErankAr
             for (int k = slot; k < npairs; k += nslots) {
                 int i, j;
                 rr_pair(Cp, rd, k, i, j);
-                my_rot |= jac_pair<G, NCH, EXACT>(A4, nrm, S4, Rp4, nchd, i, j, lg, tol2, negl);
+                my_rot |= jac_pair<G, NCH, EXACT>(A4, nrm, S4, Rp4, nchd, i, j, lg, tol2, negl, kStop2);
             }
             __syncthreads();
         }
@@ -339,7 +350,7 @@ __global__ __launch_bounds__(kJacThreads) void erank_blk_round_kernel(ErankBlk g
             int i, j;
             if (mode == 0) rr_pair(b, t, k, i, j);
             else { i = k; j = k + t; if (j >= b) j -= b; j += b; }
-            my_rot |= jac_pair<G, NCH, EXACT>(A4, nrm, Rp4, Rp4, Rp4 / G, i, j, lg, tol2, negl);
+            my_rot |= jac_pair<G, NCH, EXACT>(A4, nrm, Rp4, Rp4, Rp4 / G, i, j, lg, tol2, negl, kStop2);
         }
         __syncthreads();
     }
