@@ -102,6 +102,86 @@ def save_checkpoint(model, path, data_parallel_keys=False):
 # ---------------------------------------------------------------------------------------------------------------------
 # device-resident input pipeline
 # ---------------------------------------------------------------------------------------------------------------------
+class NpyClipReader:
+    """Feature / depth rows of a batch of clips straight from the per-video `.npy` files the reference's preprocessing
+    writes (data/nturgbd-preprocess-depth.py:118, utkinect-preprocess-depth.py:133: `[frames, 1, h, w]` float32; RGB
+    features `[frames, 2048]`) into PINNED, reused staging buffers -- the host half of "depth .npy -> pinned -> async
+    copy" (SURVEY.md 8(f).2).  The reference goes file -> ndarray (np.load, whole video) -> slice -> torch.tensor (copy)
+    -> pad_sequence (copy) -> .to(device) (pageable, synchronous): basedataset_darai_depth.py:110-130,176,199-203 and
+    train_proposed_depth.py:132-137.  Here the files are memory-mapped (only the sampled frames are read), each sampled
+    frame is copied ONCE, into its place in a pinned `[B, S_max, ...]` buffer (zero padding as `pad_sequence(batch_first=
+    True, padding_value=0)` leaves it), and InputPrefetcher's side stream moves that buffer while the previous step runs.
+    Labels / targets are the caller's (a few hundred bytes; the transcript logic of BaseDataset stays the reference's).
+
+    clip spec = (feature_file, depth_file, start, stop, step): rows `start:stop:step` of both files, as the dataset's
+    observed-range slice and sample_rate produce them (:129-130).  `slots` buffers rotate, so a batch stays valid while
+    the next `slots - 1` are being filled (InputPrefetcher holds at most two)."""
+
+    def __init__(self, slots=3, pin=None, workers=8):
+        self.slots, self._bufs, self._turn = max(2, int(slots)), {}, 0
+        self.pin = torch.cuda.is_available() if pin is None else bool(pin)
+        self._maps = {}
+        # one copy job per clip: numpy's copies release the GIL, and a single thread moves ~10 GB/s -- 2.7 ms for the
+        # 27 MB batch of the bench shape, ten training steps' worth
+        self._pool = None
+        if workers and workers > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=int(workers))
+
+    def _open(self, path):
+        m = self._maps.get(path)
+        if m is None:
+            m = np.load(path, mmap_mode="r")                         # .npy only: nothing in the file is executed
+            if len(self._maps) >= 64:                                # (bounded: a descriptor and a mapping per file)
+                self._maps.pop(next(iter(self._maps)))
+            self._maps[path] = m
+        return m
+
+    def _buf(self, key, shape):
+        ring = self._bufs.setdefault(key, [])
+        slot = self._turn % self.slots
+        while len(ring) <= slot:
+            ring.append(None)
+        b = ring[slot]
+        if b is None or tuple(b.shape[1:]) != tuple(shape[1:]) or b.shape[0] < shape[0]:
+            b = torch.empty(shape, dtype=torch.float32, pin_memory=self.pin)
+            ring[slot] = b
+        return b[:shape[0]]
+
+    def batch(self, clips):
+        """-> (features [B, S_max, D], depth [B, S_max, *frame_shape]) float32, zero-padded, in pinned memory."""
+        rows = [range(*slice(c[2], c[3], c[4]).indices(self._open(c[0]).shape[0])) for c in clips]
+        S = max((len(r) for r in rows), default=0)
+        f0, d0 = self._open(clips[0][0]), self._open(clips[0][1])
+        feats = self._buf("f", (len(clips), S) + tuple(f0.shape[1:]))
+        depth = self._buf("d", (len(clips), S) + tuple(d0.shape[1:]))
+        self._turn += 1
+        fn, dn = feats.numpy(), depth.numpy()                        # (views of the pinned storage)
+        maps = [(self._open(c[0]), self._open(c[1])) for c in clips]
+
+        CH = max(S, 1)            # one copy job per clip (jobs of 8 frames on 16 threads measured slower: 1035 vs 773 us)
+
+        def fill(job):
+            b, lo = job
+            (f, d), r = maps[b], rows[b]
+            n = min(len(r), f.shape[0], d.shape[0]) if len(r) else 0
+            hi = min(lo + CH, S)
+            m = max(0, min(hi, n) - lo)                              # real frames in [lo, hi); the rest is padding
+            if m:
+                sl = slice(r.start + lo * r.step, r.start + (lo + m) * r.step, r.step)
+                fn[b, lo:lo + m] = f[sl]
+                dn[b, lo:lo + m] = d[sl]
+            fn[b, lo + m:hi] = 0
+            dn[b, lo + m:hi] = 0
+        jobs = [(b, lo) for b in range(len(clips)) for lo in range(0, S, CH)]
+        if self._pool is not None and len(jobs) > 1:
+            list(self._pool.map(fill, jobs))
+        else:
+            for j in jobs:
+                fill(j)
+        return feats, depth
+
+
 class InputPrefetcher:
     """Wraps any iterable of the 5-tuple batches of BaseDataset.my_collate (basedataset_darai_depth.py:185-206) and keeps
     the NEXT batch on the device while the current step runs: pinned staging buffers + async copies on a side stream.

@@ -54,6 +54,65 @@ def test_input_prefetcher_feeds_the_same_training(tmp_path):
     assert torch.equal(finals[0], finals[1])
 
 
+def test_npy_files_through_pinned_reader_and_prefetcher_train_identically(tmp_path):
+    """SURVEY.md 8(f).2 end to end: the batches' feature / depth rows written as per-video `.npy` files, read back by
+    NpyClipReader into pinned staging buffers and moved by InputPrefetcher's side stream, train to the same parameters
+    (bitwise) as the tensors handed over directly."""
+    import numpy as np
+    from r3d_amd.train_proposed_depth import train
+    from r3d_amd.optim import FlatAdamW
+    from r3d_amd.utils import InputPrefetcher, NpyClipReader
+    fx = load_fixture("train_loop")
+    m = fx["meta"]
+    batches = [[t for t in fixture_batch(fx, seed=400 + i)] for i in range(3)]
+    val = [[t[:1] for t in fixture_batch(fx, seed=300)]]
+    specs = []
+    for i, b in enumerate(batches):                                   # one "video" per clip, with frames before and after
+        clips = []
+        for c in range(b[0].shape[0]):
+            S = b[0].shape[1]
+            pre, post = 3 + c, 2
+            f = np.concatenate([np.full((pre,) + tuple(b[0].shape[2:]), 7.0, np.float32), b[0][c].numpy(),
+                                np.full((post,) + tuple(b[0].shape[2:]), 9.0, np.float32)])
+            d = np.concatenate([np.full((pre,) + tuple(b[1].shape[2:]), 7.0, np.float32), b[1][c].numpy(),
+                                np.full((post,) + tuple(b[1].shape[2:]), 9.0, np.float32)])
+            fp, dp = tmp_path / f"b{i}c{c}.npy", tmp_path / f"b{i}c{c}_1.npy"
+            np.save(fp, f)
+            np.save(dp, d)
+            clips.append((str(fp), str(dp), pre, pre + S, 1))
+        specs.append(clips)
+    rd = NpyClipReader()
+    assert rd.pin
+
+    def from_files():
+        for clips, b in zip(specs, batches):
+            f, d = rd.batch(clips)
+            assert f.is_pinned() and d.is_pinned()
+            yield [f, d, b[2], b[3], b[4]]
+
+    class Loader:                                                      # (train() wants len() for its epoch print)
+        def __iter__(self):
+            return from_files()
+
+        def __len__(self):
+            return len(batches)
+    finals = []
+    for files in (False, True):
+        model = build_model(fx)
+        args = argparse.Namespace(epochs=1, input_type="i3d_transcript", seg=True, anticipate=True, task="long", min_batch=1)
+        opt = FlatAdamW(model.parameters(), 1e-3, weight_decay=5e-3)
+
+        class NoSched:
+            def step(self):
+                pass
+        model.eval()
+        loader = InputPrefetcher(Loader(), "cuda") if files else batches
+        train(args, model, loader, opt, NoSched(), None, str(tmp_path), m["pad_idx"], torch.device("cuda"), val, seed=1)
+        torch.cuda.synchronize()
+        finals.append(model.engine().arena.params.clone())
+    assert torch.equal(finals[0], finals[1])
+
+
 def test_train_harness_matches_reference_capture(tmp_path, capsys):
     """r3d_amd.train_proposed_depth.train() -- loop, epoch prints, validate(), checkpoint-on-improve -- against the capture
     of the reference's own train() on the same batches (tests/golden/train_loop.npz: its stdout, validate() result and

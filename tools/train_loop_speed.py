@@ -2,7 +2,9 @@
 """Steps/s of r3d_amd.train_proposed_depth.train() itself (the drop-in loop, not bench.py's captured step) on synthetic
 batches of the headline shape: device-resident (default) or `--host`: pinned HOST batches through
 r3d_amd.utils.InputPrefetcher -- the PCIe-inclusive rate (27 MB of inputs per step cross the bus under the previous step).
-    python tools/train_loop_speed.py [--graph] [--host]"""
+`--npy`: the same batches as per-clip `.npy` files (in /dev/shm: page-cache resident) read by r3d_amd.utils.NpyClipReader into
+pinned staging buffers, then InputPrefetcher -- the whole real-data input path minus the disk.
+    python tools/train_loop_speed.py [--graph] [--host | --npy]"""
 import argparse, os, sys, time, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -20,6 +22,33 @@ def main():
         from r3d_amd.utils import InputPrefetcher
         pinned = [[t.cpu().pin_memory() for t in b] for b in batches[:4]]
         batches = InputPrefetcher(pinned * 500, dev)
+    npy = "--npy" in sys.argv
+    shm = None
+    if npy:
+        import numpy as np, shutil
+        from r3d_amd.utils import InputPrefetcher, NpyClipReader
+        shm = tempfile.mkdtemp(dir="/dev/shm")
+        host4 = [[t.cpu() for t in b] for b in batches[:4]]
+        specs = []
+        for i, b in enumerate(host4):
+            clips = []
+            for k in range(b[0].shape[0]):
+                fp, dp = os.path.join(shm, f"b{i}c{k}.npy"), os.path.join(shm, f"b{i}c{k}_1.npy")
+                np.save(fp, b[0][k].numpy()); np.save(dp, b[1][k].numpy())
+                clips.append((fp, dp, 0, b[0].shape[1], 1))
+            specs.append(clips)
+        rd = NpyClipReader()
+
+        class Loader:
+            def __iter__(self):
+                for j in range(2000):
+                    f, d = rd.batch(specs[j % 4])
+                    yield [f, d] + [t.pin_memory() if not t.is_pinned() else t for t in host4[j % 4][2:]]
+
+            def __len__(self):
+                return 2000
+        batches = InputPrefetcher(Loader(), dev)
+        host = True
     val = [[t[:1] for t in make_inputs(c, dev, seed=99)]]
     args = argparse.Namespace(epochs=1, input_type="i3d_transcript", seg=True, anticipate=True, task="long",
                               graph_steps=("--graph" in sys.argv))
@@ -34,7 +63,9 @@ def main():
         train(args, model, batches, opt, NoSched(), None, d, c["K"] + 1, dev, val, seed=1)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
     n = len(batches)
-    print(("host batches over PCIe (InputPrefetcher), " if host else "device-resident batches, ") +
+    if shm:
+        shutil.rmtree(shm, ignore_errors=True)
+    print((".npy files -> NpyClipReader (pinned) -> InputPrefetcher, " if npy else "host batches over PCIe (InputPrefetcher), " if host else "device-resident batches, ") +
           ("hipGraph steps: " if "--graph" in sys.argv else "enqueued steps: "), end="")
     print(f"train(): {n} steps in {dt:.3f}s -> {dt / n * 1e6:.0f} us/step, {c['B'] * n / dt:.0f} clips/s (incl. 1 validation + checkpoint)")
 
