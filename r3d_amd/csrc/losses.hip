@@ -27,16 +27,24 @@ __device__ __forceinline__ float ce_row(const float* logit, int K, int64_t label
                                         float gscale, float* dl, int lane, int* argmax_out) {
     float m = -INFINITY;
     int am = 0x7fffffff;
-    for (int c = lane; c < K; c += 64) {
-        const float x = logit[c];
-        if (x > m || (x == m && c < am)) { m = x; am = c; }
-    }
-    // wave arg-max: largest value, smallest index among equals (first occurrence, as torch.max on CPU)
+    if (K <= 64) {
+        // one class per lane: the maximum by DPP, its first occurrence (smallest index, as torch.max on CPU) by ballot
+        const float x = lane < K ? logit[lane] : -INFINITY;
+        m = wave_max(x);
+        const unsigned long long hit = __ballot(lane < K && x == m);
+        am = hit ? __builtin_ctzll(hit) : 0x7fffffff;
+    } else {
+        for (int c = lane; c < K; c += 64) {
+            const float x = logit[c];
+            if (x > m || (x == m && c < am)) { m = x; am = c; }
+        }
+        // wave arg-max: largest value, smallest index among equals
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const float om = __shfl_xor(m, off, 64);
-        const int oa = __shfl_xor(am, off, 64);
-        if (om > m || (om == m && oa < am)) { m = om; am = oa; }
+        for (int off = 32; off > 0; off >>= 1) {
+            const float om = __shfl_xor(m, off, 64);
+            const int oa = __shfl_xor(am, off, 64);
+            if (om > m || (om == m && oa < am)) { m = om; am = oa; }
+        }
     }
     *argmax_out = am;
     float se = 0.f;
@@ -300,6 +308,15 @@ __global__ __launch_bounds__(512) void tail_losses_kernel(const r3d_tail_losses_
         float keep[2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) keep[e] = t.drop ? t.drop_scale * (float)t.drop[(size_t)row * H + cc[e]] : 1.f;
+        // ... and the clip's labels, targets and durations (S <= 64, B*Q <= 64: one per lane -- validated by the host):
+        // one round trip under the forward tail instead of four dependent ones after the barrier
+        const bool small = a.S <= 64 && BQ <= 64;                    // (beyond that the label / mask scans loop, below)
+        const int64_t pl_pre = a.past_label[(size_t)b * a.S + (lane < a.S ? lane : 0)];
+        const int64_t tgt_first = a.target[(size_t)b * Q];
+        const int64_t tgt_row = a.target[row];
+        const float td_all = a.target_dur[lane < BQ ? lane : 0];
+        const float td_clip = a.target_dur[(size_t)b * Q + (lane < Q ? lane : 0)];
+        const float dden_pre = a.dur_den ? *a.dur_den : 0.f;
         // ---- forward tail: norm3 -> decoder.norm -> heads
         float y3[2], yF[2], m3, r3, mF, rF;
         ln2_apply(x, g3, b3, H, lane, y3, m3, r3);
@@ -327,14 +344,25 @@ __global__ __launch_bounds__(512) void tail_losses_kernel(const r3d_tail_losses_
         // ---- losses of this row: anticipation CE (cal_weighted_loss) ...
         float out_l, out_c, out_v;
         {
+            // last observed (non-pad) label of the clip: highest lane whose label is not the pad index
             int last = -1;
-            for (int s = lane; s < a.S; s += 64)
-                if (a.past_label[(size_t)b * a.S + s] != (int64_t)a.pad_idx) last = s;
+            int64_t ref = (int64_t)a.pad_idx;
+            if (small) {
+                const unsigned long long obs = __ballot(lane < a.S && pl_pre != (int64_t)a.pad_idx);
+                last = obs ? 63 - __builtin_clzll(obs) : -1;
+                const int lsel = __builtin_amdgcn_readfirstlane(last < 0 ? 0 : last);
+                const unsigned rlo = __builtin_amdgcn_readlane((unsigned)(unsigned long long)pl_pre, lsel);
+                const unsigned rhi = __builtin_amdgcn_readlane((unsigned)((unsigned long long)pl_pre >> 32), lsel);
+                if (last >= 0) ref = (int64_t)(((unsigned long long)rhi << 32) | rlo);
+            } else {
+                for (int s = lane; s < a.S; s += 64)
+                    if (a.past_label[(size_t)b * a.S + s] != (int64_t)a.pad_idx) last = s;
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) last = max(last, __shfl_xor(last, off, 64));
-            const int64_t ref = (last >= 0) ? a.past_label[(size_t)b * a.S + last] : (int64_t)a.pad_idx;
-            const float w = (ref == a.target[(size_t)b * Q]) ? 1.0f : 10.0f;
-            const int64_t lab = a.target[row];
+                for (int off = 32; off > 0; off >>= 1) last = max(last, __shfl_xor(last, off, 64));
+                if (last >= 0) ref = a.past_label[(size_t)b * a.S + last];
+            }
+            const float w = (ref == tgt_first) ? 1.0f : 10.0f;
+            const int64_t lab = tgt_row;
             const bool valid = (lab != (int64_t)a.pad_idx) && (lab != (int64_t)a.exclude_idx) && lab >= 0 && lab < K;
             int am;
             const float l = ce_row(&lg[wave][0], K, lab, valid, a.pad_idx, w * a.grad_scale / (float)BQ, &dl[wave][0], lane, &am);
@@ -349,31 +377,29 @@ __global__ __launch_bounds__(512) void tail_losses_kernel(const r3d_tail_losses_
         // wave 0 reports the clip's loss term)
         {
             float mc = 0.f;
-            for (int e = lane; e < BQ; e += 64) mc += (a.target_dur[e] != (float)a.pad_idx) ? 1.f : 0.f;
+            if (small) mc = (lane < BQ && td_all != (float)a.pad_idx) ? 1.f : 0.f;
+            else
+                for (int e = lane; e < BQ; e += 64) mc += (a.target_dur[e] != (float)a.pad_idx) ? 1.f : 0.f;
             mc = wave_sum(mc);
-            const float dur_den = a.dur_den ? *a.dur_den : mc;
-            float ssum = 0.f;
-            for (int q = lane; q < Q; q += 64) {
-                const float td = a.target_dur[(size_t)b * Q + q];
-                const float mk = (td != (float)a.pad_idx) ? 1.f : 0.f;
-                ssum += fabsf(expf(lg[q][K]) * mk);
-            }
-            ssum = wave_sum(ssum);
+            const float dur_den = a.dur_den ? dden_pre : mc;
+            const float mkq = (lane < Q && td_clip != (float)a.pad_idx) ? 1.f : 0.f;      // lane q < Q holds query q
+            const float eq = lane < Q ? expf(lg[lane < Q ? lane : 0][K]) * mkq : 0.f;
+            const float ssum = wave_sum(fabsf(eq));
             const float den = fmaxf(ssum, 1e-12f);
             float sq = 0.f, gp = 0.f;
-            for (int q = lane; q < Q; q += 64) {
-                const float td = a.target_dur[(size_t)b * Q + q];
-                const float mk = (td != (float)a.pad_idx) ? 1.f : 0.f;
-                const float p = expf(lg[q][K]) * mk / den;
-                const float tt = td * mk * mk;
+            if (lane < Q) {
+                const float p = eq / den;
+                const float tt = td_clip * mkq * mkq;
                 const float diff = p - tt;
-                sq += diff * diff;
-                gp += (2.f * diff / dur_den) * p;
+                sq = diff * diff;
+                gp = (2.f * diff / dur_den) * p;
             }
             sq = wave_sum(sq);
             gp = wave_sum(gp);
+            const float td_w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(unsigned, td_clip),
+                                                                                   __builtin_amdgcn_readfirstlane(wave)));
             if (lane == 0) {
-                const float td = a.target_dur[(size_t)b * Q + wave];
+                const float td = td_w;
                 const float mk = (td != (float)a.pad_idx) ? 1.f : 0.f;
                 const float p = expf(lg[wave][K]) * mk / den;
                 const float g = 2.f * (p - td * mk * mk) / dur_den;
