@@ -26,7 +26,7 @@ struct EmbedFwdArgs {
 
 template <int EPL>
 __global__ __launch_bounds__(256) void embed_fuse_fwd_kernel(const EmbedFwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float red[];       // [4 waves][2][H]
+    extern __shared__ __attribute__((aligned(16))) float red[];       // [8 partials = 4 waves x 2 halves][2 projections][H]
     const int n = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, H = a.H;
     const size_t stride = (size_t)a.N * H, rowo = (size_t)n * H;
     int cc[EPL];
@@ -44,39 +44,82 @@ __global__ __launch_bounds__(256) void embed_fuse_fwd_kernel(const EmbedFwdArgs 
         msk[e] = (t == 0 ? a.m_rgb : a.m_dep)[cc[e]];
         keep[e] = a.drop ? a.drop_scale * (float)a.drop[((size_t)2 * n + t) * H + cc[e]] : 1.f;
     }
-    // ---- slab sums: wave w takes slabs w, w+4, ... of both projections, 4 independent partial sums per column
-    float ar[EPL], ad[EPL];
+    // ---- slab sums: wave w takes slabs w, w+4, ... of both projections; `red` holds 8 partial rows per projection
+    const bool vec4 = EPL == 2 && (H & 3) == 0 &&
+                      (((uintptr_t)a.rgb_src | (uintptr_t)a.dep_src) & 15) == 0;
+    if (vec4) {
+        // H <= 128: a row is <= 32 float4, so the two half-waves take alternate slabs of the wave's set and every lane has
+        // ALL its loads (8 per projection and 64 slabs) in flight at once -- one memory round trip for the ~61 depth and
+        // the RGB slabs together instead of one per batch of eight scalar loads (all clamped, none under a branch)
+        const int j = lane >> 5, c4 = lane & 31, H4 = H >> 2;
+        const size_t st4 = stride >> 2;
+        const float4* pr = reinterpret_cast<const float4*>(a.rgb_src + rowo) + (c4 < H4 ? c4 : 0);
+        const float4* pd = reinterpret_cast<const float4*>(a.dep_src + rowo) + (c4 < H4 ? c4 : 0);
+        auto slab_sum = [&](const float4* p, int ns) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int base = 0; base < ns; base += 64) {
+                float4 v[8];
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) {
-        float s4[4] = {0.f, 0.f, 0.f, 0.f};
-        if (a.ns_r > 0) {
-            const float* p = a.rgb_src + rowo + cc[e];
-            int s = wave;
-            for (; s + 12 < a.ns_r; s += 16) {
+                for (int i = 0; i < 8; ++i) {
+                    const int sl = base + wave + 4 * (2 * i + j);
+                    v[i] = p[(size_t)(sl < ns ? sl : ns - 1) * st4];
+                }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) s4[q] += p[(size_t)(s + 4 * q) * stride];
+                for (int i = 0; i < 8; ++i)
+                    if (base + wave + 4 * (2 * i + j) >= ns) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#define R3D_A4(P_, Q_) make_float4(P_.x + Q_.x, P_.y + Q_.y, P_.z + Q_.z, P_.w + Q_.w)
+                const float4 t01 = R3D_A4(v[0], v[1]), t23 = R3D_A4(v[2], v[3]), t45 = R3D_A4(v[4], v[5]), t67 = R3D_A4(v[6], v[7]);
+                const float4 t03 = R3D_A4(t01, t23), t47 = R3D_A4(t45, t67), tt = R3D_A4(t03, t47);
+                acc = R3D_A4(acc, tt);
+#undef R3D_A4
             }
-            for (; s < a.ns_r; s += 4) s4[0] += p[(size_t)s * stride];
-        } else if (wave == 0) {
-            s4[0] = a.rgb_src[rowo + cc[e]];
+            return acc;
+        };
+        float4 ra = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.ns_r > 0) ra = slab_sum(pr, a.ns_r);
+        else if (wave == 0 && j == 0) ra = pr[0];
+        const float4 da = slab_sum(pd, a.ns_d);
+        if (c4 < H4) {
+            *reinterpret_cast<float4*>(red + ((size_t)(wave * 2 + j) * 2 + 0) * H + 4 * c4) = ra;
+            *reinterpret_cast<float4*>(red + ((size_t)(wave * 2 + j) * 2 + 1) * H + 4 * c4) = da;
         }
-        ar[e] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
-        float d8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // depth: ~61 slabs -> 8 loads in flight per column
-        {
-            const float* p = a.dep_src + rowo + cc[e];
-            int s = wave;
-            for (; s + 28 < a.ns_d; s += 32) {
+    } else {
+        float ar[EPL], ad[EPL];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) d8[q] += p[(size_t)(s + 4 * q) * stride];
+        for (int e = 0; e < EPL; ++e) {
+            float s4[4] = {0.f, 0.f, 0.f, 0.f};
+            if (a.ns_r > 0) {
+                const float* p = a.rgb_src + rowo + cc[e];
+                int s = wave;
+                for (; s + 12 < a.ns_r; s += 16) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) s4[q] += p[(size_t)(s + 4 * q) * stride];
+                }
+                for (; s < a.ns_r; s += 4) s4[0] += p[(size_t)s * stride];
+            } else if (wave == 0) {
+                s4[0] = a.rgb_src[rowo + cc[e]];
             }
-            for (int q = 0; s < a.ns_d; s += 4, ++q) d8[q & 7] += p[(size_t)s * stride];
-        }
-        ad[e] = ((d8[0] + d8[1]) + (d8[2] + d8[3])) + ((d8[4] + d8[5]) + (d8[6] + d8[7]));
-    }
+            ar[e] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+            float d8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // depth: ~61 slabs -> 8 loads in flight per column
+            {
+                const float* p = a.dep_src + rowo + cc[e];
+                int s = wave;
+                for (; s + 28 < a.ns_d; s += 32) {
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) {
-        const int c = lane + 64 * e;
-        if (c < H) { red[(wave * 2 + 0) * H + c] = ar[e]; red[(wave * 2 + 1) * H + c] = ad[e]; }
+                    for (int q = 0; q < 8; ++q) d8[q] += p[(size_t)(s + 4 * q) * stride];
+                }
+                for (int q = 0; s < a.ns_d; s += 4, ++q) d8[q & 7] += p[(size_t)s * stride];
+            }
+            ad[e] = ((d8[0] + d8[1]) + (d8[2] + d8[3])) + ((d8[4] + d8[5]) + (d8[6] + d8[7]));
+        }
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const int c = lane + 64 * e;
+            if (c < H) {
+                red[((size_t)(wave * 2) * 2 + 0) * H + c] = ar[e]; red[((size_t)(wave * 2) * 2 + 1) * H + c] = ad[e];
+                red[((size_t)(wave * 2 + 1) * 2 + 0) * H + c] = 0.f; red[((size_t)(wave * 2 + 1) * 2 + 1) * H + c] = 0.f;
+            }
+        }
     }
     __syncthreads();
     if (wave >= 2) return;
@@ -88,8 +131,11 @@ __global__ __launch_bounds__(256) void embed_fuse_fwd_kernel(const EmbedFwdArgs 
         const int c = lane + 64 * e;
         float vr = 0.f, vd = 0.f;
         if (c < H) {
-            vr = (red[0 * H + c] + red[2 * H + c]) + (red[4 * H + c] + red[6 * H + c]);
-            vd = (red[1 * H + c] + red[3 * H + c]) + (red[5 * H + c] + red[7 * H + c]) + bdp[e];
+            // partial k of projection q sits at red[(2 k + q) H + c]; k = 2 wave + half
+            vr = ((red[0 * H + c] + red[2 * H + c]) + (red[4 * H + c] + red[6 * H + c])) +
+                 ((red[8 * H + c] + red[10 * H + c]) + (red[12 * H + c] + red[14 * H + c]));
+            vd = ((red[1 * H + c] + red[3 * H + c]) + (red[5 * H + c] + red[7 * H + c])) +
+                 ((red[9 * H + c] + red[11 * H + c]) + (red[13 * H + c] + red[15 * H + c])) + bdp[e];
             if (a.ns_r > 0) vr = fmaxf(vr + br[e], 0.f);
         }
         r[e] = vr; dpre[e] = vd;
@@ -299,7 +345,7 @@ R3D_EXPORT int r3d_embed_fuse_fwd(const float* rgb_src, int ns_r, const float* b
     R3D_REQUIRE(N > 0 && H > 0 && H <= 1024 && ns_r >= 0 && ns_d >= 1);
     EmbedFwdArgs a{rgb_src, ns_r, bias_r, dep_src, ns_d, bias_d, lnd_gamma, lnd_beta, mask_rgb, mask_dep, drop_mask,
                    drop_scale, ln1_gamma, ln1_beta, rgb_out, dep_pre_out, mean_d, rstd_d, dep_out, x0, h1, m1, r1, N, H};
-    const size_t shmem = (size_t)8 * H * sizeof(float);
+    const size_t shmem = (size_t)16 * H * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
     if (H <= 128) hipLaunchKernelGGL(embed_fuse_fwd_kernel<2>, dim3(N), dim3(256), shmem, s, a);
     else if (H <= 512) hipLaunchKernelGGL(embed_fuse_fwd_kernel<8>, dim3(N), dim3(256), shmem, s, a);
