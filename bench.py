@@ -234,7 +234,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-graph", action="store_true", help="enqueue every step from Python instead of replaying hipGraphs")
-    ap.add_argument("--steps-per-graph", type=int, default=4,
+    ap.add_argument("--steps-per-graph", type=int, default=8,
                     help="one GPU: consecutive training steps captured into one hipGraph (consecutive graph launches leave "
                          "the GPU idle for ~8 us; a loader that stages this many batches ahead amortises it).  The timed "
                          "region still runs EXACTLY --steps steps (a remainder replays a one-step graph)")
