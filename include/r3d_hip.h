@@ -118,8 +118,11 @@ int r3d_gemm_plan(r3d_gemm_desc* d);
  * descriptors, fills tile/vec and prefix[0..n] (first workgroup of each problem; prefix[n] = grid size); the caller
  * copies both arrays to device memory once per shape and calls launch() every step. */
 int r3d_gemm_grouped_prepare(r3d_gemm_desc* descs, int n, int tile, int32_t* prefix);
-int r3d_gemm_grouped_launch(const r3d_gemm_desc* dev_descs, const int32_t* dev_prefix, int n, int total_tiles, int layout,
-                            int tile, void* stream);
+/* host_prefix (optional): the HOST copy of prefix[0..n]; with it, groups of <= 32 problems carry the table in the kernel
+ * arguments and a workgroup finds its problem without touching memory (the device-side search is a chain of dependent
+ * scalar loads in front of every workgroup's first operand load). */
+int r3d_gemm_grouped_launch(const r3d_gemm_desc* dev_descs, const int32_t* dev_prefix, const int32_t* host_prefix, int n,
+                            int total_tiles, int layout, int tile, void* stream);
 
 /* ---- row-wise kernels ---------------------------------------------------------------------------------------
  * LayerNorm (eps 1e-5, biased variance, affine): depth_layernorm (model/futr_safuser_tokenfusion.py:147,196),

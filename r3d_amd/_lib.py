@@ -92,7 +92,7 @@ _SIGNATURES = {
     "r3d_gemm_partial_floats": ([C.c_int32, C.c_int32, C.c_int32], C.c_int64),
     "r3d_gemm_plan": ([C.POINTER(GemmDesc)], C.c_int),
     "r3d_gemm_grouped_prepare": ([C.POINTER(GemmDesc), _I, _I, C.POINTER(C.c_int32)], C.c_int),
-    "r3d_gemm_grouped_launch": ([_P, _P, _I, _I, _I, _I, _P], C.c_int),
+    "r3d_gemm_grouped_launch": ([_P, _P, C.POINTER(C.c_int32), _I, _I, _I, _I, _P], C.c_int),
     "r3d_layernorm_fwd_multi": ([_P, _I, _P], C.c_int),
     "r3d_layernorm_bwd_multi": ([_P, _I, _P], C.c_int),
     "r3d_layernorm_bwd_finalize_batched": ([_P, _I, _I, _P], C.c_int),

@@ -582,18 +582,34 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_f32_kernel(const r3d_g
 
 // Many independent problems (same layout and tile config, splitk == 1) in one launch.  prefix[p] = first workgroup
 // of problem p, prefix[n] = grid size; descriptors live in device memory (uploaded once per shape by the host).
+// Groups of up to kGroupArgs problems carry the prefix table IN THE KERNEL ARGUMENTS (pf.v[p] = first workgroup of problem
+// p, INT_MAX beyond the last): the problem of a workgroup is found with scalar compares.  Searching the table in device
+// memory is a chain of log2(n) dependent scalar loads -- one L2 round trip each, in front of the descriptor load and the
+// operand loads of every workgroup of every grouped launch (nine per step).
+constexpr int kGroupArgs = 32;
+struct GroupPrefix { int v[kGroupArgs]; };
+
 template <int LA, int LB, int BM, int BN, int BK, int WM, int WN, int WK>
 __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_grouped_kernel(const r3d_gemm_desc* __restrict__ descs,
-                                                                    const int* __restrict__ prefix, int n) {
+                                                                    const int* __restrict__ prefix, int n,
+                                                                    const GroupPrefix pf, const int use_pf) {
     __shared__ __attribute__((aligned(16))) float smem[gemm_lds_floats<LA, LB, BM, BN, BK>()];
-    int lo = 0, hi = n;                      // largest p with prefix[p] <= blockIdx.x
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (prefix[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
+    int lo = 0, base = 0;                    // largest p with prefix[p] <= blockIdx.x, and that prefix
+    if (use_pf) {
+#pragma unroll
+        for (int p = 1; p < kGroupArgs; ++p)
+            if (pf.v[p] <= (int)blockIdx.x) { lo = p; base = pf.v[p]; }
+    } else {
+        int hi = n;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (prefix[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
+        }
+        base = prefix[lo];
     }
     const r3d_gemm_desc& d = descs[lo];
-    if (d.vec) gemm_body<LA, LB, BM, BN, BK, WM, WN, WK, true>(d, (int)blockIdx.x - prefix[lo], 0, smem);
-    else gemm_body<LA, LB, BM, BN, BK, WM, WN, WK, false>(d, (int)blockIdx.x - prefix[lo], 0, smem);
+    if (d.vec) gemm_body<LA, LB, BM, BN, BK, WM, WN, WK, true>(d, (int)blockIdx.x - base, 0, smem);
+    else gemm_body<LA, LB, BM, BN, BK, WM, WN, WK, false>(d, (int)blockIdx.x - base, 0, smem);
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const r3d_gemm_desc d, int nsplit) {
@@ -763,13 +779,19 @@ static int launch_layout(const r3d_gemm_desc& d, int nsplit, hipStream_t s) {
 }
 
 template <int LA, int LB>
-static int launch_grouped(const r3d_gemm_desc* descs, const int* prefix, int n, int total, int tile, hipStream_t s) {
+static int launch_grouped(const r3d_gemm_desc* descs, const int* prefix, const int32_t* host_prefix, int n, int total,
+                          int tile, hipStream_t s) {
+    GroupPrefix pf;
+    const int use_pf = (host_prefix && n <= kGroupArgs) ? 1 : 0;
+    for (int p = 0; p < kGroupArgs; ++p) pf.v[p] = (use_pf && p < n) ? host_prefix[p] : 0x7fffffff;
     switch (tile) {
         case 1:
-            hipLaunchKernelGGL((gemm_grouped_kernel<LA, LB, 32, 32, 64, 1, 1, 4>), dim3(total), dim3(256), 0, s, descs, prefix, n);
+            hipLaunchKernelGGL((gemm_grouped_kernel<LA, LB, 32, 32, 64, 1, 1, 4>), dim3(total), dim3(256), 0, s, descs, prefix, n,
+                               pf, use_pf);
             break;
         case 2:
-            hipLaunchKernelGGL((gemm_grouped_kernel<LA, LB, 64, 64, 64, 2, 2, 1>), dim3(total), dim3(256), 0, s, descs, prefix, n);
+            hipLaunchKernelGGL((gemm_grouped_kernel<LA, LB, 64, 64, 64, 2, 2, 1>), dim3(total), dim3(256), 0, s, descs, prefix, n,
+                               pf, use_pf);
             break;
         default: return R3D_EINVAL;
     }
@@ -951,7 +973,9 @@ R3D_EXPORT int r3d_splitk_reduce(const r3d_gemm_desc* dp, void* stream) {
 
 /* Host-side preparation of a problem group: validates the n descriptors (same layout, splitk == 1), fills their
  * `tile` (all get `tile`) and `vec` fields in place and writes prefix[0..n] (first workgroup of each problem).
- * The caller uploads descs and prefix to device memory once and replays r3d_gemm_grouped_launch every step. */
+ * The caller uploads descs and prefix to device memory once and replays r3d_gemm_grouped_launch every step; passing the
+ * HOST copy of prefix as well (host_prefix, optional) lets groups of <= 32 problems carry the table in the kernel
+ * arguments instead of searching it in device memory. */
 R3D_EXPORT int r3d_gemm_grouped_prepare(r3d_gemm_desc* descs, int n, int tile, int32_t* prefix) {
     if (!descs || !prefix || n <= 0 || (tile != 1 && tile != 2)) return R3D_EINVAL;
     int total = 0;
@@ -972,14 +996,15 @@ R3D_EXPORT int r3d_gemm_grouped_prepare(r3d_gemm_desc* descs, int n, int tile, i
     return R3D_OK;
 }
 
-R3D_EXPORT int r3d_gemm_grouped_launch(const r3d_gemm_desc* dev_descs, const int32_t* dev_prefix, int n, int total_tiles,
-                                       int layout, int tile, void* stream) {
+R3D_EXPORT int r3d_gemm_grouped_launch(const r3d_gemm_desc* dev_descs, const int32_t* dev_prefix, const int32_t* host_prefix,
+                                       int n, int total_tiles, int layout, int tile, void* stream) {
     if (!dev_descs || !dev_prefix || n <= 0 || total_tiles <= 0) return R3D_EINVAL;
+    if (host_prefix && (host_prefix[0] != 0 || host_prefix[n] != total_tiles)) return R3D_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     switch (layout) {
-        case R3D_GEMM_NT: return launch_grouped<0, 0>(dev_descs, dev_prefix, n, total_tiles, tile, s);
-        case R3D_GEMM_NN: return launch_grouped<0, 1>(dev_descs, dev_prefix, n, total_tiles, tile, s);
-        case R3D_GEMM_TN: return launch_grouped<1, 1>(dev_descs, dev_prefix, n, total_tiles, tile, s);
+        case R3D_GEMM_NT: return launch_grouped<0, 0>(dev_descs, dev_prefix, host_prefix, n, total_tiles, tile, s);
+        case R3D_GEMM_NN: return launch_grouped<0, 1>(dev_descs, dev_prefix, host_prefix, n, total_tiles, tile, s);
+        case R3D_GEMM_TN: return launch_grouped<1, 1>(dev_descs, dev_prefix, host_prefix, n, total_tiles, tile, s);
         default: return R3D_EINVAL;
     }
 }

@@ -162,6 +162,7 @@ class GemmGroup:
         dev = problems[0]["a"].device
         self.descs = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
         self.prefix = torch.tensor(list(prefix), dtype=torch.int32, device=dev)
+        self._prefix_host = prefix                       # (kernel-argument copy of the table: see r3d_gemm_grouped_launch)
         self.n, self.total, self.layout, self.tile = n, int(prefix[n]), layout, tile
         self._b_ptr = [pr["b"].data_ptr() for pr in problems]
 
@@ -178,8 +179,8 @@ class GemmGroup:
         self._keep[i] = dict(self._keep[i], b=b)
 
     def launch(self):
-        check(_lib.load().r3d_gemm_grouped_launch(_p(self.descs), _p(self.prefix), self.n, self.total, self.layout, self.tile,
-                                                  _stream()), "r3d_gemm_grouped_launch")
+        check(_lib.load().r3d_gemm_grouped_launch(_p(self.descs), _p(self.prefix), self._prefix_host, self.n, self.total,
+                                                  self.layout, self.tile, _stream()), "r3d_gemm_grouped_launch")
 
 
 class RowsumGroup:
