@@ -186,6 +186,23 @@ def test_gemm_grouped_matches_individual(ops):
                 assert_close(pr["bias_grad"].cpu(), rb, 1e-4, 1e-4, "grouped db")
 
 
+@pytest.mark.parametrize("nprob", [1, 32, 33, 45])
+def test_gemm_grouped_problem_lookup(ops, nprob):
+    """A workgroup finds its problem from the prefix table in the kernel arguments (<= 32 problems) or by the search in
+    device memory (more): every problem of groups on both sides of the limit, ragged tile counts."""
+    probs, refs = [], []
+    for i in range(nprob):
+        M, N, K = 20 + 13 * (i % 5), 30 + 17 * (i % 4), 24 + 8 * (i % 3)
+        a, b = rnd(M, K, seed=100 + i), rnd(N, K, seed=300 + i)
+        probs.append(dict(a=dev(a), b=dev(b), c=torch.full((M, N), float("nan"), device="cuda")))
+        refs.append(a.double() @ b.double().t())
+    grp = ops.GemmGroup(0, probs, tile=1)                       # NT
+    grp.launch()
+    torch.cuda.synchronize()
+    for i, (pr, r) in enumerate(zip(probs, refs)):
+        assert_close(pr["c"].cpu(), r, 1e-4, 1e-3, f"problem {i} of {nprob}")
+
+
 def test_layernorm_deferred_and_batched_finalize(ops):
     jobs, refs = [], []
     for i, (rows, H) in enumerate([(256, 128), (64, 128), (3, 128)]):
