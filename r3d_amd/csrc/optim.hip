@@ -14,6 +14,11 @@ namespace r3d {
 __device__ __forceinline__ void adamw_body(float4* __restrict__ p, const float4* __restrict__ g, float4* __restrict__ m,
                                            float4* __restrict__ v, size_t n4, const float* lr_ptr, const int64_t* step_ptr,
                                            float b1, float b2, float eps, float wd, float gscale, unsigned bid, unsigned nb) {
+    // No fused multiply-add contraction in here: hipcc contracted the two-stride main loop and its one-stride tail
+    // differently, so WHICH elements fell into the tail (the start and length of the range) changed their last bit.  The
+    // same parameter must get the same update whether it is reached by one launch over the arena or by two over its parts
+    // (found when a split launch stopped matching the single one bitwise from the second step on).
+#pragma clang fp contract(off)
     const float lr = *lr_ptr;
     const double step = (double)*step_ptr;
     const float bc1 = (float)(1.0 - pow((double)b1, step));

@@ -203,6 +203,24 @@ def test_gemm_grouped_problem_lookup(ops, nprob):
         assert_close(pr["c"].cpu(), r, 1e-4, 1e-3, f"problem {i} of {nprob}")
 
 
+def test_adamw_flat_is_bitwise_independent_of_how_the_range_is_cut(ops):
+    """One launch over [0, n) and two launches over [0, k) + [k, n) must give the same bits for every element (the
+    grid-stride loop's main body and tail used to be contracted into different FMA patterns)."""
+    n, k = 4 * 1234567, 4 * 246793
+    g = torch.Generator().manual_seed(3)
+    p0, gr = torch.randn(n, generator=g).cuda(), (torch.randn(n, generator=g) * 1e-2).cuda()
+    m0, v0 = (torch.randn(n, generator=g) * 1e-3).cuda(), (torch.rand(n, generator=g) * 1e-4).cuda()
+    lr, st = torch.tensor([1e-3], device="cuda"), torch.tensor([7], dtype=torch.int64, device="cuda")
+    a = [p0.clone(), m0.clone(), v0.clone()]
+    ops.adamw_flat(a[0], gr, a[1], a[2], lr, st, weight_decay=5e-3)
+    b = [p0.clone(), m0.clone(), v0.clone()]
+    ops.adamw_flat(b[0][:k], gr[:k], b[1][:k], b[2][:k], lr, st, weight_decay=5e-3)
+    ops.adamw_flat(b[0][k:], gr[k:], b[1][k:], b[2][k:], lr, st, weight_decay=5e-3)
+    torch.cuda.synchronize()
+    for x, y, name in zip(a, b, ("p", "m", "v")):
+        assert torch.equal(x, y), name
+
+
 def test_layernorm_deferred_and_batched_finalize(ops):
     jobs, refs = [], []
     for i, (rows, H) in enumerate([(256, 128), (64, 128), (3, 128)]):
