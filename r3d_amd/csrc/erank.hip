@@ -48,6 +48,12 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 template <int G> __device__ __forceinline__ float group_sum(float v) {
+    if (G == 8) {                               // quad butterflies + the mirror inside a half row (lane i <-> 7 - i)
+        v += dpp_f<0xB1>(v);                    // quad_perm [1,0,3,2]
+        v += dpp_f<0x4E>(v);                    // quad_perm [2,3,0,1]
+        v += dpp_f<0x141>(v);                   // row_half_mirror
+        return v;
+    }
     v = row16_sum(v);
     if (G == 64) {
         const int x = __builtin_bit_cast(int, v);
@@ -134,6 +140,41 @@ __device__ __forceinline__ bool jac_pair(float4* A4, float* nrm, int S4, int D4,
     return rot && ga * ga > stop2 * al * be;
 }
 
+// The same rotation with column i RESIDENT IN REGISTERS (u, its cached squared norm al) -- only the partner column j goes
+// through LDS: half the LDS traffic of jac_pair.  G = 16 or 8, EXACT layout (NCH chunks per lane, all of them matrix rows).
+// G = 8: the 16 lanes the LDS serves together belong to two pairs whose columns start on the same bank, so the odd group
+// visits its chunks in the order q ^ 1 (qx): at any instruction the two groups sit on different halves of the bank row.
+template <int G, int NCH>
+__device__ __forceinline__ bool jac_pair_fixed(float4 (&u)[NCH], float& al, float4* aj, float* nrm_j, int lg, float tol2,
+                                               float negl, float stop2, int qx) {
+    float4 v[NCH];
+    float ga = 0.f;
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) v[q] = aj[lg + G * (q ^ qx)];
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) ga += dot4(u[q], v[q]);
+    ga = group_sum<G>(ga);
+    const float be = *nrm_j;
+    const bool rot = ga * ga > tol2 * al * be && al > negl && be > negl;
+    if (rot) {
+        const float tau = be - al, d = 2.f * ga;
+        float t = d * __builtin_amdgcn_rcpf(fabsf(tau) + __builtin_amdgcn_sqrtf(tau * tau + d * d));
+        t = tau >= 0.f ? t : -t;
+        const float c = __builtin_amdgcn_rsqf(1.f + t * t), s = c * t;
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) {
+            const float4 a = u[q], b = v[q];
+            u[q] = make_float4(c * a.x - s * b.x, c * a.y - s * b.y, c * a.z - s * b.z, c * a.w - s * b.w);
+            aj[lg + G * (q ^ qx)] = make_float4(s * a.x + c * b.x, s * a.y + c * b.y, s * a.z + c * b.z, s * a.w + c * b.w);
+        }
+        if (lg == 0) *nrm_j = be + t * ga;
+        const float bigger = ga * ga > stop2 * al * be;
+        al = fmaxf(al - t * ga, 0.f);
+        return bigger;
+    }
+    return false;
+}
+
 struct ErankArgs {
     const float* x; int ld; long long batch_stride;      // [batch][R][ld]
     int R, C;
@@ -172,7 +213,14 @@ __device__ __forceinline__ void erank_stats_block(const float* sig, int C, float
     }
 }
 
-template <int G, int NCH, bool EXACT>
+// HALVE (C a power of two <= 128, G = 16, EXACT, no basis carried): the pairs of a sweep are visited level by level --
+// level s = C/2, C/4, .., 1 splits every block of 2s columns into halves and runs s rounds, round r pairing column kk of the
+// first half with column (kk + r) mod s of the second: C/2 disjoint pairs in every one of the (C/2 + C/4 + .. + 1) = C - 1
+// rounds, every pair once per sweep, like the round-robin order (same or fewer sweeps: simulated on CPU and measured).
+// Unlike it, a group keeps the SAME first column for a whole level, so that column stays in registers and only the
+// partner travels through LDS: per round 1 column read + 1 written per pair instead of 2 + 2.  The round is bound by the
+// LDS (ds_write_b128 ~83 B/clk/CU, reads ~244) plus the dot -> rcp / sqrt / rsq -> rotate latency chain, not by issue.
+template <int G, int NCH, bool EXACT, bool HALVE = false>
 __global__ __launch_bounds__(kJacThreads) void erank_jacobi_kernel(const ErankArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];   // columns [Cp][Sp] (Sp = Rp [+ Cv]), nrm [Cp]
     __shared__ int rotated;
@@ -226,6 +274,34 @@ __global__ __launch_bounds__(kJacThreads) void erank_jacobi_kernel(const ErankAr
             negl = f * 1e-12f;
         }
         bool my_rot = false;
+        if constexpr (HALVE) {
+            const bool act = slot < npairs;                        // (npairs <= 64 <= nslots)
+            const int qx = (G == 8) ? (slot & 1) : 0;
+            for (int hs = npairs; hs >= 1; hs >>= 1) {
+                const int bp = slot / hs, kk = slot - bp * hs;
+                const int i = bp * 2 * hs + kk, jb = bp * 2 * hs + hs;
+                float4 u[NCH > 0 ? NCH : 1];
+                float al = 0.f;
+                if (act) {
+#pragma unroll
+                    for (int q = 0; q < NCH; ++q) u[q] = A4[(size_t)i * S4 + lg + G * (q ^ qx)];
+                    al = nrm[i];
+                }
+                for (int r = 0; r < hs; ++r) {
+                    if (act) {
+                        const int j = jb + ((kk + r) & (hs - 1));
+                        my_rot |= jac_pair_fixed<G, (NCH > 0 ? NCH : 1)>(u, al, A4 + (size_t)j * S4, nrm + j, lg, tol2, negl, kStop2, qx);
+                    }
+                    __syncthreads();
+                }
+                if (act) {
+#pragma unroll
+                    for (int q = 0; q < NCH; ++q) A4[(size_t)i * S4 + lg + G * (q ^ qx)] = u[q];
+                    if (lg == 0) nrm[i] = al;
+                }
+                __syncthreads();
+            }
+        } else {
         for (int rd = 0; rd < nrounds; ++rd) {
             for (int k = slot; k < npairs; k += nslots) {
                 int i, j;
@@ -233,6 +309,7 @@ __global__ __launch_bounds__(kJacThreads) void erank_jacobi_kernel(const ErankAr
                 my_rot |= jac_pair<G, NCH, EXACT>(A4, nrm, S4, Rp4, nchd, i, j, lg, tol2, negl, kStop2);
             }
             __syncthreads();
+        }
         }
         if (my_rot) rotated = 1;
         __syncthreads();
@@ -481,6 +558,39 @@ R3D_EXPORT int r3d_erank_jacobi_warm(const float* x, int ld, int64_t batch_strid
     hipStream_t st = (hipStream_t)stream;
     const int npairs = ((C + 1) & ~1) / 2;
     const int s4 = erank_rp(R) / 4 + (vt_out ? ((C + 3) & ~3) / 4 : 0);       // 16-byte chunks per column
+#ifndef R3D_JAC_HALVING
+#define R3D_JAC_HALVING 1
+#endif
+    if (R3D_JAC_HALVING && !vt_out && C >= 32 && C <= 128 && (C & (C - 1)) == 0 && (R & 63) == 0 && R <= 512) {
+        // power-of-two column count, whole chunks: the level order with the first column of every pair in registers
+        auto go = [&](auto kern) {
+            if (lds > 64 * 1024) {
+                hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return (int)e;
+            }
+            hipLaunchKernelGGL(kern, dim3(batch), dim3(kJacThreads), (size_t)lds, st, a);
+            R3D_LAUNCH_CHECK();
+            return (int)R3D_OK;
+        };
+#ifndef R3D_JAC_LANES
+#define R3D_JAC_LANES 8
+#endif
+        if (R3D_JAC_LANES == 8) {
+            switch (R / 64) {
+                case 1: return go(erank_jacobi_kernel<8, 2, true, true>);
+                case 2: return go(erank_jacobi_kernel<8, 4, true, true>);
+                case 4: return go(erank_jacobi_kernel<8, 8, true, true>);
+                default: break;
+            }
+        }
+        switch (R / 64) {
+            case 1: return go(erank_jacobi_kernel<16, 1, true, true>);
+            case 2: return go(erank_jacobi_kernel<16, 2, true, true>);
+            case 4: return go(erank_jacobi_kernel<16, 4, true, true>);
+            case 8: return go(erank_jacobi_kernel<16, 8, true, true>);
+            default: break;
+        }
+    }
     if (npairs > 16) {                          // 16 lanes per pair: 64 pairs per pass
         if (s4 <= 16) return erank_launch<16, 1>(a, batch, lds, st);
         if (s4 <= 32) return erank_launch<16, 2>(a, batch, lds, st);
