@@ -422,6 +422,30 @@ __global__ __launch_bounds__(kJacThreads) void erank_blk_round_kernel(ErankBlk g
     bool my_rot = false;
     const int npairs = (mode == 0) ? b / 2 : b;
     const int nrounds = (mode == 0) ? b - 1 : b;
+    if (EXACT && NCH > 0 && mode == 1 && nslots >= b) {
+        // cross rounds: wave k keeps column k of block p for all b rounds -- resident in registers, only the partner
+        // column of block q goes through LDS (see jac_pair_fixed)
+        const bool act = slot < b;
+        float4 u[NCH > 0 ? NCH : 1];
+        float al = 0.f;
+        if (act) {
+#pragma unroll
+            for (int q = 0; q < NCH; ++q) u[q] = A4[(size_t)slot * Rp4 + lg + G * q];
+            al = nrm[slot];
+        }
+        for (int t = 0; t < b; ++t) {
+            if (act) {
+                int j = slot + t; if (j >= b) j -= b; j += b;
+                my_rot |= jac_pair_fixed<G, (NCH > 0 ? NCH : 1)>(u, al, A4 + (size_t)j * Rp4, nrm + j, lg, tol2, negl, kStop2, 0);
+            }
+            __syncthreads();
+        }
+        if (act) {
+#pragma unroll
+            for (int q = 0; q < NCH; ++q) A4[(size_t)slot * Rp4 + lg + G * q] = u[q];
+        }
+        __syncthreads();
+    } else {
     for (int t = 0; t < nrounds; ++t) {
         for (int k = slot; k < npairs; k += nslots) {
             int i, j;
@@ -430,6 +454,7 @@ __global__ __launch_bounds__(kJacThreads) void erank_blk_round_kernel(ErankBlk g
             my_rot |= jac_pair<G, NCH, EXACT>(A4, nrm, Rp4, Rp4, Rp4 / G, i, j, lg, tol2, negl, kStop2);
         }
         __syncthreads();
+    }
     }
     float4* Pw = reinterpret_cast<float4*>(g.at + (size_t)p * b * Rp);
     float4* Qw = reinterpret_cast<float4*>(g.at + (size_t)(q < 0 ? p : q) * b * Rp);
