@@ -15,6 +15,10 @@
 // reduction (gamma), done with v_add_f32_dpp row_ror butterflies -- no LDS crossbar traffic.  A pair is rotated when
 // |gamma| > tol * sqrt(alpha * beta), tol = sqrt(R) * eps_f32 (the sgesvj criterion); sweeps repeat until one starts with
 // every coupling below kStop (see there), or max_sweeps.
+// For power-of-two C <= 128 (the training step's [B S, H] tokens) the pairs of a sweep are visited LEVEL BY LEVEL instead
+// (HALVE, see erank_jacobi_kernel): a lane group of 8 keeps the first column of its pair in registers for a whole level and
+// only the partner goes through LDS -- the kernel is bound by the LDS write rate and the rotation's latency chain, and this
+// halves the former.
 // Outputs: singular values (unsorted), entropy, erank, sweep count and optionally the rotated columns
 // Af^T = (X V)^T [C][R], from which the backward  dX = Af diag(g / sigma^3) (Af^T X)  is two MFMA GEMMs
 // (U diag(g) V^T with V^T = Sigma^-2 Af^T X; no accumulation of V in the sweep).
