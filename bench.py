@@ -424,11 +424,16 @@ def main():
                 run_step, launch = g.replay, "hipGraph (1 graph/step)"
                 spg = max(1, a.steps_per_graph)
                 if spg > 1:
-                    gk = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gk):
-                        for _ in range(spg):
-                            step_eager()
-                    run_many = (gk, spg)
+                    # graphs of spg, spg/2, .., 2 steps: any step count is replayed with the fewest launches (a remainder of
+                    # single-step graphs would pay the ~8 us between graph launches on every one of its steps)
+                    run_many, k = [], spg
+                    while k > 1:
+                        gk = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(gk):
+                            for _ in range(k):
+                                step_eager()
+                        run_many.append((gk, k))
+                        k //= 2
                     launch = f"hipGraph ({spg} steps/graph)"
             elif rs is not None:
                 G, S = {}, {}
@@ -555,11 +560,10 @@ def main():
                 tp.ready.clear()
     def run_steps(n):
         """exactly n training steps"""
-        if run_many is not None:
-            gk, spg = run_many
-            for _ in range(n // spg):
+        for gk, k in (run_many or []):
+            for _ in range(n // k):
                 gk.replay()
-            n = n % spg
+            n = n % k
         for _ in range(n):
             run_step()
 
