@@ -582,7 +582,8 @@ def test_gemm_bf16x3_long_k_projection(ops, M, N, K):
 # ----------------------------------------------------------------------------------------------------------
 # effective rank
 # ----------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("R,Cc", [(128, 128), (40, 24), (256, 128), (33, 64), (64, 512), (1024, 32), (16, 16), (127, 129)])
+@pytest.mark.parametrize("R,Cc", [(128, 128), (40, 24), (256, 128), (33, 64), (64, 512), (1024, 32), (16, 16), (127, 129),
+                                  (64, 64), (64, 32), (128, 32), (512, 64), (192, 128)])   # level order: 8 / 16 lanes, C = 32..128
 def test_erank_jacobi_vs_svdvals(ops, R, Cc):
     from oracle import futr_oracle as O
     x = rnd(R, Cc, seed=R) @ torch.diag(torch.linspace(0.05, 2.0, Cc)) + 0.3
@@ -598,6 +599,25 @@ def test_erank_jacobi_vs_svdvals(ops, R, Cc):
     G = aft[0].cpu().double() @ aft[0].cpu().double().t()
     off = G - torch.diag(torch.diag(G))
     assert float(off.abs().max()) < 1e-3 * float(sv[0]) ** 2
+
+
+def test_erank_jacobi_level_order_batched_and_rank_deficient(ops):
+    """The level-order kernel (power-of-two C <= 128) on a batch of matrices, one of them rank-deficient (R < C: the surplus
+    columns must report sigma = 0, not rotation noise) and one with two exactly equal columns."""
+    from oracle import futr_oracle as O
+    R, Cc = 64, 128
+    xs = [rnd(R, Cc, seed=5), rnd(R, Cc, seed=6) @ torch.diag(torch.linspace(1e-3, 1.0, Cc)), rnd(R, Cc, seed=7)]
+    xs[2][:, 17] = xs[2][:, 3]
+    x = torch.stack(xs)
+    sig, st = torch.empty(3, Cc, device="cuda"), torch.empty(3, 4, device="cuda")
+    ops.erank_jacobi(dev(x), sig, st)
+    torch.cuda.synchronize()
+    for b in range(3):
+        sv = torch.linalg.svdvals(x[b].double())
+        got = torch.sort(sig[b].cpu(), descending=True)[0]
+        assert_close(got[:R], sv, 1e-4, 1e-4 * float(sv[0]), f"sigma[{b}]")
+        assert float(got[R:].abs().max()) <= 1e-5 * float(sv[0]), f"matrix {b}: surplus columns"
+        assert abs(float(st[b, 0]) - O.effective_rank(x[b])) < 5e-3
 
 
 @pytest.mark.parametrize("R,Cc", [(128, 128), (96, 64), (70, 30)])
