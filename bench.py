@@ -189,9 +189,11 @@ def cpu_baseline(c, budget_s=15.0):
         if time.perf_counter() - t0 > budget_s or n >= 400:
             break
     dt = time.perf_counter() - t0
-    return dict(value=c["B"] * n / dt, unit="clips/s", cores=cores, kind="port",
+    return dict(value=c["B"] * n / dt, unit="clips/s", cores=cores, kind="port", host_cores=os.cpu_count(),
+                host_cores_available=avail,
                 sample=f"{n} full CPU training steps (fwd+3 losses+autograd bwd+AdamW) of the same B={c['B']},S={c['S']},"
-                       f"H={c['H']} workload in {dt:.1f}s, torch {torch.__version__} CPU, {cores} threads")
+                       f"H={c['H']} workload in {dt:.1f}s, torch {torch.__version__} CPU, {cores} threads "
+                       f"(box: {os.cpu_count()} cores, {avail} available to this process)")
 
 
 def rccl_probe_child(a, timeout_s=300):
