@@ -367,7 +367,7 @@ int r3d_erank_jacobi(const float* x, int ld, int64_t batch_stride, int batch, in
  * fills out[0] = floats of af_t ([Cpad][Rp], the rotated columns (X V)^T; Rp = R rounded up to 4 is the row stride,
  * rows past C and the row tails R..Rp-1 are zero), out[1] = ints of ctrl (scratch), out[2] = Rp, out[3] = columns per
  * block.  af_t must be 16-byte aligned.  sigma [C] unsorted, stats [4] = {erank, entropy, sum sigma, sweeps}.
- * max_sweeps <= 0 selects 20.  Enqueues its launches, no sync. */
+ * max_sweeps <= 0 selects 16.  Enqueues its launches, no sync. */
 int r3d_erank_blocked_sizes(int R, int C, int max_sweeps, int64_t* out);
 int r3d_erank_blocked(const float* x, int ld, int R, int C, float* sigma, float* af_t, int* ctrl, float* stats,
                       int max_sweeps, void* stream);

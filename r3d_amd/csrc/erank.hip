@@ -650,7 +650,7 @@ R3D_EXPORT int r3d_erank_blocked_sizes(int R, int C, int max_sweeps, int64_t* ou
     R3D_REQUIRE(((int64_t)2 * b * erank_rp(R) + 2 * b) * 4 <= 150 * 1024);
     const int nreal = r3d_cdiv(C, b);
     out[0] = (int64_t)nreal * b * erank_rp(R);
-    out[1] = 4 + (max_sweeps > 0 ? max_sweeps : 20);
+    out[1] = 4 + (max_sweeps > 0 ? max_sweeps : 16);
     out[2] = erank_rp(R);
     out[3] = b;
     return R3D_OK;
@@ -685,7 +685,7 @@ static int erank_blk_sweeps(const ErankBlk& g, int ms, int64_t lds, hipStream_t 
  * with the columns in HBM (see above).  af_t [Cpad][Rp] receives the rotated columns (X V)^T (rows >= C and the
  * columns R..Rp-1 of every row are zero padding); ctrl is integer scratch; sizes from r3d_erank_blocked_sizes.
  * sigma [C], stats [4] as r3d_erank_jacobi.  Enqueues 3 + max_sweeps * (nblk + 1) launches on the stream (default
- * max_sweeps 20; launches after convergence return at once), never synchronises. */
+ * max_sweeps 16 -- 8 to 10 are used at the BASELINE shapes; launches after convergence return at once but still cost ~3 us each), never synchronises. */
 R3D_EXPORT int r3d_erank_blocked(const float* x, int ld, int R, int C, float* sigma, float* af_t, int* ctrl, float* stats,
                                  int max_sweeps, void* stream) {
     R3D_REQUIRE(x && sigma && af_t && ctrl && stats && R > 0 && C > 0 && ld >= C);
@@ -694,7 +694,7 @@ R3D_EXPORT int r3d_erank_blocked(const float* x, int ld, int R, int C, float* si
     const int Rp = erank_rp(R);
     const int64_t lds = ((int64_t)2 * b * Rp + 2 * b) * 4;
     R3D_REQUIRE(lds <= 150 * 1024);
-    const int ms = max_sweeps > 0 ? max_sweeps : 20;
+    const int ms = max_sweeps > 0 ? max_sweeps : 16;
     const int nreal = r3d_cdiv(C, b);
     const int nblk = (nreal + 1) & ~1;
     hipStream_t st = (hipStream_t)stream;

@@ -601,7 +601,7 @@ def erank_jacobi(x, sigma, stats, *, af_t=None, gram=False, max_sweeps=30):
                                max_sweeps, _stream()), "r3d_erank_jacobi")
 
 
-def erank_blocked(x, max_sweeps=20):
+def erank_blocked(x, max_sweeps=16):
     """x: [R, C] (row stride >= C).  Returns (sigma [C], stats [4], af_t [Cpad, R] -- a view of the [Cpad, Rp] buffer the
     kernel sweeps, Rp = R rounded up to 4) -- any size, columns in HBM."""
     import ctypes

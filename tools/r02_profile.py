@@ -53,6 +53,21 @@ def timed(fn, reps=5):
     return sorted(ts)[len(ts) // 2]          # us
 
 
+def timed_graph(fn, reps=5):
+    """The same launches replayed as a hipGraph (how they run inside the training step: no host dispatch between the
+    dependent launches of the two-level kernel).  None if the capture fails."""
+    try:
+        fn()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fn()
+        return timed(g.replay, reps)
+    except Exception:                                       # noqa: BLE001
+        torch.cuda.synchronize()
+        return None
+
+
 def run_erank(a):
     from r3d_amd import ops, erank as ER
     dev = torch.device("cuda:0")
@@ -78,6 +93,7 @@ def run_erank(a):
                 st = stats.cpu()
                 Rr, Cc = xx.shape
                 info = ops.erank_blocked_info(Rr, Cc) if hasattr(ops, "erank_blocked_info") else {}
+                info = dict(info, us_in_graph=timed_graph(fn))
             elif route == "lds":
                 sigma = torch.empty(1, C, device=dev)
                 stats = torch.empty(1, 4, device=dev)
