@@ -6,6 +6,7 @@
 //   Dropout: nn.Dropout(0.1) sites of the path (futr_safuser_tokenfusion.py:26,83; transformer.py:268-276 and the
 //          attention-probability dropout inside nn.MultiheadAttention).  RNG parity with PyTorch is impossible, so the
 //          masks come from Philox4x32-10 keyed by (seed, per-step offset read from device memory).
+#include <cstdlib>
 #include "common.h"
 #include "../../include/r3d_hip.h"
 
@@ -36,7 +37,8 @@ __device__ __forceinline__ void adamw_body(float4* __restrict__ p, const float4*
             pp.c -= step_size * (mm.c / den);                      \
         }
     // two grid-strides per iteration: eight 16-byte loads in flight per lane before the first use (arenas beyond the
-    // 256 MiB Infinity Cache are a pure HBM stream: more bytes in flight per CU, measured at the cfg4 / cfg5 arena sizes)
+    // 256 MiB Infinity Cache are a pure HBM stream: more bytes in flight per CU, measured at the cfg4 / cfg5 arena sizes;
+    // consecutive 4 KB pieces per workgroup instead of grid strides measured 10 % slower there)
     const size_t stride = (size_t)nb * 256;
     size_t i = (size_t)bid * 256 + threadIdx.x;
     for (; i + stride < n4; i += 2 * stride) {
@@ -150,13 +152,23 @@ __global__ __launch_bounds__(256) void adamw_dropout_kernel(float4* __restrict__
 
 using namespace r3d;
 
+// Workgroups of the flat AdamW launch.  Swept 256 .. 16384 at the cfg2 / cfg4 / cfg5 arena sizes on two boxes
+// (tools/r02_profile.py adamw, R3D_ADAMW_BLOCKS overrides): beyond the 256 MiB Infinity Cache (4 arrays x 4 B x n) three
+// workgroups per CU stream best -- 0.65 - 0.73 of 8 TB/s against 0.60 - 0.63 with 4096 workgroups, whose 28 concurrent
+// streams per CU scatter over more DRAM pages; inside the cache 4096 stay 0.5 us ahead (more requests in flight).
+static inline int adam_blocks(size_t n4) {
+    int cap = (n4 * 64 > ((size_t)200 << 20)) ? 768 : 4096;
+    if (const char* e = getenv("R3D_ADAMW_BLOCKS")) cap = atoi(e);
+    return (int)((n4 + 255) / 256 < (size_t)cap ? (n4 + 255) / 256 : (size_t)cap);
+}
+
 R3D_EXPORT int r3d_adamw_flat(float* p, const float* g, float* m, float* v, int64_t n, const float* lr, const int64_t* step,
                               float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream) {
     R3D_REQUIRE(p && g && m && v && lr && step && n > 0);
     R3D_REQUIRE((n % 4) == 0);
     if (!(r3d_aligned16(p) && r3d_aligned16(g) && r3d_aligned16(m) && r3d_aligned16(v))) return R3D_EALIGN;
     const size_t n4 = (size_t)n / 4;
-    const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+    const int blocks = adam_blocks(n4);
     hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float4*)p, (const float4*)g,
                        (float4*)m, (float4*)v, n4, lr, step, beta1, beta2, eps, weight_decay, grad_scale);
     R3D_LAUNCH_CHECK();
@@ -172,7 +184,7 @@ R3D_EXPORT int r3d_adamw_flat_dropout(float* p, const float* g, float* m, float*
     R3D_REQUIRE((n % 4) == 0);
     if (!(r3d_aligned16(p) && r3d_aligned16(g) && r3d_aligned16(m) && r3d_aligned16(v))) return R3D_EALIGN;
     const size_t n4 = (size_t)n / 4;
-    const unsigned nb_adam = (unsigned)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+    const unsigned nb_adam = (unsigned)adam_blocks(n4);
     const double t = (double)p_drop * 4294967296.0;
     const uint32_t thresh = (uint32_t)(t >= 4294967295.0 ? 4294967295.0 : t);
     const size_t m4 = ((size_t)n_mask + 3) / 4;
