@@ -261,6 +261,8 @@ def main():
     ap.add_argument("--torch-collectives", action="store_true",
                     help="multi-GPU: exchanges through torch.distributed (ProcessGroupNCCL's stream + event joins, several "
                          "graphs per step) instead of RCCL enqueued on the launch stream")
+    ap.add_argument("--no-gemm-ln", action="store_true",
+                    help="LayerNorm sites as GEMM + LayerNorm launches instead of the row-complete gemm_ln kernel (A/B)")
     ap.add_argument("--separate-tail", action="store_true",
                     help="decoder tail forward, losses and tail backward as three launches instead of one")
     ap.add_argument("--frame-major-input", action="store_true",
@@ -322,6 +324,7 @@ def main():
     eng.erank_warm_start = a.erank_warm
     eng.use_side_stream = a.side_stream
     eng.use_fused_decoder = a.fused_decoder
+    eng.use_gemm_ln = not a.no_gemm_ln
     eng.defer_tail = not a.separate_tail      # forward -> losses -> backward run back to back: one tail/loss launch
     from r3d_amd.parallel import DataParallelStep
     feats, depth, lab, dur, tgt = make_inputs(c, device, seed=1 + rank)
@@ -374,6 +377,7 @@ def main():
                 model.eval()
             eng = model.engine()
             eng.use_side_stream = a.side_stream
+            eng.use_gemm_ln = not a.no_gemm_ln
             eng.defer_tail = not a.separate_tail
             dp = DataParallelStep(eng, pixel_shard=pixel_shard, input_group=pg_in if pixel_shard else None)
             dp.broadcast_parameters()

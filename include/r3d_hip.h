@@ -196,6 +196,33 @@ int r3d_tick(int64_t* a, int64_t* b, void* stream);
 int r3d_add_rowbcast(const float* x, int ldx, const float* add, int ldadd, int mod, float* out, int ldo, int rows, int cols,
                      void* stream);
 
+/* ---- nn.Linear -> dropout -> residuals -> LayerNorm in ONE launch (gemm_ln.hip; hidden size 128) ----------------
+ * y = LN(pre), pre = drop_scale * drop_mask * (A . W^T + bias) + res1 + res2      (A [M,K], W [H,K], both K-contiguous)
+ * -- the sub-layer epilogues of model/extras/transformerblock.py:131-134 (attn.proj + x -> norm2; mlp fc2 + x),
+ * model/futr_safuser_tokenfusion.py:92-94 (+ x_res -> norm -> mean over the two modality tokens: pair_out[n] =
+ * (y[2n] + y[2n+1]) / 2) and model/extras/transformer.py:292-293,304-306 (out_proj -> dropout -> + tgt -> norm1 / norm2).
+ * A workgroup owns 16 complete rows, so the LayerNorm is the GEMM's epilogue: one dependent launch and one memory round
+ * trip of the pre-norm rows less per site than r3d_gemm_f32 + r3d_layernorm_fwd.  pre_out (the LayerNorm's input, read
+ * by the backward), mean and rstd are written exactly as those two entry points write them.  K == 0: no product, the
+ * rows already in pre_out are normalised (a plain LayerNorm job riding in the same launch).  Up to 4 jobs per launch.
+ * Requirements (r3d_gemm_ln_supported): H == 128, M % 16 == 0, K in {0, 128, 256, 384, 512}, A / W 16-byte aligned with lda, ldw % 4 == 0.
+ */
+typedef struct r3d_gemm_ln_job {
+    const float* A; int32_t lda;
+    const float* W; int32_t ldw;
+    const float* bias;
+    const uint8_t* drop_mask; int32_t lddrop; float drop_scale;
+    const float* res1; int32_t ldr1;
+    const float* res2; int32_t ldr2;
+    float* pre_out; int32_t ldpre;
+    const float* gamma; const float* beta;
+    float* y; int32_t ldy; float* mean; float* rstd;
+    float* pair_out;
+    int32_t M, K;
+} r3d_gemm_ln_job;
+int r3d_gemm_ln_supported(int M, int K, int H);
+int r3d_gemm_ln_fwd(const r3d_gemm_ln_job* jobs, int njobs, int H, void* stream);
+
 /* ---- token selection / exchange: CMFuser.token_fusion (model/futr_safuser_tokenfusion.py:33-66) ------------- */
 /* out[c] = sum_r |x[r,c]| in fp64 (the eval-mode score before the division by B*T, :49-50). */
 int r3d_colabssum(const float* x, int ld, int rows, int cols, double* out, void* stream);

@@ -56,6 +56,16 @@ class LnBwdJob(C.Structure):
                 ("rows_per_block", C.c_int32), ("nblocks", C.c_int32)]
 
 
+class GemmLnJob(C.Structure):
+    """struct r3d_gemm_ln_job"""
+    _fields_ = [("A", C.c_void_p), ("lda", C.c_int32), ("W", C.c_void_p), ("ldw", C.c_int32), ("bias", C.c_void_p),
+                ("drop_mask", C.c_void_p), ("lddrop", C.c_int32), ("drop_scale", C.c_float),
+                ("res1", C.c_void_p), ("ldr1", C.c_int32), ("res2", C.c_void_p), ("ldr2", C.c_int32),
+                ("pre_out", C.c_void_p), ("ldpre", C.c_int32), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+                ("y", C.c_void_p), ("ldy", C.c_int32), ("mean", C.c_void_p), ("rstd", C.c_void_p),
+                ("pair_out", C.c_void_p), ("M", C.c_int32), ("K", C.c_int32)]
+
+
 class RowsumJob(C.Structure):
     """struct r3d_rowsum_job"""
     _fields_ = [("src1", C.c_void_p), ("src2", C.c_void_p), ("dst", C.c_void_p), ("ld1", C.c_int32), ("ld2", C.c_int32),
@@ -93,6 +103,8 @@ _SIGNATURES = {
     "r3d_gemm_plan": ([C.POINTER(GemmDesc)], C.c_int),
     "r3d_gemm_grouped_prepare": ([C.POINTER(GemmDesc), _I, _I, C.POINTER(C.c_int32)], C.c_int),
     "r3d_gemm_grouped_launch": ([_P, _P, C.POINTER(C.c_int32), _I, _I, _I, _I, _P], C.c_int),
+    "r3d_gemm_ln_supported": ([_I, _I, _I], C.c_int),
+    "r3d_gemm_ln_fwd": ([_P, _I, _I, _P], C.c_int),
     "r3d_layernorm_fwd_multi": ([_P, _I, _P], C.c_int),
     "r3d_layernorm_bwd_multi": ([_P, _I, _P], C.c_int),
     "r3d_layernorm_bwd_finalize_batched": ([_P, _I, _I, _P], C.c_int),

@@ -202,6 +202,9 @@ class FusionEngine:
         # of forward() are valid only after losses() in that mode
         self.defer_tail = False
         self.use_paired_launches = True          # one-layer decoder: independent GEMMs of the two chains share launches
+        # hidden = 128: nn.Linear -> dropout -> residuals -> LayerNorm sites run as ONE row-complete launch (gemm_ln.hip)
+        # instead of GEMM + LayerNorm: a dependent launch and a memory round trip less per site
+        self.use_gemm_ln = True
         # the two depth-projection GEMMs (83 % of the step's FLOPs) on the bf16 matrix cores through an exact three-way
         # operand split (csrc/gemm_bf3.hip; error per product <= 3 * 2^-24); 0 = the fp32 MFMA everywhere
         self.depth_prec = 1
@@ -339,10 +342,17 @@ class FusionEngine:
                      bias=a.p(pl + "self_attn.in_proj_bias"), ws=wsx)
             ops.mha_core_fwd(c["sa_qkv"][:, :H], c["sa_qkv"][:, H:2 * H], c["sa_qkv"][:, 2 * H:], c["p_sa"], c["sa_o"], B,
                              heads, Q, Q, dh, drop_mask=dm(f"sa_p{l}"), drop_scale=dsc)
-            ops.gemm(GEMM_NT, c["sa_o"], a.p(pl + "self_attn.out_proj.weight"), c["t1_pre"],
-                     bias=a.p(pl + "self_attn.out_proj.bias"), drop_mask=self._dm2(dm(f"d1_{l}"), BQ, H), drop_scale=dsc,
-                     res1=None if l == 0 else tgt_in, ws=wsx)                 # layer 0: tgt = 0 (:209)
-            ops.layernorm_fwd(c["t1_pre"], a.p(pl + "norm1.weight"), a.p(pl + "norm1.bias"), c["t1"], c["m1"], c["r1"])
+            if self._gln(BQ, H):
+                ops.gemm_ln_fwd([dict(a=c["sa_o"], w=a.p(pl + "self_attn.out_proj.weight"),
+                                      bias=a.p(pl + "self_attn.out_proj.bias"), drop_mask=self._dm2(dm(f"d1_{l}"), BQ, H),
+                                      drop_scale=dsc, res1=None if l == 0 else tgt_in, pre=c["t1_pre"],
+                                      gamma=a.p(pl + "norm1.weight"), beta=a.p(pl + "norm1.bias"), y=c["t1"], mean=c["m1"],
+                                      rstd=c["r1"])])
+            else:
+                ops.gemm(GEMM_NT, c["sa_o"], a.p(pl + "self_attn.out_proj.weight"), c["t1_pre"],
+                         bias=a.p(pl + "self_attn.out_proj.bias"), drop_mask=self._dm2(dm(f"d1_{l}"), BQ, H),
+                         drop_scale=dsc, res1=None if l == 0 else tgt_in, ws=wsx)                 # layer 0: tgt = 0 (:209)
+                ops.layernorm_fwd(c["t1_pre"], a.p(pl + "norm1.weight"), a.p(pl + "norm1.bias"), c["t1"], c["m1"], c["r1"])
             wi, bi = a.p(pl + "multihead_attn.in_proj_weight"), a.p(pl + "multihead_attn.in_proj_bias")
             ops.gemm(GEMM_NT, c["t1"], wi[:H], c["caq"], a_add=qpos, a_add_mod=Q, bias=bi[:H], ws=wsx)
 
@@ -426,14 +436,26 @@ class FusionEngine:
             self._forward_paired(w, fw, dm, dsc, drop, wv, pre, qpos, pos)
         else:
             ops.gemm(GEMM_NT, w.h1, wv, w.vsw, c_row_xor=1, ws=self.ws)        # V of the OTHER modality token
-            ops.gemm(GEMM_NT, w.vsw, a.p(pre + "attn.proj.weight"), w.x1, bias=a.p(pre + "attn.proj.bias"), res1=w.x0,
-                     ws=self.ws)
-            ops.layernorm_fwd(w.x1, a.p(pre + "norm2.weight"), a.p(pre + "norm2.bias"), w.h2, w.m2, w.r2)
+            gln = self._gln(2 * N, H) and self._gln(2 * N, 4 * H)
+            if gln:
+                ops.gemm_ln_fwd([dict(a=w.vsw, w=a.p(pre + "attn.proj.weight"), bias=a.p(pre + "attn.proj.bias"),
+                                      res1=w.x0, pre=w.x1, gamma=a.p(pre + "norm2.weight"), beta=a.p(pre + "norm2.bias"),
+                                      y=w.h2, mean=w.m2, rstd=w.r2)])
+            else:
+                ops.gemm(GEMM_NT, w.vsw, a.p(pre + "attn.proj.weight"), w.x1, bias=a.p(pre + "attn.proj.bias"), res1=w.x0,
+                         ws=self.ws)
+                ops.layernorm_fwd(w.x1, a.p(pre + "norm2.weight"), a.p(pre + "norm2.bias"), w.h2, w.m2, w.r2)
             ops.gemm(GEMM_NT, w.h2, a.p(pre + "mlp.mlp.0.weight"), w.f1, bias=a.p(pre + "mlp.mlp.0.bias"), act=2,
                      pre_out=w.u, ws=self.ws)
-            ops.gemm(GEMM_NT, w.f1, a.p(pre + "mlp.mlp.2.weight"), w.x3, bias=a.p(pre + "mlp.mlp.2.bias"), res1=w.x1,
-                     res2=None if self.bn else w.x0, ws=self.ws)        # (the BN-blend variant has no x_res, :97,101)
-            ops.layernorm_fwd(w.x3, a.p("fuser.norm.weight"), a.p("fuser.norm.bias"), w.y, w.mf, w.rf, pair_out=w.fused)
+            if gln:
+                ops.gemm_ln_fwd([dict(a=w.f1, w=a.p(pre + "mlp.mlp.2.weight"), bias=a.p(pre + "mlp.mlp.2.bias"), res1=w.x1,
+                                      res2=None if self.bn else w.x0, pre=w.x3, gamma=a.p("fuser.norm.weight"),
+                                      beta=a.p("fuser.norm.bias"), y=w.y, mean=w.mf, rstd=w.rf, pair_out=w.fused)])
+            else:
+                ops.gemm(GEMM_NT, w.f1, a.p(pre + "mlp.mlp.2.weight"), w.x3, bias=a.p(pre + "mlp.mlp.2.bias"), res1=w.x1,
+                         res2=None if self.bn else w.x0, ws=self.ws)        # (the BN-blend variant has no x_res, :97,101)
+                ops.layernorm_fwd(w.x3, a.p("fuser.norm.weight"), a.p("fuser.norm.bias"), w.y, w.mf, w.rf,
+                                  pair_out=w.fused)
         # ---- segmentation head (:228-232); with the composed decoder it shares a launch with the layer-0 key/value
         # projection (both read `fused`, neither depends on the other)
         if paired:
@@ -501,6 +523,9 @@ class FusionEngine:
         """Effective rank of the last forward's fused tokens (device scalar; valid when erank_weight != 0)."""
         return self.last["w"].er_stats[0, 0]
 
+    def _gln(self, rows, K):
+        return self.use_gemm_ln and ops.gemm_ln_supported(rows, K, self.H)
+
     def _forward_paired(self, w, fw, dm, dsc, drop, wv, pre, qpos, pos):
         """Fuser block (transformerblock.py:118-135, :86-94) interleaved with the layer-0 query self-attention sub-layer
         (transformer.py:289-293,300): independent GEMMs share a launch."""
@@ -526,19 +551,34 @@ class FusionEngine:
             w.tables[key] = (g1, g2, g3)
         g1, g2, g3 = w.tables[key]
         g1.launch()
-        ops.gemm(GEMM_NT, w.vsw, a.p(pre + "attn.proj.weight"), w.x1, bias=a.p(pre + "attn.proj.bias"), res1=w.x0,
-                 ws=self.ws)
+        gln = self._gln(2 * w.N, H) and self._gln(2 * w.N, 4 * H) and self._gln(BQ, 0)
+        if gln:      # attn.proj + x -> norm2 (transformerblock.py:131-132): the LayerNorm is the product's epilogue
+            ops.gemm_ln_fwd([dict(a=w.vsw, w=a.p(pre + "attn.proj.weight"), bias=a.p(pre + "attn.proj.bias"), res1=w.x0,
+                                  pre=w.x1, gamma=a.p(pre + "norm2.weight"), beta=a.p(pre + "norm2.bias"), y=w.h2,
+                                  mean=w.m2, rstd=w.r2)])
+        else:
+            ops.gemm(GEMM_NT, w.vsw, a.p(pre + "attn.proj.weight"), w.x1, bias=a.p(pre + "attn.proj.bias"), res1=w.x0,
+                     ws=self.ws)
         ops.mha_core_fwd(c["sa_qkv"][:, :H], c["sa_qkv"][:, H:2 * H], c["sa_qkv"][:, 2 * H:], c["p_sa"], c["sa_o"], B, heads,
                          Q, Q, dh, drop_mask=dm("sa_p0"), drop_scale=dsc)
-        ops.layernorm_fwd(w.x1, a.p(pre + "norm2.weight"), a.p(pre + "norm2.bias"), w.h2, w.m2, w.r2)
+        if not gln:
+            ops.layernorm_fwd(w.x1, a.p(pre + "norm2.weight"), a.p(pre + "norm2.bias"), w.h2, w.m2, w.r2)
         g2.launch()
-        ops.gemm(GEMM_NT, w.f1, a.p(pre + "mlp.mlp.2.weight"), w.x3, bias=a.p(pre + "mlp.mlp.2.bias"), res1=w.x1,
-                 res2=None if self.bn else w.x0, ws=self.ws)          # (no x_res in the BN-blend variant)
-        ops.layernorm_fwd_multi([                      # decoder norm1 and the fuser's final norm + token mean: one launch
-            dict(x=c["t1_pre"], gamma=a.p(pl + "norm1.weight"), beta=a.p(pl + "norm1.bias"), y=c["t1"], mean=c["m1"],
-                 rstd=c["r1"]),
-            dict(x=w.x3, gamma=a.p("fuser.norm.weight"), beta=a.p("fuser.norm.bias"), y=w.y, mean=w.mf, rstd=w.rf,
-                 pair_out=w.fused)])
+        if gln:      # mlp fc2 + x (+ x_res) -> fuser.norm -> token mean (:92-94), and the decoder's norm1 as a plain job
+            ops.gemm_ln_fwd([
+                dict(a=w.f1, w=a.p(pre + "mlp.mlp.2.weight"), bias=a.p(pre + "mlp.mlp.2.bias"), res1=w.x1,
+                     res2=None if self.bn else w.x0, pre=w.x3, gamma=a.p("fuser.norm.weight"),
+                     beta=a.p("fuser.norm.bias"), y=w.y, mean=w.mf, rstd=w.rf, pair_out=w.fused),
+                dict(a=None, pre=c["t1_pre"], gamma=a.p(pl + "norm1.weight"), beta=a.p(pl + "norm1.bias"), y=c["t1"],
+                     mean=c["m1"], rstd=c["r1"])])
+        else:
+            ops.gemm(GEMM_NT, w.f1, a.p(pre + "mlp.mlp.2.weight"), w.x3, bias=a.p(pre + "mlp.mlp.2.bias"), res1=w.x1,
+                     res2=None if self.bn else w.x0, ws=self.ws)          # (no x_res in the BN-blend variant)
+            ops.layernorm_fwd_multi([                  # decoder norm1 and the fuser's final norm + token mean: one launch
+                dict(x=c["t1_pre"], gamma=a.p(pl + "norm1.weight"), beta=a.p(pl + "norm1.bias"), y=c["t1"], mean=c["m1"],
+                     rstd=c["r1"]),
+                dict(x=w.x3, gamma=a.p("fuser.norm.weight"), beta=a.p("fuser.norm.bias"), y=w.y, mean=w.mf, rstd=w.rf,
+                     pair_out=w.fused)])
         g3.launch()
 
     def _decoder_unfused(self, w, key_labels, dm, dsc, multi, main, s2, sa_block, paired=False):
@@ -561,10 +601,17 @@ class FusionEngine:
             # (paired: the layer-0 sub-layer ran inside _forward_paired)
             ops.mha_core_fwd(c["caq"], c["cakv"][:, :H], c["cakv"][:, H:], c["p_ca"], c["ca_o"], B, heads, Q, S, dh,
                              key_labels=key_labels, pad_idx=self.pad_idx, drop_mask=dm(f"ca_p{l}"), drop_scale=dsc)
-            ops.gemm(GEMM_NT, c["ca_o"], a.p(pl + "multihead_attn.out_proj.weight"), c["t2_pre"],
-                     bias=a.p(pl + "multihead_attn.out_proj.bias"), drop_mask=self._dm2(dm(f"d2_{l}"), BQ, H),
-                     drop_scale=dsc, res1=c["t1"], ws=self.ws)
-            ops.layernorm_fwd(c["t2_pre"], a.p(pl + "norm2.weight"), a.p(pl + "norm2.bias"), c["t2"], c["m2"], c["r2"])
+            if self._gln(BQ, H):      # out_proj -> dropout -> + tgt -> norm2 (transformer.py:304-306): one launch
+                ops.gemm_ln_fwd([dict(a=c["ca_o"], w=a.p(pl + "multihead_attn.out_proj.weight"),
+                                      bias=a.p(pl + "multihead_attn.out_proj.bias"),
+                                      drop_mask=self._dm2(dm(f"d2_{l}"), BQ, H), drop_scale=dsc, res1=c["t1"],
+                                      pre=c["t2_pre"], gamma=a.p(pl + "norm2.weight"), beta=a.p(pl + "norm2.bias"),
+                                      y=c["t2"], mean=c["m2"], rstd=c["r2"])])
+            else:
+                ops.gemm(GEMM_NT, c["ca_o"], a.p(pl + "multihead_attn.out_proj.weight"), c["t2_pre"],
+                         bias=a.p(pl + "multihead_attn.out_proj.bias"), drop_mask=self._dm2(dm(f"d2_{l}"), BQ, H),
+                         drop_scale=dsc, res1=c["t1"], ws=self.ws)
+                ops.layernorm_fwd(c["t2_pre"], a.p(pl + "norm2.weight"), a.p(pl + "norm2.bias"), c["t2"], c["m2"], c["r2"])
             ops.gemm(GEMM_NT, c["t2"], a.p(pl + "linear1.weight"), c["ff1"], bias=a.p(pl + "linear1.bias"), act=1,
                      drop_mask=self._dm2(dm(f"ff_{l}"), BQ, 4 * H), drop_scale=dsc, ws=self.ws)
             ops.gemm(GEMM_NT, c["ff1"], a.p(pl + "linear2.weight"), c["t3_pre"], bias=a.p(pl + "linear2.bias"),

@@ -282,6 +282,41 @@ def layernorm_fwd_multi(jobs):
     check(_lib.load().r3d_layernorm_fwd_multi(arr, len(jobs), _stream()), "r3d_layernorm_fwd_multi")
 
 
+def gemm_ln_supported(M, K, H):
+    return bool(_lib.load().r3d_gemm_ln_supported(int(M), int(K), int(H)))
+
+
+def gemm_ln_fwd(jobs):
+    """nn.Linear -> dropout -> residuals -> LayerNorm as ONE launch (gemm_ln.hip), up to 4 independent jobs.
+    job: dict(a [M,K] | None, w [H,K], bias, drop_mask, drop_scale, res1, res2, pre [M,H], gamma, beta, y, mean, rstd,
+    pair_out); a is None: the rows already in `pre` are normalised (plain LayerNorm job)."""
+    from ._lib import GemmLnJob
+    arr = (GemmLnJob * len(jobs))()
+    H = jobs[0]["pre"].shape[1]
+    for i, j in enumerate(jobs):
+        g = lambda k: j.get(k)                    # noqa: E731
+        a, t = arr[i], g("a")
+        M = j["pre"].shape[0]
+        assert j["pre"].shape[1] == H
+        if t is not None:
+            _f32(t, "A"), _f32(j["w"], "W")
+            assert j["w"].shape == (H, t.shape[1]) and t.shape[0] == M
+            a.A, a.lda, a.W, a.ldw, a.K = t.data_ptr(), _ld(t), j["w"].data_ptr(), _ld(j["w"]), t.shape[1]
+            a.bias = _pv(g("bias"))
+            a.drop_mask, a.lddrop = _pv(g("drop_mask")), _ld(g("drop_mask")) if g("drop_mask") is not None else 0
+            a.drop_scale = g("drop_scale") or 1.0
+            a.res1, a.ldr1 = _pv(g("res1")), _ld(g("res1")) if g("res1") is not None else 0
+            a.res2, a.ldr2 = _pv(g("res2")), _ld(g("res2")) if g("res2") is not None else 0
+        else:
+            a.K = 0
+        a.pre_out, a.ldpre = j["pre"].data_ptr(), _ld(j["pre"])
+        a.gamma, a.beta, a.y, a.ldy = j["gamma"].data_ptr(), j["beta"].data_ptr(), j["y"].data_ptr(), _ld(j["y"])
+        a.mean, a.rstd = j["mean"].data_ptr(), j["rstd"].data_ptr()
+        a.pair_out = _pv(g("pair_out"))
+        a.M = M
+    check(_lib.load().r3d_gemm_ln_fwd(arr, len(jobs), H, _stream()), "r3d_gemm_ln_fwd")
+
+
 def layernorm_bwd_multi(jobs):
     """jobs: up to 4 dicts with the arguments of layernorm_bwd (dy, x, mean, rstd, gamma, beta, dx, dgamma, dbeta,
     partial required; pair_in, relu, dy2, add1, add2, dx2, drop_mask, drop_scale optional)."""

@@ -243,6 +243,49 @@ def test_layernorm_deferred_and_batched_finalize(ops):
         assert_close(db.cpu(), rb, 1e-3, 1e-3, f"batched dbeta rows={rows}")
 
 
+@pytest.mark.parametrize("M,K", [(256, 128), (256, 512), (64, 128), (16, 256), (48, 384)])
+@pytest.mark.parametrize("full", [False, True])
+def test_gemm_ln_fwd_is_linear_dropout_residual_layernorm(ops, M, K, full):
+    """r3d_gemm_ln_fwd (row-complete GEMM with the LayerNorm as its epilogue) against fp64 nn.Linear -> mask -> residuals
+    -> F.layer_norm -> pair mean, alone and with a plain-LayerNorm job (K = 0) riding in the same launch."""
+    H = 128
+    a, w, bias = rnd(M, K + 4, seed=M + K)[:, :K], rnd(H, K, seed=K + 1, scale=K ** -0.5), 0.1 * rnd(H, seed=3)
+    g, b = 1 + 0.2 * rnd(H, seed=4), 0.1 * rnd(H, seed=5)
+    r1, r2 = rnd(M, H, seed=6), rnd(M, H, seed=7)
+    mask = (torch.rand(M, H, generator=torch.Generator().manual_seed(8)) > 0.1).to(torch.uint8)
+    dsc = 1.0 / 0.9
+    pre = a.double() @ w.double().t() + bias.double()
+    if full:
+        pre = pre * dsc * mask.double() + r1.double() + r2.double()
+    y = F.layer_norm(pre, (H,), g.double(), b.double(), 1e-5)
+    x2 = rnd(32, H, seed=9)
+    y2 = F.layer_norm(x2.double(), (H,), g.double(), b.double(), 1e-5)
+    f = lambda *sh: torch.full(sh, float("nan"), device="cuda")      # noqa: E731
+    pre_d, yd, mean, rstd, pair = f(M, H), f(M, H), f(M), f(M), f(M // 2, H)
+    x2d, y2d, m2, s2 = dev(x2), f(32, H), f(32), f(32)
+    ad = dev(rnd(M, K + 4, seed=M + K))[:, :K]
+    job = dict(a=ad, w=dev(w), bias=dev(bias), pre=pre_d, gamma=dev(g), beta=dev(b), y=yd, mean=mean, rstd=rstd, pair_out=pair)
+    if full:
+        job.update(drop_mask=dev(mask), drop_scale=dsc, res1=dev(r1), res2=dev(r2))
+    assert ops.gemm_ln_supported(M, K, H) and not ops.gemm_ln_supported(M + 1, K, H) and not ops.gemm_ln_supported(M, K, 256)
+    ops.gemm_ln_fwd([job, dict(a=None, pre=x2d, gamma=dev(g), beta=dev(b), y=y2d, mean=m2, rstd=s2)])
+    torch.cuda.synchronize()
+    assert_close(pre_d.cpu(), pre, 1e-5, 1e-5, "pre-norm rows")
+    assert_close(yd.cpu(), y, 1e-4, 1e-5, "y")
+    assert_close(mean.cpu(), pre.mean(1), 1e-5, 1e-5, "mean")
+    assert_close(rstd.cpu(), 1.0 / torch.sqrt(pre.var(1, unbiased=False) + 1e-5), 1e-4, 1e-5, "rstd")
+    assert_close(pair.cpu(), y.view(M // 2, 2, H).mean(1), 1e-4, 1e-5, "pair mean")
+    assert_close(y2d.cpu(), y2, 1e-4, 1e-5, "plain LayerNorm job")
+    assert torch.equal(x2d.cpu(), x2), "a K = 0 job must leave its rows untouched"
+    # the two-launch path writes the same buffers
+    pre_t, y_t, m_t, s_t = f(M, H), f(M, H), f(M), f(M)
+    kw = dict(drop_mask=dev(mask), drop_scale=dsc, res1=dev(r1), res2=dev(r2)) if full else {}
+    ops.gemm(0, ad, dev(w), pre_t, bias=dev(bias), ws=ops.GemmWorkspace("cuda"), **kw)
+    ops.layernorm_fwd(pre_t, dev(g), dev(b), y_t, m_t, s_t)
+    torch.cuda.synchronize()
+    assert_close(yd.cpu(), y_t.cpu().double(), 2e-5, 2e-5, "fused vs gemm + layernorm")
+
+
 def test_add_rowbcast(ops):
     x, add = rnd(24, 40, seed=1), rnd(8, 40, seed=2)
     out = torch.empty(24, 40, device="cuda")
