@@ -31,10 +31,19 @@ extern "C" {
 #define R3D_OK 0
 #define R3D_EINVAL (-1)
 #define R3D_EALIGN (-2)
+#define R3D_ENORCCL (-3)      /* r3d_allreduce_flat: no RCCL is mapped into the process */
+#define R3D_ERCCL_BASE (-100) /* r3d_allreduce_flat: ncclResult_t r is returned as R3D_ERCCL_BASE - r */
 
 int r3d_abi_version(void);
 /* Writes up to `cap` bytes "gfx950;<build info>" -- used by the host to fail loudly on a stale library. */
 int r3d_build_info(char* buf, int cap);
+
+/* ---- gradient exchange (data parallel; replaces the per-step nn.DataParallel gather through device 0, main_darai.py:129-133)
+ * In-place sum of buf[0..count) (fp32) over the ranks of `comm` (an ncclComm_t the caller created, e.g. r3d_amd.rccl.RcclComm):
+ * ncclAllReduce of the RCCL copy already loaded in the process (PyTorch's), enqueued on `stream` like every other entry
+ * point -- one more kernel in stream order, capturable into the step's hipGraph.  1/world is folded into
+ * r3d_adamw_flat's grad_scale.  The library itself does not link RCCL. */
+int r3d_allreduce_flat(float* buf, int64_t count, void* comm, void* stream);
 
 /* ---- GEMM family ------------------------------------------------------------------------------------------
  * One fp32-exact MFMA GEMM (v_mfma_f32_32x32x2_f32, LDS-staged k-major tiles) carries every dense contraction of

@@ -97,6 +97,7 @@ _I, _L, _F, _P, _D = C.c_int, C.c_int64, C.c_float, C.c_void_p, C.c_double
 _SIGNATURES = {
     "r3d_abi_version": ([], C.c_int),
     "r3d_build_info": ([C.c_char_p, _I], C.c_int),
+    "r3d_allreduce_flat": ([_P, _L, _P, _P], C.c_int),
     "r3d_gemm_f32": ([C.POINTER(GemmDesc), _P], C.c_int),
     "r3d_splitk_reduce": ([C.POINTER(GemmDesc), _P], C.c_int),
     "r3d_gemm_partial_floats": ([C.c_int32, C.c_int32, C.c_int32], C.c_int64),
@@ -200,10 +201,13 @@ def load():
     return lib
 
 
-_ERR = {-1: "R3D_EINVAL (rejected argument)", -2: "R3D_EALIGN (misaligned pointer / leading dimension)"}
+_ERR = {-1: "R3D_EINVAL (rejected argument)", -2: "R3D_EALIGN (misaligned pointer / leading dimension)",
+        -3: "R3D_ENORCCL (no RCCL mapped into the process)"}
 
 
 def check(rc, what):
+    if rc <= -100:
+        raise R3DHipError(f"{what} failed: ncclResult_t {-100 - rc} from RCCL")
     if rc != 0:
         raise R3DHipError(f"{what} failed: {_ERR.get(rc, f'hipError_t {rc}' if rc > 0 else rc)}")
 

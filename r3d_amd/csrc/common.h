@@ -6,6 +6,8 @@
 #define R3D_OK 0
 #define R3D_EINVAL (-1)     // bad argument (null pointer, negative size, unsupported shape)
 #define R3D_EALIGN (-2)     // pointer / leading dimension violates an alignment the entry point documents
+#define R3D_ENORCCL (-3)
+#define R3D_ERCCL_BASE (-100)
 
 #define R3D_EXPORT extern "C" __attribute__((visibility("default")))
 

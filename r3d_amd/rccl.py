@@ -117,6 +117,11 @@ class RcclComm:
     def all_reduce(self, t, stream=None):
         """In-place sum over the ranks."""
         self._ok(t)
+        if t.dtype == torch.float32:          # the gradient buckets: through the C ABI (r3d_allreduce_flat, include/r3d_hip.h)
+            from . import _lib as _abi
+            _abi.check(_abi.load().r3d_allreduce_flat(t.data_ptr(), t.numel(), self._comm, _stream(stream)),
+                       "r3d_allreduce_flat")
+            return
         _check(_load().ncclAllReduce(t.data_ptr(), t.data_ptr(), t.numel(), _DTYPES[t.dtype], _NCCL_SUM, self._comm,
                                      _stream(stream)), "ncclAllReduce")
 

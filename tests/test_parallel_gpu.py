@@ -355,6 +355,52 @@ def test_train_loop_rccl_step_one_rank_equals_single_gpu():
     assert status == "ok", info
 
 
+def _allreduce_flat_worker(port, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+        from r3d_amd import _lib
+        from r3d_amd.rccl import RcclComm
+        lib = _lib.load()
+        comm = RcclComm()
+        x = torch.arange(1000, dtype=torch.float32, device="cuda") * 0.25
+        ref = x.clone()
+        st = torch.cuda.current_stream().cuda_stream
+        assert lib.r3d_allreduce_flat(x.data_ptr(), x.numel(), comm._comm, st) == 0
+        assert lib.r3d_allreduce_flat(None, 4, comm._comm, st) == -1            # R3D_EINVAL
+        assert lib.r3d_allreduce_flat(x.data_ptr(), 4, None, st) == -1
+        assert lib.r3d_allreduce_flat(x.data_ptr(), 0, comm._comm, st) == 0
+        comm.all_reduce(x)                      # the float32 path of RcclComm goes through the same entry point
+        g = torch.cuda.CUDAGraph()              # ... and is capturable into a hipGraph like the step's other launches
+        with torch.cuda.graph(g):
+            x.mul_(2.0)
+            comm.all_reduce(x)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(x, ref * 2.0), float((x - ref * 2.0).abs().max())    # (capture records, the replay runs it once)
+        comm.close()
+        q.put((0, "ok", ""))
+    except Exception as e:          # noqa: BLE001
+        import traceback
+        q.put((0, "fail", traceback.format_exc() + repr(e)))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_allreduce_flat_c_abi_one_rank():
+    """r3d_allreduce_flat (the C-ABI gradient exchange, include/r3d_hip.h) finds the RCCL copy PyTorch loaded, sums in
+    place over a one-rank communicator (identity), rejects null arguments and replays from a hipGraph."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_allreduce_flat_worker, args=(_free_port(), q))
+    p.start()
+    rank, status, info = q.get(timeout=300)
+    p.join(timeout=60)
+    assert status == "ok", info
+
+
 # ----------------------------------------------------------------------------------------------------------
 # train(--pixel_shard) on the sharded RcclStep with a one-batch look-ahead
 # ----------------------------------------------------------------------------------------------------------
