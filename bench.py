@@ -263,6 +263,9 @@ def main():
                          "graphs per step) instead of RCCL enqueued on the launch stream")
     ap.add_argument("--no-gemm-ln", action="store_true",
                     help="LayerNorm sites as GEMM + LayerNorm launches instead of the row-complete gemm_ln kernel (A/B)")
+    ap.add_argument("--no-defer-loss", action="store_true",
+                    help="reduce the loss statistics inside the loss kernel (last-arriving workgroup) instead of in one extra "
+                         "workgroup of the AdamW launch (A/B)")
     ap.add_argument("--separate-tail", action="store_true",
                     help="decoder tail forward, losses and tail backward as three launches instead of one")
     ap.add_argument("--frame-major-input", action="store_true",
@@ -326,6 +329,9 @@ def main():
     eng.use_fused_decoder = a.fused_decoder
     eng.use_gemm_ln = not a.no_gemm_ln
     eng.defer_tail = not a.separate_tail      # forward -> losses -> backward run back to back: one tail/loss launch
+    # single-GPU flow: the loss / counter statistics (read by the host after the run) are reduced by one extra workgroup
+    # of the AdamW launch instead of the loss kernel's last-arriving workgroup (the multi-GPU flows keep the latter)
+    eng.defer_loss_reduce = not dist_on and not a.no_defer_loss
     from r3d_amd.parallel import DataParallelStep
     feats, depth, lab, dur, tgt = make_inputs(c, device, seed=1 + rank)
     x_dep2d = depth.reshape(c["B"] * c["S"], -1)

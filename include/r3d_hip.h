@@ -376,6 +376,9 @@ typedef struct r3d_tail_losses_args {
     int B, S, Q, K, pad_idx, exclude_idx; const float* dur_den; float grad_scale;
     float* d_seg; int ld_dseg; float* d_out; int ld_dout; float* loss_out; int64_t* counts; int64_t* tick_a; int64_t* tick_b;
     const uint8_t* drop; float drop_scale; float* dx; float* dx2; float* wsF; float* ws3;
+    int defer_finalize;      /* != 0: the launch leaves the per-unit loss partials in ws (and ticks the counters) but does NOT
+                                reduce them into loss_out / counts -- no arrival atomics, no last-workgroup pass at the end of
+                                the step's longest small kernel; r3d_losses_finalize or r3d_adamw_flat_dropout_fin does it */
 } r3d_tail_losses_args;
 int r3d_decoder_tail_losses_supported(int H, int n_head, int Q, int rows);
 int r3d_decoder_tail_losses(const r3d_tail_losses_args* a, float* ws, void* stream);
@@ -389,6 +392,21 @@ int r3d_adamw_flat(float* p, const float* g, float* m, float* v, int64_t n, cons
 int r3d_adamw_flat_dropout(float* p, const float* g, float* m, float* v, int64_t n, const float* lr, const int64_t* step,
                            float beta1, float beta2, float eps, float weight_decay, float grad_scale, uint8_t* mask,
                            int64_t n_mask, float p_drop, uint64_t seed, const int64_t* offset, void* stream);
+/* The reduction r3d_decoder_tail_losses(defer_finalize) left out: loss_out[4] / counts[4] from the 4-float partials of the
+ * B*S + B*Q + B units in `part` (the ws of that call), exactly as the undeferred launch computes them (fp64 sums, fixed
+ * order).  Stand-alone launch, or -- r3d_adamw_flat_dropout_fin -- one extra workgroup of the AdamW launch, where it costs
+ * nothing: the losses are host-visible statistics (utils.py:375-376 reads them per step with .item(); here once per
+ * epoch), nothing on the device depends on them. */
+typedef struct r3d_loss_finalize_job {
+    const float* part; int32_t B, S, Q, has_seg;
+    const float* dur_den;            /* optional device scalar, as in r3d_losses_fwd_bwd */
+    float* loss_out; int64_t* counts;
+} r3d_loss_finalize_job;
+int r3d_losses_finalize(const r3d_loss_finalize_job* job, void* stream);
+int r3d_adamw_flat_dropout_fin(float* p, const float* g, float* m, float* v, int64_t n, const float* lr, const int64_t* step,
+                               float beta1, float beta2, float eps, float weight_decay, float grad_scale, uint8_t* mask,
+                               int64_t n_mask, float p_drop, uint64_t seed, const int64_t* offset,
+                               const r3d_loss_finalize_job* fin, void* stream);
 /* The same update on a [rows x cols] block (leading dimension ld) of p/g/m/v: a pixel shard of depth_projection.weight. */
 int r3d_adamw_2d(float* p, const float* g, float* m, float* v, int rows, int cols, int ld, const float* lr,
                  const int64_t* step, float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream);

@@ -82,7 +82,13 @@ class TailLossesArgs(C.Structure):
                 [("dur_den", C.c_void_p), ("grad_scale", C.c_float), ("d_seg", C.c_void_p), ("ld_dseg", C.c_int32),
                  ("d_out", C.c_void_p), ("ld_dout", C.c_int32), ("loss_out", C.c_void_p), ("counts", C.c_void_p),
                  ("tick_a", C.c_void_p), ("tick_b", C.c_void_p), ("drop", C.c_void_p), ("drop_scale", C.c_float)] +
-                [(n, C.c_void_p) for n in ("dx", "dx2", "wsF", "ws3")])
+                [(n, C.c_void_p) for n in ("dx", "dx2", "wsF", "ws3")] + [("defer_finalize", C.c_int32)])
+
+
+class LossFinalizeJob(C.Structure):
+    """struct r3d_loss_finalize_job"""
+    _fields_ = [("part", C.c_void_p), ("B", C.c_int32), ("S", C.c_int32), ("Q", C.c_int32), ("has_seg", C.c_int32),
+                ("dur_den", C.c_void_p), ("loss_out", C.c_void_p), ("counts", C.c_void_p)]
 
 
 class LnFinalizeJob(C.Structure):
@@ -149,6 +155,8 @@ _SIGNATURES = {
     "r3d_losses_ws_floats": ([_I, _I, _I], C.c_int64),
     "r3d_adamw_flat": ([_P, _P, _P, _P, _L, _P, _P, _F, _F, _F, _F, _F, _P], C.c_int),
     "r3d_adamw_flat_dropout": ([_P, _P, _P, _P, _L, _P, _P, _F, _F, _F, _F, _F, _P, _L, _F, C.c_uint64, _P, _P], C.c_int),
+    "r3d_losses_finalize": ([_P, _P], C.c_int),
+    "r3d_adamw_flat_dropout_fin": ([_P, _P, _P, _P, _L, _P, _P, _F, _F, _F, _F, _F, _P, _L, _F, C.c_uint64, _P, _P, _P], C.c_int),
     "r3d_adamw_2d": ([_P, _P, _P, _P, _I, _I, _I, _P, _P, _F, _F, _F, _F, _F, _P], C.c_int),
     "r3d_dropout_mask": ([_P, _L, _F, C.c_uint64, _P, _P], C.c_int),
     "r3d_erank_lds_bytes": ([_I, _I], C.c_int64),

@@ -9,6 +9,7 @@
 // one-workgroup finaliser with a fixed reduction order -> bitwise reproducible.
 #include "common.h"
 #include "../../include/r3d_hip.h"
+#include "loss_finalize.h"
 
 namespace r3d {
 
@@ -470,6 +471,15 @@ __global__ __launch_bounds__(512) void tail_losses_kernel(const r3d_tail_losses_
         const int u = ((int)blockIdx.x - a.B) * 8 + wave;
         if (u < N) losses_unit(a, part, u, lane);
     }
+    if (t.defer_finalize) {
+        // the partials stay in `part` for a later launch (r3d_losses_finalize / the AdamW launch's extra workgroup): no
+        // agent-scope arrival round trip and no last-workgroup pass at the end of this chain; only the counters tick here
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            if (a.tick_a) *a.tick_a += 1;
+            if (a.tick_b) *a.tick_b += 1;
+        }
+        return;
+    }
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
     if (threadIdx.x == 0)
@@ -478,6 +488,11 @@ __global__ __launch_bounds__(512) void tail_losses_kernel(const r3d_tail_losses_
     if (!is_last) return;
     losses_finalize8(a, part);
     if (threadIdx.x == 0) *arrivals = 0u;
+}
+
+__global__ __launch_bounds__(256) void losses_finalize_kernel(const r3d_loss_finalize_job j) {
+    __shared__ double red[4][3][3];
+    loss_finalize_block<4>(j, red);
 }
 
 }  // namespace r3d
@@ -541,6 +556,17 @@ R3D_EXPORT int r3d_decoder_tail_losses(const r3d_tail_losses_args* p, float* ws,
     const int grid = t.B + r3d_cdiv(t.B * t.S, 8);
     hipLaunchKernelGGL(tail_losses_kernel, dim3(grid), dim3(512), 0, (hipStream_t)stream, t, a, ws,
                        reinterpret_cast<unsigned*>(ws + 4 * (size_t)units));
+    R3D_LAUNCH_CHECK();
+    return R3D_OK;
+}
+
+static int loss_finalize_job_ok(const r3d_loss_finalize_job* j) {
+    return j && j->part && j->loss_out && j->counts && j->B > 0 && j->S > 0 && j->Q > 0;
+}
+
+R3D_EXPORT int r3d_losses_finalize(const r3d_loss_finalize_job* job, void* stream) {
+    R3D_REQUIRE(loss_finalize_job_ok(job));
+    hipLaunchKernelGGL(losses_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *job);
     R3D_LAUNCH_CHECK();
     return R3D_OK;
 }

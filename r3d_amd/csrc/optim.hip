@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include "common.h"
 #include "../../include/r3d_hip.h"
+#include "loss_finalize.h"
 
 namespace r3d {
 
@@ -148,6 +149,21 @@ __global__ __launch_bounds__(256) void adamw_dropout_kernel(float4* __restrict__
     else dropout_body(mask, n_mask, thresh, seed, offset_ptr, blockIdx.x - nb_adam, gridDim.x - nb_adam);
 }
 
+// ... and the reduction of the step's loss partials as ONE more workgroup (r3d_decoder_tail_losses(defer_finalize)):
+// host-visible statistics nothing on the device waits for, so they leave the loss kernel's chain and hide here.
+__global__ __launch_bounds__(256) void adamw_dropout_fin_kernel(float4* __restrict__ p, const float4* __restrict__ g,
+                                                                float4* __restrict__ m, float4* __restrict__ v, size_t n4,
+                                                                const float* lr_ptr, const int64_t* step_ptr, float b1,
+                                                                float b2, float eps, float wd, float gscale, unsigned nb_adam,
+                                                                uint8_t* mask, size_t n_mask, uint32_t thresh, uint64_t seed,
+                                                                const int64_t* offset_ptr, const r3d_loss_finalize_job fin) {
+    __shared__ double red[4][3][3];
+    if (blockIdx.x < nb_adam) adamw_body(p, g, m, v, n4, lr_ptr, step_ptr, b1, b2, eps, wd, gscale, blockIdx.x, nb_adam);
+    else if (blockIdx.x + 1 < gridDim.x) dropout_body(mask, n_mask, thresh, seed, offset_ptr, blockIdx.x - nb_adam,
+                                                      gridDim.x - 1 - nb_adam);
+    else loss_finalize_block<4>(fin, red);
+}
+
 }  // namespace r3d
 
 using namespace r3d;
@@ -192,6 +208,31 @@ R3D_EXPORT int r3d_adamw_flat_dropout(float* p, const float* g, float* m, float*
     hipLaunchKernelGGL(adamw_dropout_kernel, dim3(nb_adam + nb_drop), dim3(256), 0, (hipStream_t)stream, (float4*)p,
                        (const float4*)g, (float4*)m, (float4*)v, n4, lr, step, beta1, beta2, eps, weight_decay, grad_scale,
                        nb_adam, mask, (size_t)n_mask, thresh, seed, offset);
+    R3D_LAUNCH_CHECK();
+    return R3D_OK;
+}
+
+/* r3d_adamw_flat_dropout + the deferred loss reduction (fin; NULL = plain r3d_adamw_flat_dropout). */
+R3D_EXPORT int r3d_adamw_flat_dropout_fin(float* p, const float* g, float* m, float* v, int64_t n, const float* lr,
+                                          const int64_t* step, float beta1, float beta2, float eps, float weight_decay,
+                                          float grad_scale, uint8_t* mask, int64_t n_mask, float p_drop, uint64_t seed,
+                                          const int64_t* offset, const r3d_loss_finalize_job* fin, void* stream) {
+    if (!fin)
+        return r3d_adamw_flat_dropout(p, g, m, v, n, lr, step, beta1, beta2, eps, weight_decay, grad_scale, mask, n_mask,
+                                      p_drop, seed, offset, stream);
+    R3D_REQUIRE(p && g && m && v && lr && step && n > 0 && mask && n_mask > 0 && p_drop >= 0.f && p_drop < 1.f);
+    R3D_REQUIRE((n % 4) == 0);
+    R3D_REQUIRE(fin->part && fin->loss_out && fin->counts && fin->B > 0 && fin->S > 0 && fin->Q > 0);
+    if (!(r3d_aligned16(p) && r3d_aligned16(g) && r3d_aligned16(m) && r3d_aligned16(v))) return R3D_EALIGN;
+    const size_t n4 = (size_t)n / 4;
+    const unsigned nb_adam = (unsigned)adam_blocks(n4);
+    const double t = (double)p_drop * 4294967296.0;
+    const uint32_t thresh = (uint32_t)(t >= 4294967295.0 ? 4294967295.0 : t);
+    const size_t m4 = ((size_t)n_mask + 3) / 4;
+    const unsigned nb_drop = (unsigned)((m4 + 255) / 256 < 512 ? (m4 + 255) / 256 : 512);
+    hipLaunchKernelGGL(adamw_dropout_fin_kernel, dim3(nb_adam + nb_drop + 1), dim3(256), 0, (hipStream_t)stream, (float4*)p,
+                       (const float4*)g, (float4*)m, (float4*)v, n4, lr, step, beta1, beta2, eps, weight_decay, grad_scale,
+                       nb_adam, mask, (size_t)n_mask, thresh, seed, offset, *fin);
     R3D_LAUNCH_CHECK();
     return R3D_OK;
 }

@@ -205,6 +205,10 @@ class FusionEngine:
         # hidden = 128: nn.Linear -> dropout -> residuals -> LayerNorm sites run as ONE row-complete launch (gemm_ln.hip)
         # instead of GEMM + LayerNorm: a dependent launch and a memory round trip less per site
         self.use_gemm_ln = True
+        # fused training flows (forward -> losses(tick=True) -> backward -> adamw(ticked=True)) may set this: the loss
+        # kernel then leaves the reduction of its per-unit partials (loss / counter statistics only the host reads) to
+        # one extra workgroup of the AdamW launch -- w.loss / w.counts are valid after adamw(), not after losses()
+        self.defer_loss_reduce = False
         # the two depth-projection GEMMs (83 % of the step's FLOPs) on the bf16 matrix cores through an exact three-way
         # operand split (csrc/gemm_bf3.hip; error per product <= 3 * 2^-24); 0 = the fp32 MFMA everywhere
         self.depth_prec = 1
@@ -691,14 +695,17 @@ class FusionEngine:
             if with_grad and not val_mode:
                 # forward tail + losses + backward tail: one launch (losses.hip: tail_losses_kernel)
                 drop = self.last["drop"]
+                defer = bool(self.defer_loss_reduce and tick)
                 ops.decoder_tail_losses(**tail, seg=w.seg, past_label=past_label, target=target, target_dur=target_dur,
                                         B=w.B, S=w.S, Q=self.Q, K=K, pad_idx=self.pad_idx, exclude_idx=EXCLUDE_CLASS_IDX,
                                         dur_den=self.dur_den, grad_scale=1.0, d_seg=w.d_seg, d_out=w.d_actdur, loss_out=w.loss,
                                         counts=w.counts, tick_a=ta, tick_b=tb,
                                         drop=w.drop[f"d3_{Lm}"] if drop else None, drop_scale=1.0 / (1.0 - DROP_P),
                                         dx=w.glayers[Lm]["t3pre"], dx2=w.glayers[Lm]["ff2"], wsF=w.lnp["final"],
-                                        ws3=w.lnp[f"d3_{Lm}"], ws=w.loss_ws)
+                                        ws3=w.lnp[f"d3_{Lm}"], ws=w.loss_ws, defer_finalize=defer)
                 w._tail_done = True
+                self._loss_pending = ops.loss_finalize_job(w.loss_ws, w.B, w.S, self.Q, True, self.dur_den, w.loss,
+                                                           w.counts) if defer else None
                 return w.loss, w.counts
             ops.decoder_tail_fwd(tail["x"], tail["g3"], tail["b3"], tail["gF"], tail["bF"], tail["w_head"], tail["b_head"],
                                  tail["t3"], tail["m3"], tail["r3"], tail["tgtF"], tail["mF"], tail["rF"], tail["out"])
@@ -1068,14 +1075,18 @@ class FusionEngine:
                          weight_decay=weight_decay, grad_scale=grad_scale)
         if before_flat is not None:
             before_flat()
+        pending, self._loss_pending = getattr(self, "_loss_pending", None), None
         if prefill_dropout and st is not None and st["drop"] and (ticked or tick_dropout):
             ops.adamw_flat_dropout(a.params[:n], a.grads[:n], a.exp_avg[:n], a.exp_avg_sq[:n], self.lr_t, self.step_t,
                                    st["w"].drop_pool, DROP_P, self.drop_seed, self.drop_offset, beta1=betas[0], beta2=betas[1],
-                                   eps=eps, weight_decay=weight_decay, grad_scale=grad_scale)
+                                   eps=eps, weight_decay=weight_decay, grad_scale=grad_scale, loss_fin=pending)
             self._drop_ready = st["w"]
+            pending = None
         else:
             ops.adamw_flat(a.params[:n], a.grads[:n], a.exp_avg[:n], a.exp_avg_sq[:n], self.lr_t, self.step_t,
                            beta1=betas[0], beta2=betas[1], eps=eps, weight_decay=weight_decay, grad_scale=grad_scale)
+        if pending is not None:                     # (no carrier launch on this path: the reduction goes alone)
+            ops.losses_finalize(pending)
         if self.tp is not None and not skip_depth and not depth_cols_first:
             t = self.tp                             # depth_projection.weight: only this rank's pixel columns are live
             ops.adamw_2d(t.w, t.g, t.m, t.v, self.lr_t, self.step_t, beta1=betas[0], beta2=betas[1], eps=eps,
@@ -1084,11 +1095,12 @@ class FusionEngine:
     def train_step(self, feats, depth, past_label, target_dur, target, lr, weight_decay, training=True):
         """forward + losses + backward + AdamW, all enqueued, no host sync.  Returns (loss[4], counts[4]) on device."""
         keep, self.defer_tail = self.defer_tail, True       # forward -> losses -> backward back to back: one tail launch
+        keep_r, self.defer_loss_reduce = self.defer_loss_reduce, True     # loss statistics reduced in the AdamW launch
         try:
             self.forward(feats, depth, past_label, "train", training)
+            loss, counts = self.losses(past_label, target, target_dur, tick=True)
         finally:
-            self.defer_tail = keep
-        loss, counts = self.losses(past_label, target, target_dur, tick=True)
+            self.defer_tail, self.defer_loss_reduce = keep, keep_r
         # (backward(fused_adamw=...) + adamw(skip_depth=True) would update depth_projection.weight inside its
         #  weight-gradient GEMM; measured neutral at the bench shape, so the plain sequence stays the default)
         self.backward()

@@ -557,8 +557,9 @@ def tail_losses_supported(H, n_head, Q, rows):
 
 def decoder_tail_losses(*, x, g3, b3, gF, bF, w_head, b_head, t3, m3, r3, tgtF, mF, rF, out, seg, past_label, target,
                         target_dur, B, S, Q, K, pad_idx, exclude_idx, dur_den, grad_scale, d_seg, d_out, loss_out, counts,
-                        tick_a, tick_b, drop, drop_scale, dx, dx2, wsF, ws3, ws):
-    """r3d_decoder_tail_fwd + r3d_losses_fwd_bwd + r3d_decoder_tail_bwd in one launch (training step)."""
+                        tick_a, tick_b, drop, drop_scale, dx, dx2, wsF, ws3, ws, defer_finalize=False):
+    """r3d_decoder_tail_fwd + r3d_losses_fwd_bwd + r3d_decoder_tail_bwd in one launch (training step).
+    defer_finalize: leave the reduction of the loss partials (ws) to losses_finalize() / adamw_flat_dropout(loss_fin=...)."""
     from ._lib import TailLossesArgs
     assert past_label.dtype == torch.int64 and target.dtype == torch.int64 and target_dur.dtype == torch.float32
     assert past_label.is_contiguous() and target.is_contiguous() and target_dur.is_contiguous()
@@ -577,6 +578,7 @@ def decoder_tail_losses(*, x, g3, b3, gF, bF, w_head, b_head, t3, m3, r3, tgtF, 
     a.ld_seg, a.ld_dseg, a.ld_dout = _ld(seg), _ld(d_seg), _ld(d_out)
     a.B, a.S, a.Q, a.K, a.pad_idx, a.exclude_idx = B, S, Q, K, pad_idx, exclude_idx
     a.grad_scale, a.drop_scale = grad_scale, drop_scale
+    a.defer_finalize = 1 if defer_finalize else 0
     check(_lib.load().r3d_decoder_tail_losses(C.byref(a), _p(ws), _stream()), "r3d_decoder_tail_losses")
 
 
@@ -593,12 +595,31 @@ def adamw_flat(p, g, m, v, lr_t, step_t, *, beta1=0.9, beta2=0.999, eps=1e-8, we
                              _stream()), "r3d_adamw_flat")
 
 
+def loss_finalize_job(part, B, S, Q, has_seg, dur_den, loss_out, counts):
+    """r3d_loss_finalize_job for the partials a decoder_tail_losses(defer_finalize=True) launch left in `part`."""
+    from ._lib import LossFinalizeJob
+    j = LossFinalizeJob()
+    j.part, j.B, j.S, j.Q, j.has_seg = part.data_ptr(), B, S, Q, 1 if has_seg else 0
+    j.dur_den, j.loss_out, j.counts = _pv(dur_den), loss_out.data_ptr(), counts.data_ptr()
+    return j
+
+
+def losses_finalize(job):
+    check(_lib.load().r3d_losses_finalize(C.byref(job), _stream()), "r3d_losses_finalize")
+
+
 def adamw_flat_dropout(p, g, m, v, lr_t, step_t, mask, p_drop, seed, offset_t, *, beta1=0.9, beta2=0.999, eps=1e-8,
-                       weight_decay=0.0, grad_scale=1.0):
-    """adamw_flat + dropout_mask(mask, p_drop, seed, offset_t) in one launch (the masks are the next step's)."""
+                       weight_decay=0.0, grad_scale=1.0, loss_fin=None):
+    """adamw_flat + dropout_mask(mask, p_drop, seed, offset_t) in one launch (the masks are the next step's); loss_fin
+    (a loss_finalize_job): the deferred loss reduction rides along as one more workgroup."""
     lib = _lib.load()
     n = p.numel()
     assert g.numel() == n and m.numel() == n and v.numel() == n and mask.dtype == torch.uint8
+    if loss_fin is not None:
+        check(lib.r3d_adamw_flat_dropout_fin(_p(p), _p(g), _p(m), _p(v), n, _p(lr_t), _p(step_t), beta1, beta2, eps,
+                                             weight_decay, grad_scale, _p(mask), mask.numel(), p_drop, seed, _p(offset_t),
+                                             C.byref(loss_fin), _stream()), "r3d_adamw_flat_dropout_fin")
+        return
     check(lib.r3d_adamw_flat_dropout(_p(p), _p(g), _p(m), _p(v), n, _p(lr_t), _p(step_t), beta1, beta2, eps, weight_decay,
                                      grad_scale, _p(mask), mask.numel(), p_drop, seed, _p(offset_t), _stream()),
           "r3d_adamw_flat_dropout")

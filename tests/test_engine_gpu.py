@@ -471,3 +471,34 @@ def test_deferred_tail_one_launch_equals_three(oracle_lib):
         assert torch.equal(a["counts"], b["counts"]) and a["step"] == b["step"]
         d = (a["grads"] - b["grads"]).abs().max()
         assert float(d) <= 2e-5 * float(a["grads"].abs().max()), (float(d), float(a["grads"].abs().max()))
+
+
+def test_deferred_loss_reduction_in_the_adamw_launch():
+    """engine.defer_loss_reduce: the loss kernel leaves its per-unit partials unreduced (no arrival atomics, no
+    last-workgroup pass) and one extra workgroup of the AdamW launch -- or r3d_losses_finalize on paths without that
+    launch -- writes the same losses and counters; counters tick, gradients and the parameter update are bit-identical."""
+    import bench
+    c = dict(bench.CFG)
+    for prefill in (True, False):
+        res = []
+        for defer in (False, True):
+            model = bench.build_model(c, torch.device("cuda"))
+            eng = model.engine()
+            eng.defer_tail, eng.defer_loss_reduce = True, defer
+            feats, depth, lab, dur, tgt = bench.make_inputs(c, torch.device("cuda"), seed=7)
+            for _ in range(2):
+                eng.forward(feats, depth, lab, "train", True)
+                loss, counts = eng.losses(lab, tgt, dur, tick=True)
+                assert (getattr(eng, "_loss_pending", None) is not None) == defer
+                eng.backward()
+                grads = eng.arena.grads.clone()
+                eng.adamw(c["lr"], c["wd"], ticked=True, prefill_dropout=prefill)
+                assert getattr(eng, "_loss_pending", None) is None
+            torch.cuda.synchronize()
+            res.append(dict(loss=loss.clone(), counts=counts.clone(), grads=grads, params=eng.arena.params.clone(),
+                            step=int(eng.step_t), off=int(eng.drop_offset)))
+        a, b = res
+        assert torch.equal(a["loss"], b["loss"]), (a["loss"], b["loss"])
+        assert torch.equal(a["counts"], b["counts"]) and a["step"] == b["step"] == 2 and a["off"] == b["off"]
+        assert torch.equal(a["grads"], b["grads"]) and torch.equal(a["params"], b["params"])
+        assert float(a["loss"][3]) > 0 and int(a["counts"][1]) > 0
