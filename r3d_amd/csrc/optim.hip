@@ -158,10 +158,12 @@ __global__ __launch_bounds__(256) void adamw_dropout_fin_kernel(float4* __restri
                                                                 uint8_t* mask, size_t n_mask, uint32_t thresh, uint64_t seed,
                                                                 const int64_t* offset_ptr, const r3d_loss_finalize_job fin) {
     __shared__ double red[4][3][3];
-    if (blockIdx.x < nb_adam) adamw_body(p, g, m, v, n4, lr_ptr, step_ptr, b1, b2, eps, wd, gscale, blockIdx.x, nb_adam);
-    else if (blockIdx.x + 1 < gridDim.x) dropout_body(mask, n_mask, thresh, seed, offset_ptr, blockIdx.x - nb_adam,
-                                                      gridDim.x - 1 - nb_adam);
-    else loss_finalize_block<4>(fin, red);
+    // workgroup 0 (dispatched first): its load -> reduce -> store chain then runs under the streaming workgroups instead of
+    // trailing the launch (as the LAST workgroup it lengthened the kernel by ~2 us)
+    if (blockIdx.x == 0) { loss_finalize_block<4>(fin, red); return; }
+    const unsigned bid = blockIdx.x - 1;
+    if (bid < nb_adam) adamw_body(p, g, m, v, n4, lr_ptr, step_ptr, b1, b2, eps, wd, gscale, bid, nb_adam);
+    else dropout_body(mask, n_mask, thresh, seed, offset_ptr, bid - nb_adam, gridDim.x - 1 - nb_adam);
 }
 
 }  // namespace r3d
