@@ -397,7 +397,9 @@ class FusionEngine:
         # One decoder layer on one stream: the query self-attention sub-layer depends on parameters only, the fuser block
         # only on the embeddings -- their GEMMs are paired into shared launches (ops.GemmGroup) instead of queueing
         # behind each other.  Otherwise: branch s2 (or inline) first, then the fuser chain.
-        paired = self.use_paired_launches and (not fused_dec) and (not multi) and self.L == 1
+        # (hidden >= 512: the shared launches' single tile and missing split-K cost more than the launches they save --
+        #  cfg5's per-GPU shape 1.87 -> 1.69 ms/step unpaired, cfg4's 1.191 -> 1.179)
+        paired = self.use_paired_launches and (not fused_dec) and (not multi) and self.L == 1 and H < 512
         if multi and fw["rgb_done"] is None:
             s2.wait_stream(main)              # (otherwise forward_begin already forked this branch)
         if not fused_dec and not paired:
@@ -768,6 +770,8 @@ class FusionEngine:
         pre = "fuser.blocks.0."
         P = []
 
+        # (hidden >= 512: taking the 2 GFLOP weight gradients out of this launch and through the planner one by one was
+        #  measured and reverted -- cfg4's per-GPU shape 1.179 -> 1.212 ms, cfg5's 1.690 -> 1.721)
         def add(dy, x, gw, gb=None, b_add=None, b_mod=0):
             P.append(dict(a=dy, b=x, c=gw, bias_grad=gb, b_add=b_add, b_add_mod=b_mod))
         add(w.d_actdur, w.tgtF, self.gw_head, self.gb_head)
