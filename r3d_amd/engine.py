@@ -770,8 +770,9 @@ class FusionEngine:
         pre = "fuser.blocks.0."
         P = []
 
-        # (hidden >= 512: taking the 2 GFLOP weight gradients out of this launch and through the planner one by one was
-        #  measured and reverted -- cfg4's per-GPU shape 1.179 -> 1.212 ms, cfg5's 1.690 -> 1.721)
+        # (hidden >= 512: taking the 0.5 - 2 GFLOP weight gradients out of this launch was measured twice and reverted --
+        #  through the planner's fp32 tiles cfg4's per-GPU shape went 1.179 -> 1.212 ms, cfg5's 1.690 -> 1.721; through the
+        #  bf16x3 TN kernel (128 x 128 tiles: 64 workgroups for a [2048, 512] gradient, a quarter of the chip) 1.241 / 1.685)
         def add(dy, x, gw, gb=None, b_add=None, b_mod=0):
             P.append(dict(a=dy, b=x, c=gw, bias_grad=gb, b_add=b_add, b_add_mod=b_mod))
         add(w.d_actdur, w.tgtF, self.gw_head, self.gb_head)
