@@ -188,6 +188,7 @@ class FusionEngine:
         self.bn = hasattr(module.fuser, "bn_rgb")
         self.arena = ParamArena(list(module.named_parameters()), self.device, BN_LIVE_PREFIXES if self.bn else ())
         self.ws = ops.GemmWorkspace(self.device)
+        self._sel = {}                                  # constant 0/1 selection matrices of _wgrad_with_sums
         self.ws_side = ops.GemmWorkspace(self.device)
         self.side = torch.cuda.Stream(self.device)      # weight-gradient stream: off the backward's critical path
         self.side2 = torch.cuda.Stream(self.device)     # independent branch (self-attention of the queries)
@@ -209,6 +210,10 @@ class FusionEngine:
         # kernel then leaves the reduction of its per-unit partials (loss / counter statistics only the host reads) to
         # one extra workgroup of the AdamW launch -- w.loss / w.counts are valid after adamw(), not after losses()
         self.defer_loss_reduce = False
+        # the bias / broadcast-parameter / LayerNorm-parameter sums at the end of the backward as problems of the grouped
+        # weight-gradient launch (a column sum over the rows of a residue class is a TN product with a constant 0/1
+        # selection matrix) instead of a launch of their own
+        self.fold_rowsums = True
         # the two depth-projection GEMMs (83 % of the step's FLOPs) on the bf16 matrix cores through an exact three-way
         # operand split (csrc/gemm_bf3.hip; error per product <= 3 * 2^-24); 0 = the fp32 MFMA everywhere
         self.depth_prec = 1
@@ -797,6 +802,7 @@ class FusionEngine:
         w.rgb_wgrad_idx = len(P)
         add(w.d_rgb_pre, self.last["x_rgb"], a.g("input_embed.weight"), a.g("input_embed.bias"))
         w.wgrad_group = ops.GemmGroup(GEMM_TN, P, tile=1 if H < 256 else 2)
+        w.wgrad_problems, w.wgrad_plus = P, {}
         J = [(w.lnp["final"], BQ, H, a.g("transformer.decoder.norm.weight"), a.g("transformer.decoder.norm.bias")),
              (w.lnp["nf"], 2 * N, H, a.g("fuser.norm.weight"), a.g("fuser.norm.bias")),
              (w.lnp["n2"], 2 * N, H, a.g(pre + "norm2.weight"), a.g(pre + "norm2.bias")),
@@ -839,11 +845,34 @@ class FusionEngine:
                     return None                 # layernorm_bwd wrote the final values itself
             o = (dg.data_ptr() - a.grads.data_ptr()) // 4
             return (part[:blocks * 2 * Hh].view(blocks, 2 * Hh), None, 1, a.grads[o:o + 2 * Hh].view(1, 2 * Hh))
-        w.tail_groups = {}
+        w.tail_groups, w.tail_jobs = {}, {}
         for name, jobs in (("plain", J), ("seam", Js)) + ((("bn", Jb),) if Jb is not None else ()):
             conv = [as_rowsum(j) for j in jobs]
             if all(c is not None for c in conv):
                 w.tail_groups[name] = ops.RowsumGroup(R + conv)
+                w.tail_jobs[name] = R + conv
+
+    def _wgrad_with_sums(self, w, name):
+        """The grouped weight-gradient launch with the row-sum jobs of tail group `name` folded in as TN problems:
+        dst[r, :] = sum over rows with row % mod == r of (src1 + src2) = sel^T . (src1 + src2), sel[row, row % mod] = 1
+        (exact products, fp32 accumulation).  None when the table would not fit the kernel's 32-problem argument."""
+        if name in w.wgrad_plus:
+            return w.wgrad_plus[name]
+        g = None
+        jobs = w.tail_jobs.get(name)
+        if jobs is not None and len(w.wgrad_problems) + len(jobs) <= 32 and self.H < 256:
+            extra = []
+            for s1, s2, mod, dst in jobs:
+                rows = s1.shape[0]
+                key = (rows, mod)
+                if key not in self._sel:
+                    sel = torch.zeros(rows, mod, dtype=torch.float32, device=self.device)
+                    sel[torch.arange(rows, device=self.device), torch.arange(rows, device=self.device) % mod] = 1.0
+                    self._sel[key] = sel
+                extra.append(dict(a=self._sel[key], b=s1, c=dst, b_add=s2, b_add_mod=rows if s2 is not None else 0))
+            g = ops.GemmGroup(GEMM_TN, w.wgrad_problems + extra, tile=1)
+        w.wgrad_plus[name] = g
+        return g
 
     def backward_main(self, d_seg=None, d_actdur=None):
         """Everything of the backward except depth_projection.weight.
@@ -1037,10 +1066,15 @@ class FusionEngine:
         if not joined:
             main.wait_stream(s2)
         # ---- everything that only feeds parameter gradients: 2 launches + the broadcast-parameter sums
-        w.wgrad_group.set_b(w.rgb_wgrad_idx, st["x_rgb"])
-        w.wgrad_group.launch()
-        tail = w.tail_groups.get("bn" if self.bn else ("seam" if st["seam"] else "plain"))
-        if tail is not None:               # pos_embedding (:190), depth_projection.bias, query_embed (top layer) and
+        tname = "bn" if self.bn else ("seam" if st["seam"] else "plain")
+        both = self._wgrad_with_sums(w, tname) if (self.fold_rowsums and self.L == 1) else None
+        wg = both if both is not None else w.wgrad_group
+        wg.set_b(w.rgb_wgrad_idx, st["x_rgb"])
+        wg.launch()
+        tail = w.tail_groups.get(tname)
+        if both is not None:               # (the sums below rode in the weight-gradient launch)
+            pass
+        elif tail is not None:             # pos_embedding (:190), depth_projection.bias, query_embed (top layer) and
             tail.launch()                  # every LayerNorm parameter gradient: one launch
         else:
             assert not self.bn, "BN-blend variant: LayerNorm gradient slots must be adjacent in the arena"
