@@ -266,6 +266,8 @@ def main():
     ap.add_argument("--no-fold-rowsums", action="store_true",
                     help="bias / broadcast / LayerNorm parameter sums as their own launch instead of problems of the grouped "
                          "weight-gradient launch (A/B)")
+    ap.add_argument("--no-ride-attention", action="store_true",
+                    help="the query self-attention cores as launches of their own instead of riders (A/B)")
     ap.add_argument("--no-paired", action="store_true",
                     help="every GEMM of the fuser / query-branch chains through the planner on its own (no shared launches)")
     ap.add_argument("--no-defer-loss", action="store_true",
@@ -336,6 +338,7 @@ def main():
     if a.no_paired:
         eng.use_paired_launches = False
     eng.fold_rowsums = not a.no_fold_rowsums
+    eng.ride_attention = not a.no_ride_attention
     eng.defer_tail = not a.separate_tail      # forward -> losses -> backward run back to back: one tail/loss launch
     # single-GPU flow: the loss / counter statistics (read by the host after the run) are reduced by one extra workgroup
     # of the AdamW launch instead of the loss kernel's last-arriving workgroup (the multi-GPU flows keep the latter)

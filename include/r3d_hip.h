@@ -231,6 +231,18 @@ typedef struct r3d_gemm_ln_job {
 } r3d_gemm_ln_job;
 int r3d_gemm_ln_supported(int M, int K, int H);
 int r3d_gemm_ln_fwd(const r3d_gemm_ln_job* jobs, int njobs, int H, void* stream);
+/* The same launch carrying an INDEPENDENT small attention core (the arguments of r3d_mha_core_fwd; heads * 8 queries, dh 16,
+ * <= 64 keys: r3d_gemm_ln_mha_supported) as extra workgroups: the query self-attention of decoder layer 0
+ * (model/extras/transformer.py:289-291 with tgt = 0, model/futr_safuser_tokenfusion.py:205-209) depends on parameters only,
+ * so it needs no launch of its own and rides beside the fuser's attn.proj + norm2. */
+typedef struct r3d_mha_job {
+    const float* q; int32_t ldq; const float* k; int32_t ldk; const float* v; int32_t ldv;
+    const uint8_t* key_padding_mask; const int64_t* key_label; int32_t pad_idx;
+    float* probs; const uint8_t* drop_mask; float drop_scale; float* o; int32_t ldo;
+    int32_t B, heads, Lq, Lk, dh;
+} r3d_mha_job;
+int r3d_gemm_ln_mha_supported(int heads, int Lq, int Lk, int dh);
+int r3d_gemm_ln_mha_fwd(const r3d_gemm_ln_job* jobs, int njobs, int H, const r3d_mha_job* mha, void* stream);
 
 /* ---- token selection / exchange: CMFuser.token_fusion (model/futr_safuser_tokenfusion.py:33-66) ------------- */
 /* out[c] = sum_r |x[r,c]| in fp64 (the eval-mode score before the division by B*T, :49-50). */

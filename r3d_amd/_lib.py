@@ -66,6 +66,15 @@ class GemmLnJob(C.Structure):
                 ("pair_out", C.c_void_p), ("M", C.c_int32), ("K", C.c_int32)]
 
 
+class MhaJob(C.Structure):
+    """struct r3d_mha_job"""
+    _fields_ = [("q", C.c_void_p), ("ldq", C.c_int32), ("k", C.c_void_p), ("ldk", C.c_int32), ("v", C.c_void_p),
+                ("ldv", C.c_int32), ("key_padding_mask", C.c_void_p), ("key_label", C.c_void_p), ("pad_idx", C.c_int32),
+                ("probs", C.c_void_p), ("drop_mask", C.c_void_p), ("drop_scale", C.c_float), ("o", C.c_void_p),
+                ("ldo", C.c_int32), ("B", C.c_int32), ("heads", C.c_int32), ("Lq", C.c_int32), ("Lk", C.c_int32),
+                ("dh", C.c_int32)]
+
+
 class RowsumJob(C.Structure):
     """struct r3d_rowsum_job"""
     _fields_ = [("src1", C.c_void_p), ("src2", C.c_void_p), ("dst", C.c_void_p), ("ld1", C.c_int32), ("ld2", C.c_int32),
@@ -112,6 +121,8 @@ _SIGNATURES = {
     "r3d_gemm_grouped_launch": ([_P, _P, C.POINTER(C.c_int32), _I, _I, _I, _I, _P], C.c_int),
     "r3d_gemm_ln_supported": ([_I, _I, _I], C.c_int),
     "r3d_gemm_ln_fwd": ([_P, _I, _I, _P], C.c_int),
+    "r3d_gemm_ln_mha_supported": ([_I, _I, _I, _I], C.c_int),
+    "r3d_gemm_ln_mha_fwd": ([_P, _I, _I, _P, _P], C.c_int),
     "r3d_layernorm_fwd_multi": ([_P, _I, _P], C.c_int),
     "r3d_layernorm_bwd_multi": ([_P, _I, _P], C.c_int),
     "r3d_layernorm_bwd_finalize_batched": ([_P, _I, _I, _P], C.c_int),

@@ -17,6 +17,7 @@
 // futr_safuser_tokenfusion.py:92-94 (x + x_res -> norm -> mean), transformer.py:292-293,304-306 (out_proj -> dropout ->
 // residual -> norm1 / norm2).
 #include "common.h"
+#include "mha_small.h"
 #include "../../include/r3d_hip.h"
 
 namespace r3d {
@@ -31,6 +32,11 @@ struct GemmLnArgs {
     GemmLnJob j[4];
     int prefix[5];
     int njobs;
+    // rider: an independent small attention core (dh 16, 8 queries, <= 64 keys; mha_small.h) -- workgroups past prefix[4]
+    // run 8 (clip, head) units each, one per wave.  The query self-attention of decoder layer 0 depends on parameters
+    // only (tgt = 0), so it needs no launch of its own: it rides beside the fuser's attn.proj + norm2.
+    MhaArgs mha;
+    int mha_units;
 };
 
 // sum over the 16 lanes of a DPP row; every lane of the row ends with the row's value
@@ -136,6 +142,12 @@ __global__ __launch_bounds__(512) void gemm_ln_fwd_kernel(const GemmLnArgs args)
     float (*red)[8][kGlnRows] = reinterpret_cast<float (*)[8][kGlnRows]>(lds + kGlnAFloats + kGlnWFloats);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, q = lane >> 4;
+    if ((int)blockIdx.x >= args.prefix[4]) {                    // rider role (see GemmLnArgs)
+        const int unit = ((int)blockIdx.x - args.prefix[4]) * 8 + wave;
+        static_assert(8 * mha_small_lds_floats(16, 8) <= kGlnAFloats + kGlnWFloats, "rider LDS");
+        if (unit < args.mha_units) mha_fwd_small_unit<16, 8, false>(args.mha, unit, lds + wave * mha_small_lds_floats(16, 8));
+        return;
+    }
     int jb = 0;
 #pragma unroll
     for (int t = 1; t < 4; ++t) jb += (t < args.njobs && (int)blockIdx.x >= args.prefix[t]) ? 1 : 0;
@@ -228,11 +240,13 @@ __global__ __launch_bounds__(512) void gemm_ln_fwd_kernel(const GemmLnArgs args)
 
 }  // namespace r3d
 
+R3D_EXPORT int r3d_gemm_ln_mha_supported(int heads, int Lq, int Lk, int dh);
+
 R3D_EXPORT int r3d_gemm_ln_supported(int M, int K, int H) {
     return (H == r3d::kGlnH && M > 0 && (M % r3d::kGlnRows) == 0 && K >= 0 && K <= 512 && (K % 128) == 0) ? 1 : 0;
 }
 
-R3D_EXPORT int r3d_gemm_ln_fwd(const r3d_gemm_ln_job* jobs, int njobs, int H, void* stream) {
+static int gemm_ln_launch(const r3d_gemm_ln_job* jobs, int njobs, int H, const r3d_mha_job* mha, void* stream) {
     R3D_REQUIRE(jobs && njobs >= 1 && njobs <= 4);
     r3d::GemmLnArgs a{};
     int total = 0;
@@ -254,10 +268,40 @@ R3D_EXPORT int r3d_gemm_ln_fwd(const r3d_gemm_ln_job* jobs, int njobs, int H, vo
     }
     for (int i = njobs; i <= 4; ++i) a.prefix[i] = total;
     a.njobs = njobs;
+    int extra = 0;
+    if (mha) {
+        R3D_REQUIRE(r3d_gemm_ln_mha_supported(mha->heads, mha->Lq, mha->Lk, mha->dh));
+        R3D_REQUIRE(mha->q && mha->k && mha->v && mha->probs && mha->o && mha->B > 0);
+        const int Hm = mha->heads * mha->dh;
+        R3D_REQUIRE(mha->ldq >= Hm && mha->ldk >= Hm && mha->ldv >= Hm && mha->ldo >= Hm);
+        if (((mha->ldk | mha->ldv) & 3) || !r3d_aligned16(mha->k) || !r3d_aligned16(mha->v)) return R3D_EALIGN;
+        r3d::MhaArgs& m = a.mha;
+        m.q = mha->q; m.ldq = mha->ldq; m.k = mha->k; m.ldk = mha->ldk; m.v = mha->v; m.ldv = mha->ldv;
+        m.kpm = mha->key_padding_mask; m.key_label = mha->key_label; m.pad_idx = mha->pad_idx; m.probs = mha->probs;
+        m.drop = mha->drop_mask; m.drop_scale = mha->drop_scale; m.o = mha->o; m.ldo = mha->ldo;
+        m.B = mha->B; m.heads = mha->heads; m.Lq = mha->Lq; m.Lk = mha->Lk; m.dh = mha->dh;
+        m.scale = 1.0f / sqrtf((float)mha->dh);
+        a.mha_units = mha->B * mha->heads;
+        extra = r3d_cdiv(a.mha_units, 8);
+    }
     hipError_t e = hipFuncSetAttribute((const void*)r3d::gemm_ln_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        r3d::kGlnLdsBytes);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(r3d::gemm_ln_fwd_kernel, dim3(total), dim3(512), (size_t)r3d::kGlnLdsBytes, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(r3d::gemm_ln_fwd_kernel, dim3(total + extra), dim3(512), (size_t)r3d::kGlnLdsBytes,
+                       (hipStream_t)stream, a);
     R3D_LAUNCH_CHECK();
     return R3D_OK;
+}
+
+R3D_EXPORT int r3d_gemm_ln_mha_supported(int heads, int Lq, int Lk, int dh) {
+    return (heads > 0 && Lq == 8 && dh == 16 && Lk > 0 && Lk <= 64) ? 1 : 0;
+}
+
+R3D_EXPORT int r3d_gemm_ln_fwd(const r3d_gemm_ln_job* jobs, int njobs, int H, void* stream) {
+    return gemm_ln_launch(jobs, njobs, H, nullptr, stream);
+}
+
+R3D_EXPORT int r3d_gemm_ln_mha_fwd(const r3d_gemm_ln_job* jobs, int njobs, int H, const r3d_mha_job* mha, void* stream) {
+    R3D_REQUIRE(mha);
+    return gemm_ln_launch(jobs, njobs, H, mha, stream);
 }

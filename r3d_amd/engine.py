@@ -214,6 +214,8 @@ class FusionEngine:
         # weight-gradient launch (a column sum over the rows of a residue class is a TN product with a constant 0/1
         # selection matrix) instead of a launch of their own
         self.fold_rowsums = True
+        # the parameter-only query self-attention core of decoder layer 0 as extra workgroups of the gemm_ln launch
+        self.ride_attention = True
         # the two depth-projection GEMMs (83 % of the step's FLOPs) on the bf16 matrix cores through an exact three-way
         # operand split (csrc/gemm_bf3.hip; error per product <= 3 * 2^-24); 0 = the fp32 MFMA everywhere
         self.depth_prec = 1
@@ -563,15 +565,20 @@ class FusionEngine:
         g1, g2, g3 = w.tables[key]
         g1.launch()
         gln = self._gln(2 * w.N, H) and self._gln(2 * w.N, 4 * H) and self._gln(BQ, 0)
-        if gln:      # attn.proj + x -> norm2 (transformerblock.py:131-132): the LayerNorm is the product's epilogue
+        sa = dict(q=c["sa_qkv"][:, :H], k=c["sa_qkv"][:, H:2 * H], v=c["sa_qkv"][:, 2 * H:], probs=c["p_sa"], o=c["sa_o"], B=B,
+                  heads=heads, Lq=Q, Lk=Q, dh=dh, drop_mask=dm("sa_p0"), drop_scale=dsc)
+        ride = gln and self.ride_attention and ops.gemm_ln_mha_supported(heads, Q, Q, dh)
+        if gln:      # attn.proj + x -> norm2 (transformerblock.py:131-132): the LayerNorm is the product's epilogue; the
+            #          query self-attention core (parameters only) rides in the same launch
             ops.gemm_ln_fwd([dict(a=w.vsw, w=a.p(pre + "attn.proj.weight"), bias=a.p(pre + "attn.proj.bias"), res1=w.x0,
                                   pre=w.x1, gamma=a.p(pre + "norm2.weight"), beta=a.p(pre + "norm2.bias"), y=w.h2,
-                                  mean=w.m2, rstd=w.r2)])
+                                  mean=w.m2, rstd=w.r2)], mha=sa if ride else None)
         else:
             ops.gemm(GEMM_NT, w.vsw, a.p(pre + "attn.proj.weight"), w.x1, bias=a.p(pre + "attn.proj.bias"), res1=w.x0,
                      ws=self.ws)
-        ops.mha_core_fwd(c["sa_qkv"][:, :H], c["sa_qkv"][:, H:2 * H], c["sa_qkv"][:, 2 * H:], c["p_sa"], c["sa_o"], B, heads,
-                         Q, Q, dh, drop_mask=dm("sa_p0"), drop_scale=dsc)
+        if not ride:
+            ops.mha_core_fwd(sa["q"], sa["k"], sa["v"], sa["probs"], sa["o"], B, heads, Q, Q, dh, drop_mask=sa["drop_mask"],
+                             drop_scale=dsc)
         if not gln:
             ops.layernorm_fwd(w.x1, a.p(pre + "norm2.weight"), a.p(pre + "norm2.bias"), w.h2, w.m2, w.r2)
         g2.launch()

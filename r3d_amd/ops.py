@@ -286,8 +286,14 @@ def gemm_ln_supported(M, K, H):
     return bool(_lib.load().r3d_gemm_ln_supported(int(M), int(K), int(H)))
 
 
-def gemm_ln_fwd(jobs):
+def gemm_ln_mha_supported(heads, Lq, Lk, dh):
+    return bool(_lib.load().r3d_gemm_ln_mha_supported(int(heads), int(Lq), int(Lk), int(dh)))
+
+
+def gemm_ln_fwd(jobs, mha=None):
     """nn.Linear -> dropout -> residuals -> LayerNorm as ONE launch (gemm_ln.hip), up to 4 independent jobs.
+    mha: dict with the arguments of mha_core_fwd (q, k, v, probs, o, B, heads, Lq, Lk, dh[, drop_mask, drop_scale]) -- an
+    independent small attention core riding in the same launch (r3d_gemm_ln_mha_fwd).
     job: dict(a [M,K] | None, w [H,K], bias, drop_mask, drop_scale, res1, res2, pre [M,H], gamma, beta, y, mean, rstd,
     pair_out); a is None: the rows already in `pre` are normalised (plain LayerNorm job)."""
     from ._lib import GemmLnJob
@@ -314,6 +320,17 @@ def gemm_ln_fwd(jobs):
         a.mean, a.rstd = j["mean"].data_ptr(), j["rstd"].data_ptr()
         a.pair_out = _pv(g("pair_out"))
         a.M = M
+    if mha is not None:
+        from ._lib import MhaJob
+        m, g = MhaJob(), mha.get
+        m.q, m.ldq, m.k, m.ldk, m.v, m.ldv = (mha["q"].data_ptr(), _ld(mha["q"]), mha["k"].data_ptr(), _ld(mha["k"]),
+                                              mha["v"].data_ptr(), _ld(mha["v"]))
+        m.key_padding_mask, m.key_label, m.pad_idx = _pv(g("kpm")), _pv(g("key_labels")), g("pad_idx") or 0
+        m.probs, m.drop_mask, m.drop_scale = mha["probs"].data_ptr(), _pv(g("drop_mask")), g("drop_scale") or 1.0
+        m.o, m.ldo = mha["o"].data_ptr(), _ld(mha["o"])
+        m.B, m.heads, m.Lq, m.Lk, m.dh = mha["B"], mha["heads"], mha["Lq"], mha["Lk"], mha["dh"]
+        check(_lib.load().r3d_gemm_ln_mha_fwd(arr, len(jobs), H, C.byref(m), _stream()), "r3d_gemm_ln_mha_fwd")
+        return
     check(_lib.load().r3d_gemm_ln_fwd(arr, len(jobs), H, _stream()), "r3d_gemm_ln_fwd")
 
 
