@@ -183,6 +183,16 @@ typedef struct r3d_ln_bwd_job {
 } r3d_ln_bwd_job;
 int r3d_layernorm_fwd_multi(const r3d_ln_fwd_job* jobs, int njobs, void* stream);
 int r3d_layernorm_bwd_multi(r3d_ln_bwd_job* jobs, int njobs, void* stream);
+/* r3d_layernorm_bwd_multi (hidden <= 128) carrying an INDEPENDENT small attention backward (the arguments of
+ * r3d_mha_core_bwd; 8 queries, dh 16, <= 64 keys) as extra workgroups: the backward of decoder layer 0's query
+ * self-attention feeds parameter gradients only and rides beside the fuser's norm2 backward. */
+typedef struct r3d_mha_bwd_job {
+    const float* q; int32_t ldq; const float* k; int32_t ldk; const float* v; int32_t ldv;
+    const float* probs; const uint8_t* drop_mask; float drop_scale;
+    const float* d_o; int32_t lddo; float* dq; int32_t lddq; float* dk; int32_t lddk; float* dv; int32_t lddv;
+    int32_t B, heads, Lq, Lk, dh;
+} r3d_mha_bwd_job;
+int r3d_layernorm_bwd_multi_mha(r3d_ln_bwd_job* jobs, int njobs, const r3d_mha_bwd_job* mha, void* stream);
 /* The same for many LayerNorm sites in one launch; jobs live in device memory. */
 /* rows > 0: ws holds the partials r3d_layernorm_bwd left for that many rows; rows < 0: exactly -rows (dgamma, dbeta)
  * pairs [-rows][2][H] written by another producer (r3d_embed_fuse_bwd). */

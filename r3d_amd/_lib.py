@@ -75,6 +75,15 @@ class MhaJob(C.Structure):
                 ("dh", C.c_int32)]
 
 
+class MhaBwdJob(C.Structure):
+    """struct r3d_mha_bwd_job"""
+    _fields_ = [("q", C.c_void_p), ("ldq", C.c_int32), ("k", C.c_void_p), ("ldk", C.c_int32), ("v", C.c_void_p),
+                ("ldv", C.c_int32), ("probs", C.c_void_p), ("drop_mask", C.c_void_p), ("drop_scale", C.c_float),
+                ("d_o", C.c_void_p), ("lddo", C.c_int32), ("dq", C.c_void_p), ("lddq", C.c_int32), ("dk", C.c_void_p),
+                ("lddk", C.c_int32), ("dv", C.c_void_p), ("lddv", C.c_int32), ("B", C.c_int32), ("heads", C.c_int32),
+                ("Lq", C.c_int32), ("Lk", C.c_int32), ("dh", C.c_int32)]
+
+
 class RowsumJob(C.Structure):
     """struct r3d_rowsum_job"""
     _fields_ = [("src1", C.c_void_p), ("src2", C.c_void_p), ("dst", C.c_void_p), ("ld1", C.c_int32), ("ld2", C.c_int32),
@@ -125,6 +134,7 @@ _SIGNATURES = {
     "r3d_gemm_ln_mha_fwd": ([_P, _I, _I, _P, _P], C.c_int),
     "r3d_layernorm_fwd_multi": ([_P, _I, _P], C.c_int),
     "r3d_layernorm_bwd_multi": ([_P, _I, _P], C.c_int),
+    "r3d_layernorm_bwd_multi_mha": ([_P, _I, _P, _P], C.c_int),
     "r3d_layernorm_bwd_finalize_batched": ([_P, _I, _I, _P], C.c_int),
     "r3d_layernorm_fwd": ([_P, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P], C.c_int),
     "r3d_layernorm_bwd_ws_floats": ([_I, _I], C.c_int64),

@@ -3,6 +3,7 @@
 // lane c owns columns c, c+64, ... (256-B coalesced wave accesses); reductions are wave shuffles -> no LDS traffic
 // on the row path and bitwise run-to-run reproducible results (no float atomics anywhere).
 #include "common.h"
+#include "mha_small.h"
 #include "../../include/r3d_hip.h"
 
 namespace r3d {
@@ -133,6 +134,20 @@ template <int EPL>
 __global__ __launch_bounds__(256) void ln_bwd_multi_kernel(const LnBwdMulti m) {
     extern __shared__ __attribute__((aligned(16))) float red[];     // [4][2][H]
     ln_bwd_block<EPL>(m.j[blockIdx.y], red);
+}
+
+// ln_bwd_multi_kernel with a RIDER: blockIdx.y == njobs runs an independent small attention backward (dh 16, 8 queries,
+// <= 64 keys; mha_small.h), 4 (clip, head) units per workgroup.  The backward of decoder layer 0's query self-attention
+// feeds parameter gradients only, so it rides beside the fuser's norm2 backward instead of costing a launch.
+struct LnBwdMultiMha { LnBwdArgs j[4]; int njobs; MhaArgs mha; int mha_units; };
+
+template <int EPL>
+__global__ __launch_bounds__(256) void ln_bwd_multi_mha_kernel(const LnBwdMultiMha m) {
+    extern __shared__ __attribute__((aligned(16))) float red[];     // max([4][2][H], 4 x attention unit)
+    if ((int)blockIdx.y < m.njobs) { ln_bwd_block<EPL>(m.j[blockIdx.y], red); return; }
+    const int wave = threadIdx.x >> 6;
+    const int unit = (int)blockIdx.x * 4 + wave;
+    if (unit < m.mha_units) mha_bwd_small_unit<16, 8, false>(m.mha, unit, red + wave * mha_small_bwd_lds_floats(16, 8));
 }
 
 template <int EPL>
@@ -481,6 +496,50 @@ R3D_EXPORT int r3d_layernorm_bwd_multi(r3d_ln_bwd_job* jobs, int njobs, void* st
     }
     return launch_epl(ln_bwd_multi_kernel<32>, ln_bwd_multi_kernel<16>, ln_bwd_multi_kernel<8>, ln_bwd_multi_kernel<2>, H,
                       dim3(maxb, njobs), (size_t)8 * H * sizeof(float), (hipStream_t)stream, m);
+}
+
+R3D_EXPORT int r3d_layernorm_bwd_multi_mha(r3d_ln_bwd_job* jobs, int njobs, const r3d_mha_bwd_job* mha, void* stream) {
+    R3D_REQUIRE(jobs && njobs >= 1 && njobs <= 4 && mha);
+    LnBwdMultiMha m{};
+    int maxb = 0;
+    const int H = jobs[0].H;
+    R3D_REQUIRE(H > 0 && H <= 128);                        /* (the EPL = 2 instance; wider models launch the two separately) */
+    for (int i = 0; i < njobs; ++i) {
+        r3d_ln_bwd_job& a = jobs[i];
+        R3D_REQUIRE(a.dy && a.x && a.mean && a.rstd && a.gamma && a.beta && a.dx);
+        R3D_REQUIRE(a.rows > 0 && a.H == H && a.ldx >= H && a.lddx >= H && a.lddy >= H);
+        R3D_REQUIRE((a.dgamma == nullptr) == (a.dbeta == nullptr));
+        R3D_REQUIRE(!a.pair_in || (a.rows % 2) == 0);
+        R3D_REQUIRE(!a.dy2 || a.lddy2 >= H);
+        a.rows_per_block = ln_bwd_rows_per_block(a.rows);
+        a.nblocks = r3d_cdiv(a.rows, a.rows_per_block);
+        R3D_REQUIRE(a.nblocks == 1 || !a.dgamma || a.ws);
+        maxb = a.nblocks > maxb ? a.nblocks : maxb;
+        m.j[i] = a;
+    }
+    m.njobs = njobs;
+    R3D_REQUIRE(mha->heads > 0 && mha->Lq == 8 && mha->dh == 16 && mha->Lk > 0 && mha->Lk <= 64 && mha->B > 0);
+    R3D_REQUIRE(mha->q && mha->k && mha->v && mha->probs && mha->d_o && mha->dq && mha->dk && mha->dv);
+    const int Hm = mha->heads * mha->dh;
+    R3D_REQUIRE(mha->ldq >= Hm && mha->ldk >= Hm && mha->ldv >= Hm && mha->lddo >= Hm && mha->lddq >= Hm &&
+                mha->lddk >= Hm && mha->lddv >= Hm);
+    if (((mha->ldk | mha->ldv | mha->lddk | mha->lddv) & 3) || !r3d_aligned16(mha->k) || !r3d_aligned16(mha->v) ||
+        !r3d_aligned16(mha->dk) || !r3d_aligned16(mha->dv))
+        return R3D_EALIGN;
+    MhaArgs& g = m.mha;
+    g.q = mha->q; g.ldq = mha->ldq; g.k = mha->k; g.ldk = mha->ldk; g.v = mha->v; g.ldv = mha->ldv;
+    g.probs = const_cast<float*>(mha->probs); g.drop = mha->drop_mask; g.drop_scale = mha->drop_scale;
+    g.d_o = mha->d_o; g.lddo = mha->lddo; g.dq = mha->dq; g.lddq = mha->lddq; g.dk = mha->dk; g.lddk = mha->lddk;
+    g.dv = mha->dv; g.lddv = mha->lddv;
+    g.B = mha->B; g.heads = mha->heads; g.Lq = mha->Lq; g.Lk = mha->Lk; g.dh = mha->dh;
+    g.scale = 1.0f / sqrtf((float)mha->dh);
+    m.mha_units = mha->B * mha->heads;
+    const int rb = r3d_cdiv(m.mha_units, 4);
+    const size_t lds_ln = (size_t)8 * H * sizeof(float), lds_mha = (size_t)4 * mha_small_bwd_lds_floats(16, 8) * sizeof(float);
+    hipLaunchKernelGGL(ln_bwd_multi_mha_kernel<2>, dim3(maxb > rb ? maxb : rb, njobs + 1), dim3(256),
+                       lds_ln > lds_mha ? lds_ln : lds_mha, (hipStream_t)stream, m);
+    R3D_LAUNCH_CHECK();
+    return R3D_OK;
 }
 
 static int colsum_chunks(int rows) { int c = r3d_cdiv(rows, 64); return c < 1 ? 1 : (c > 32 ? 32 : c); }

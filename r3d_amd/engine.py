@@ -216,6 +216,10 @@ class FusionEngine:
         self.fold_rowsums = True
         # the parameter-only query self-attention core of decoder layer 0 as extra workgroups of the gemm_ln launch
         self.ride_attention = True
+        # ... and its backward core as extra workgroups of the fuser's norm2-backward launch (r3d_layernorm_bwd_multi_mha),
+        # with the branch's input-projection gradient moved to the chain's last group: one launch fewer but measured SLOWER
+        # (0.2382 -> 0.2410 ms/step: the K = 3H product lengthens the last group and the rider outlasts its host), so off
+        self.ride_attention_bwd = False
         # the two depth-projection GEMMs (83 % of the step's FLOPs) on the bf16 matrix cores through an exact three-way
         # operand split (csrc/gemm_bf3.hip; error per product <= 3 * 2^-24); 0 = the fp32 MFMA everywhere
         self.depth_prec = 1
@@ -1004,6 +1008,14 @@ class FusionEngine:
                 w.tables[("bwd_vh1",)] = ops.GemmGroup(GEMM_NN, [
                     dict(a=w.d_x1, b=a.p(pre + "attn.proj.weight"), c=w.d_v, c_row_xor=1),
                     dict(a=w.d_x1, b=w.wc, c=w.d_h1, c_row_xor=1)], tile=t)
+                # ride_attention: the query self-attention's backward core rides in the fuser's norm2-backward launch, so
+                # its input-projection gradient moves from the third group to the last one of the chain
+                w.tables[("bwd_ride",)] = (
+                    ops.GemmGroup(GEMM_NN, [dict(a=w.d_u, b=a.p(pre + "mlp.mlp.0.weight"), c=w.d_h2)], tile=t),
+                    ops.GemmGroup(GEMM_NN, [
+                        dict(a=w.d_x1, b=a.p(pre + "attn.proj.weight"), c=w.d_v, c_row_xor=1),
+                        dict(a=w.d_x1, b=w.wc, c=w.d_h1, c_row_xor=1),
+                        dict(a=gl["saqkv"], b=a.p(pl + "self_attn.in_proj_weight"), c=gl["sain"])], tile=t))
                 w.tables[key] = (
                     ops.GemmGroup(GEMM_NN, first, tile=t),
                     ops.GemmGroup(GEMM_NN, [dict(a=gl["sap"], b=a.p(pl + "self_attn.out_proj.weight"), c=gl["sao"]),
@@ -1023,10 +1035,14 @@ class FusionEngine:
                 lnj("nf", w.d_fused, w.x3, w.mf, w.rf, "fuser.norm.weight", "fuser.norm.bias", w.d_x3, pair_in=True,
                     dy2=w.d_fused2)])
             gb2.launch()
-            ops.mha_core_bwd(c["sa_qkv"][:, :H], c["sa_qkv"][:, H:2 * H], c["sa_qkv"][:, 2 * H:], c["p_sa"], gl["sao"],
-                             gl["saqkv"][:, :H], gl["saqkv"][:, H:2 * H], gl["saqkv"][:, 2 * H:], B, heads, Q, Q, dh,
-                             drop_mask=dmf("sa_p0"), drop_scale=dsc)
-            gb3.launch()
+            ride_bwd = bool(self.ride_attention_bwd and H <= 128 and ops.gemm_ln_mha_supported(heads, Q, Q, dh))
+            if ride_bwd:
+                w.tables[("bwd_ride",)][0].launch()                  # d_u -> d_h2 alone; the attention core follows below
+            else:
+                ops.mha_core_bwd(c["sa_qkv"][:, :H], c["sa_qkv"][:, H:2 * H], c["sa_qkv"][:, 2 * H:], c["p_sa"], gl["sao"],
+                                 gl["saqkv"][:, :H], gl["saqkv"][:, H:2 * H], gl["saqkv"][:, 2 * H:], B, heads, Q, Q, dh,
+                                 drop_mask=dmf("sa_p0"), drop_scale=dsc)
+                gb3.launch()
         else:
             if st.get("erank"):
                 self._erank_backward(w, ws)
@@ -1034,8 +1050,23 @@ class FusionEngine:
                    dy2=w.d_fused2)
             ops.gemm(GEMM_NN, w.d_x3, a.p(pre + "mlp.mlp.2.weight"), w.d_u, aux=w.u, mul=2, ws=ws)
             ops.gemm(GEMM_NN, w.d_u, a.p(pre + "mlp.mlp.0.weight"), w.d_h2, ws=ws)
-        ln_bwd("n2", w.d_h2, w.x1, w.m2, w.r2, pre + "norm2.weight", pre + "norm2.bias", w.d_x1, add1=w.d_x3)
-        if st.get("paired"):
+        ride_bwd = bool(st.get("paired") and self.ride_attention_bwd and H <= 128 and
+                        ops.gemm_ln_mha_supported(heads, Q, Q, dh))
+        if ride_bwd:
+            c0, gl0 = w.layers[0], w.glayers[0]
+            ops.layernorm_bwd_multi(
+                [dict(dy=w.d_h2, x=w.x1, mean=w.m2, rstd=w.r2, gamma=a.p(pre + "norm2.weight"), beta=a.p(pre + "norm2.bias"),
+                      dx=w.d_x1, dgamma=a.g(pre + "norm2.weight"), dbeta=a.g(pre + "norm2.bias"), partial=w.lnp["n2"],
+                      add1=w.d_x3)],
+                mha=dict(q=c0["sa_qkv"][:, :H], k=c0["sa_qkv"][:, H:2 * H], v=c0["sa_qkv"][:, 2 * H:], probs=c0["p_sa"],
+                         d_o=gl0["sao"], dq=gl0["saqkv"][:, :H], dk=gl0["saqkv"][:, H:2 * H], dv=gl0["saqkv"][:, 2 * H:], B=B,
+                         heads=heads, Lq=Q, Lk=Q, dh=dh, drop_mask=dmf("sa_p0"), drop_scale=dsc))
+            w.tables[("bwd_ride",)][1].launch()
+        else:
+            ln_bwd("n2", w.d_h2, w.x1, w.m2, w.r2, pre + "norm2.weight", pre + "norm2.bias", w.d_x1, add1=w.d_x3)
+        if ride_bwd:
+            pass
+        elif st.get("paired"):
             w.tables[("bwd_vh1",)].launch()
         else:
             ops.gemm(GEMM_NN, w.d_x1, a.p(pre + "attn.proj.weight"), w.d_v, c_row_xor=1, ws=ws)     # un-swap

@@ -334,9 +334,11 @@ def gemm_ln_fwd(jobs, mha=None):
     check(_lib.load().r3d_gemm_ln_fwd(arr, len(jobs), H, _stream()), "r3d_gemm_ln_fwd")
 
 
-def layernorm_bwd_multi(jobs):
+def layernorm_bwd_multi(jobs, mha=None):
     """jobs: up to 4 dicts with the arguments of layernorm_bwd (dy, x, mean, rstd, gamma, beta, dx, dgamma, dbeta,
-    partial required; pair_in, relu, dy2, add1, add2, dx2, drop_mask, drop_scale optional)."""
+    partial required; pair_in, relu, dy2, add1, add2, dx2, drop_mask, drop_scale optional).
+    mha: dict with the arguments of mha_core_bwd (q, k, v, probs, d_o, dq, dk, dv, B, heads, Lq, Lk, dh[, drop_mask,
+    drop_scale]) -- an independent small attention backward riding in the same launch (r3d_layernorm_bwd_multi_mha)."""
     from ._lib import LnBwdJob
     arr = (LnBwdJob * len(jobs))()
     for i, j in enumerate(jobs):
@@ -356,6 +358,20 @@ def layernorm_bwd_multi(jobs):
         a.dgamma, a.dbeta, a.ws = j["dgamma"].data_ptr(), j["dbeta"].data_ptr(), j["partial"].data_ptr()
         a.rows, a.H = rows, H
         assert j["partial"].numel() >= _lib.load().r3d_layernorm_bwd_ws_floats(rows, H)
+    if mha is not None:
+        from ._lib import MhaBwdJob
+        m, gg = MhaBwdJob(), mha.get
+        for n in ("q", "k", "v"):
+            setattr(m, n, mha[n].data_ptr())
+            setattr(m, "ld" + n, _ld(mha[n]))
+        m.probs, m.drop_mask, m.drop_scale = mha["probs"].data_ptr(), _pv(gg("drop_mask")), gg("drop_scale") or 1.0
+        m.d_o, m.lddo = mha["d_o"].data_ptr(), _ld(mha["d_o"])
+        for n in ("dq", "dk", "dv"):
+            setattr(m, n, mha[n].data_ptr())
+            setattr(m, "ld" + n, _ld(mha[n]))
+        m.B, m.heads, m.Lq, m.Lk, m.dh = mha["B"], mha["heads"], mha["Lq"], mha["Lk"], mha["dh"]
+        check(_lib.load().r3d_layernorm_bwd_multi_mha(arr, len(jobs), C.byref(m), _stream()), "r3d_layernorm_bwd_multi_mha")
+        return
     check(_lib.load().r3d_layernorm_bwd_multi(arr, len(jobs), _stream()), "r3d_layernorm_bwd_multi")
 
 
