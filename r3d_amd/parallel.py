@@ -425,6 +425,8 @@ class RcclStep:
         hook, eng.grad_hook = eng.grad_hook, None
         dp.comm_override = self.comm
         keep_defer, eng.defer_tail = eng.defer_tail, True     # forward -> losses -> backward back to back
+        # nobody reads the loss statistics before the step's AdamW launch: their reduction rides there (engine.adamw)
+        keep_red, eng.defer_loss_reduce = eng.defer_loss_reduce, after_losses is None
         wd, betas, eps = hyper if hyper is not None else (self.wd, (0.9, 0.999), 1e-8)
         lr = self.lr if lr is None else lr
         try:
@@ -462,4 +464,4 @@ class RcclStep:
         finally:
             eng.grad_hook = hook
             dp.comm_override = None
-            eng.defer_tail = keep_defer
+            eng.defer_tail, eng.defer_loss_reduce = keep_defer, keep_red
