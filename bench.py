@@ -268,6 +268,11 @@ def main():
                          "weight-gradient launch (A/B)")
     ap.add_argument("--no-ride-attention", action="store_true",
                     help="the query self-attention cores as launches of their own instead of riders (A/B)")
+    ap.add_argument("--ride-attention-bwd", action="store_true",
+                    help="also the backward query self-attention core as a rider (measured slower; off by default)")
+    ap.add_argument("--split-k4h", action="store_true",
+                    help="the K = 4H input-gradient products as two half-K problems summed by the LayerNorm backward "
+                         "(measured neutral; off by default)")
     ap.add_argument("--no-paired", action="store_true",
                     help="every GEMM of the fuser / query-branch chains through the planner on its own (no shared launches)")
     ap.add_argument("--no-defer-loss", action="store_true",
@@ -339,6 +344,8 @@ def main():
         eng.use_paired_launches = False
     eng.fold_rowsums = not a.no_fold_rowsums
     eng.ride_attention = not a.no_ride_attention
+    eng.ride_attention_bwd = a.ride_attention_bwd
+    eng.split_k4h = a.split_k4h
     eng.defer_tail = not a.separate_tail      # forward -> losses -> backward run back to back: one tail/loss launch
     # single-GPU flow: the loss / counter statistics (read by the host after the run) are reduced by one extra workgroup
     # of the AdamW launch instead of the loss kernel's last-arriving workgroup (the multi-GPU flows keep the latter)

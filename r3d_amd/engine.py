@@ -145,7 +145,7 @@ class _Shape:
             # stream can keep reading a tensor while the main stream moves on
             self.glayers = [dict(t3pre=f(BQ, H), ff2=f(BQ, H), ff1=f(BQ, 4 * H), t2=f(BQ, H), t2pre=f(BQ, H), cap=f(BQ, H),
                                  cao=f(BQ, H), caq=f(BQ, H), cakv=f(N, 2 * H), caqin=f(BQ, H), t1pre=f(BQ, H), sap=f(BQ, H),
-                                 sao=f(BQ, H), saqkv=f(BQ, 3 * H), sain=f(BQ, H)) for _ in range(L)]
+                                 sao=f(BQ, H), saqkv=f(BQ, 3 * H), sain=f(BQ, H), t2b=f(BQ, H)) for _ in range(L)]
             self.d_fused, self.d_fused2 = f(N, H), f(N, H)
             lnw = lambda rows: f(max(ops.layernorm_bwd_ws_floats(rows, H), 4))       # noqa: E731
             self.lnp = dict(final=lnw(BQ), nf=lnw(2 * N), n2=lnw(2 * N), n1=lnw(2 * N), dep=lnw(N))
@@ -156,6 +156,7 @@ class _Shape:
             self.d_x3, self.d_u, self.d_h1, self.d_h2, self.d_x1, self.d_v, self.d_x0 = (
                 f(2 * N, H), f(2 * N, 4 * H), f(2 * N, H), f(2 * N, H), f(2 * N, H), f(2 * N, H), f(2 * N, H))
             self.d_rgb_pre, self.d_dep, self.d_dep_pre = f(N, H), f(N, H), f(N, H)
+            self.d_h2b = f(2 * N, H)                     # second half-K partial of d_h2 (engine.split_k4h)
             if eng.bn:                                   # per-element terms of the BatchNorm / alpha parameter gradients
                 self.bn_terms = [f(N, H) for _ in range(5)]
             # dropout keep-masks (one Philox launch fills the whole pool)
@@ -220,6 +221,10 @@ class FusionEngine:
         # with the branch's input-projection gradient moved to the chain's last group: one launch fewer but measured SLOWER
         # (0.2382 -> 0.2410 ms/step: the K = 3H product lengthens the last group and the rider outlasts its host), so off
         self.ride_attention_bwd = False
+        # the two K = 4H input-gradient products of the backward whose consumer is a LayerNorm backward (it adds two upstream
+        # gradients anyway: dy + dy2) as TWO K = 2H problems of one grouped launch: measured neutral (0.2372 / 0.2391 against
+        # 0.2391 / 0.2380 ms/step), so off; kept under test
+        self.split_k4h = False
         # the two depth-projection GEMMs (83 % of the step's FLOPs) on the bf16 matrix cores through an exact three-way
         # operand split (csrc/gemm_bf3.hip; error per product <= 3 * 2^-24); 0 = the fp32 MFMA everywhere
         self.depth_prec = 1
@@ -956,10 +961,20 @@ class FusionEngine:
                        dy2=dy2, dx2=gl["ff2"], drop_mask=dm(f"d3_{l}", BQ, H), drop_scale=dsc)
             ops.gemm(GEMM_NN, gl["ff2"], p("linear2.weight"), gl["ff1"], drop_mask=dm(f"ff_{l}", BQ, 4 * H),
                      drop_scale=dsc, aux=c["ff1"], mul=1, ws=ws)
-            ops.gemm(GEMM_NN, gl["ff1"], p("linear1.weight"), gl["t2"], res1=gl["t3pre"], ws=ws)
+            split = self.split_k4h and H < 256 and H % 4 == 0
+            if split:                          # two half-K problems, one launch; norm2's backward adds them (dy + dy2)
+                key = ("l1_dgrad", l)
+                if key not in w.tables:
+                    w1 = p("linear1.weight")
+                    w.tables[key] = ops.GemmGroup(GEMM_NN, [
+                        dict(a=gl["ff1"][:, :2 * H], b=w1[:2 * H], c=gl["t2"], res1=gl["t3pre"]),
+                        dict(a=gl["ff1"][:, 2 * H:], b=w1[2 * H:], c=gl["t2b"])], tile=1)
+                w.tables[key].launch()
+            else:
+                ops.gemm(GEMM_NN, gl["ff1"], p("linear1.weight"), gl["t2"], res1=gl["t3pre"], ws=ws)
             # norm2 -> (t1 residual, cross attention)
             ln_bwd(f"d2_{l}", gl["t2"], c["t2_pre"], c["m2"], c["r2"], pl + "norm2.weight", pl + "norm2.bias", gl["t2pre"],
-                   dx2=gl["cap"], drop_mask=dm(f"d2_{l}", BQ, H), drop_scale=dsc)
+                   dy2=gl["t2b"] if split else None, dx2=gl["cap"], drop_mask=dm(f"d2_{l}", BQ, H), drop_scale=dsc)
             ops.gemm(GEMM_NN, gl["cap"], p("multihead_attn.out_proj.weight"), gl["cao"], ws=ws)
             ops.mha_core_bwd(c["caq"], c["cakv"][:, :H], c["cakv"][:, H:], c["p_ca"], gl["cao"], gl["caq"],
                              gl["cakv"][:, :H], gl["cakv"][:, H:], B, heads, Q, S, dh, drop_mask=dmf(f"ca_p{l}"),
@@ -994,7 +1009,8 @@ class FusionEngine:
             # the query-side branch (cross-attention query projection, norm1, self-attention: parameter gradients only
             # for a one-layer decoder) and the memory-side chain into the fuser are independent: their GEMMs share launches
             c, gl, pl = w.layers[0], w.glayers[0], "transformer.decoder.layers.0."
-            key = ("bwd_pairs", bool(tail))
+            split3 = bool(self.split_k4h and H < 256)
+            key = ("bwd_pairs", bool(tail), split3)
             if key not in w.tables:
                 wi0 = a.p(pl + "multihead_attn.in_proj_weight")
                 t = 1 if H < 256 else 2
@@ -1003,7 +1019,8 @@ class FusionEngine:
                     first.append(dict(a=w.d_seg, b=a.p("fc_seg.weight"), c=w.d_fused2))
                 # W_proj . W_v (parameters only): with it the two chained GEMMs at the end of the fuser's backward,
                 # d_v = swap(d_x1 . W_proj) and d_h1 = d_v . W_v = swap(d_x1 . (W_proj . W_v)), share one launch
-                w.wc = torch.empty(H, H, dtype=torch.float32, device=self.device)
+                if not hasattr(w, "wc"):        # (one buffer whatever variant of the groups is built later)
+                    w.wc = torch.empty(H, H, dtype=torch.float32, device=self.device)
                 first.append(dict(a=a.p(pre + "attn.proj.weight"), b=a.p(pre + "attn.qkv.weight")[2 * H:], c=w.wc))
                 w.tables[("bwd_vh1",)] = ops.GemmGroup(GEMM_NN, [
                     dict(a=w.d_x1, b=a.p(pre + "attn.proj.weight"), c=w.d_v, c_row_xor=1),
@@ -1020,8 +1037,11 @@ class FusionEngine:
                     ops.GemmGroup(GEMM_NN, first, tile=t),
                     ops.GemmGroup(GEMM_NN, [dict(a=gl["sap"], b=a.p(pl + "self_attn.out_proj.weight"), c=gl["sao"]),
                                             dict(a=w.d_x3, b=a.p(pre + "mlp.mlp.2.weight"), c=w.d_u, aux=w.u, mul=2)], tile=t),
-                    ops.GemmGroup(GEMM_NN, [dict(a=gl["saqkv"], b=a.p(pl + "self_attn.in_proj_weight"), c=gl["sain"]),
-                                            dict(a=w.d_u, b=a.p(pre + "mlp.mlp.0.weight"), c=w.d_h2)], tile=t))
+                    ops.GemmGroup(GEMM_NN, [dict(a=gl["saqkv"], b=a.p(pl + "self_attn.in_proj_weight"), c=gl["sain"])] + (
+                        [dict(a=w.d_u[:, :2 * H], b=a.p(pre + "mlp.mlp.0.weight")[:2 * H], c=w.d_h2),
+                         dict(a=w.d_u[:, 2 * H:], b=a.p(pre + "mlp.mlp.0.weight")[2 * H:], c=w.d_h2b)]
+                        if split3 else
+                        [dict(a=w.d_u, b=a.p(pre + "mlp.mlp.0.weight"), c=w.d_h2)]), tile=t))
             gb1, gb2, gb3 = w.tables[key]
             gb1.launch()
             if st.get("erank"):
@@ -1063,7 +1083,8 @@ class FusionEngine:
                          heads=heads, Lq=Q, Lk=Q, dh=dh, drop_mask=dmf("sa_p0"), drop_scale=dsc))
             w.tables[("bwd_ride",)][1].launch()
         else:
-            ln_bwd("n2", w.d_h2, w.x1, w.m2, w.r2, pre + "norm2.weight", pre + "norm2.bias", w.d_x1, add1=w.d_x3)
+            ln_bwd("n2", w.d_h2, w.x1, w.m2, w.r2, pre + "norm2.weight", pre + "norm2.bias", w.d_x1, add1=w.d_x3,
+                   dy2=w.d_h2b if (st.get("paired") and self.split_k4h and H < 256) else None)
         if ride_bwd:
             pass
         elif st.get("paired"):
