@@ -423,8 +423,14 @@ typedef struct r3d_loss_finalize_job {
     const float* part; int32_t B, S, Q, has_seg;
     const float* dur_den;            /* optional device scalar, as in r3d_losses_fwd_bwd */
     float* loss_out; int64_t* counts;
+    double* acc_loss; int64_t* acc_counts;   /* optional running sums [4] each: acc += this step's values (the epoch statistics
+                                                of train/train_proposed_depth.py:216-228, kept on the device) */
 } r3d_loss_finalize_job;
 int r3d_losses_finalize(const r3d_loss_finalize_job* job, void* stream);
+/* r3d_adamw_flat carrying the reduction as its workgroup 0 (fin != NULL), as r3d_adamw_flat_dropout_fin does. */
+int r3d_adamw_flat_fin(float* p, const float* g, float* m, float* v, int64_t n, const float* lr, const int64_t* step,
+                       float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                       const r3d_loss_finalize_job* fin, void* stream);
 int r3d_adamw_flat_dropout_fin(float* p, const float* g, float* m, float* v, int64_t n, const float* lr, const int64_t* step,
                                float beta1, float beta2, float eps, float weight_decay, float grad_scale, uint8_t* mask,
                                int64_t n_mask, float p_drop, uint64_t seed, const int64_t* offset,

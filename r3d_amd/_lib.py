@@ -106,7 +106,8 @@ class TailLossesArgs(C.Structure):
 class LossFinalizeJob(C.Structure):
     """struct r3d_loss_finalize_job"""
     _fields_ = [("part", C.c_void_p), ("B", C.c_int32), ("S", C.c_int32), ("Q", C.c_int32), ("has_seg", C.c_int32),
-                ("dur_den", C.c_void_p), ("loss_out", C.c_void_p), ("counts", C.c_void_p)]
+                ("dur_den", C.c_void_p), ("loss_out", C.c_void_p), ("counts", C.c_void_p), ("acc_loss", C.c_void_p),
+                ("acc_counts", C.c_void_p)]
 
 
 class LnFinalizeJob(C.Structure):
@@ -177,6 +178,7 @@ _SIGNATURES = {
     "r3d_adamw_flat": ([_P, _P, _P, _P, _L, _P, _P, _F, _F, _F, _F, _F, _P], C.c_int),
     "r3d_adamw_flat_dropout": ([_P, _P, _P, _P, _L, _P, _P, _F, _F, _F, _F, _F, _P, _L, _F, C.c_uint64, _P, _P], C.c_int),
     "r3d_losses_finalize": ([_P, _P], C.c_int),
+    "r3d_adamw_flat_fin": ([_P, _P, _P, _P, _L, _P, _P, _F, _F, _F, _F, _F, _P, _P], C.c_int),
     "r3d_adamw_flat_dropout_fin": ([_P, _P, _P, _P, _L, _P, _P, _F, _F, _F, _F, _F, _P, _L, _F, C.c_uint64, _P, _P, _P], C.c_int),
     "r3d_adamw_2d": ([_P, _P, _P, _P, _I, _I, _I, _P, _P, _F, _F, _F, _F, _F, _P], C.c_int),
     "r3d_dropout_mask": ([_P, _L, _F, C.c_uint64, _P, _P], C.c_int),

@@ -41,6 +41,10 @@ __device__ __forceinline__ void loss_finalize_block(const r3d_loss_finalize_job&
         j.loss_out[0] = ls; j.loss_out[1] = la; j.loss_out[2] = ld; j.loss_out[3] = ls + la + ld;
         j.counts[0] = (int64_t)(t[0][1] + 0.5); j.counts[1] = (int64_t)(t[0][2] + 0.5);
         j.counts[2] = (int64_t)(t[1][1] + 0.5); j.counts[3] = (int64_t)(t[1][2] + 0.5);
+        if (j.acc_loss)
+            for (int i = 0; i < 4; ++i) j.acc_loss[i] += (double)j.loss_out[i];
+        if (j.acc_counts)
+            for (int i = 0; i < 4; ++i) j.acc_counts[i] += j.counts[i];
     }
 }
 

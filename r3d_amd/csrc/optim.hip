@@ -166,6 +166,15 @@ __global__ __launch_bounds__(256) void adamw_dropout_fin_kernel(float4* __restri
     else dropout_body(mask, n_mask, thresh, seed, offset_ptr, bid - nb_adam, gridDim.x - 1 - nb_adam);
 }
 
+__global__ __launch_bounds__(256) void adamw_fin_kernel(float4* __restrict__ p, const float4* __restrict__ g,
+                                                        float4* __restrict__ m, float4* __restrict__ v, size_t n4,
+                                                        const float* lr_ptr, const int64_t* step_ptr, float b1, float b2,
+                                                        float eps, float wd, float gscale, const r3d_loss_finalize_job fin) {
+    __shared__ double red[4][3][3];
+    if (blockIdx.x == 0) { loss_finalize_block<4>(fin, red); return; }
+    adamw_body(p, g, m, v, n4, lr_ptr, step_ptr, b1, b2, eps, wd, gscale, blockIdx.x - 1, gridDim.x - 1);
+}
+
 }  // namespace r3d
 
 using namespace r3d;
@@ -189,6 +198,22 @@ R3D_EXPORT int r3d_adamw_flat(float* p, const float* g, float* m, float* v, int6
     const int blocks = adam_blocks(n4);
     hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float4*)p, (const float4*)g,
                        (float4*)m, (float4*)v, n4, lr, step, beta1, beta2, eps, weight_decay, grad_scale);
+    R3D_LAUNCH_CHECK();
+    return R3D_OK;
+}
+
+R3D_EXPORT int r3d_adamw_flat_fin(float* p, const float* g, float* m, float* v, int64_t n, const float* lr, const int64_t* step,
+                                  float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                                  const r3d_loss_finalize_job* fin, void* stream) {
+    if (!fin) return r3d_adamw_flat(p, g, m, v, n, lr, step, beta1, beta2, eps, weight_decay, grad_scale, stream);
+    R3D_REQUIRE(p && g && m && v && lr && step && n > 0);
+    R3D_REQUIRE((n % 4) == 0);
+    R3D_REQUIRE(fin->part && fin->loss_out && fin->counts && fin->B > 0 && fin->S > 0 && fin->Q > 0);
+    if (!(r3d_aligned16(p) && r3d_aligned16(g) && r3d_aligned16(m) && r3d_aligned16(v))) return R3D_EALIGN;
+    const size_t n4 = (size_t)n / 4;
+    const int blocks = adam_blocks(n4);
+    hipLaunchKernelGGL(adamw_fin_kernel, dim3(blocks + 1), dim3(256), 0, (hipStream_t)stream, (float4*)p, (const float4*)g,
+                       (float4*)m, (float4*)v, n4, lr, step, beta1, beta2, eps, weight_decay, grad_scale, *fin);
     R3D_LAUNCH_CHECK();
     return R3D_OK;
 }

@@ -211,6 +211,7 @@ class FusionEngine:
         # kernel then leaves the reduction of its per-unit partials (loss / counter statistics only the host reads) to
         # one extra workgroup of the AdamW launch -- w.loss / w.counts are valid after adamw(), not after losses()
         self.defer_loss_reduce = False
+        self.loss_acc = None                    # (float64[4], int64[4]) running sums the deferred reduction also feeds
         # the bias / broadcast-parameter / LayerNorm-parameter sums at the end of the backward as problems of the grouped
         # weight-gradient launch (a column sum over the rows of a residue class is a TN product with a constant 0/1
         # selection matrix) instead of a launch of their own
@@ -727,8 +728,9 @@ class FusionEngine:
                                         dx=w.glayers[Lm]["t3pre"], dx2=w.glayers[Lm]["ff2"], wsF=w.lnp["final"],
                                         ws3=w.lnp[f"d3_{Lm}"], ws=w.loss_ws, defer_finalize=defer)
                 w._tail_done = True
-                self._loss_pending = ops.loss_finalize_job(w.loss_ws, w.B, w.S, self.Q, True, self.dur_den, w.loss,
-                                                           w.counts) if defer else None
+                acc = self.loss_acc if self.loss_acc is not None else (None, None)
+                self._loss_pending = ops.loss_finalize_job(w.loss_ws, w.B, w.S, self.Q, True, self.dur_den, w.loss, w.counts,
+                                                           acc_loss=acc[0], acc_counts=acc[1]) if defer else None
                 return w.loss, w.counts
             ops.decoder_tail_fwd(tail["x"], tail["g3"], tail["b3"], tail["gF"], tail["bF"], tail["w_head"], tail["b_head"],
                                  tail["t3"], tail["m3"], tail["r3"], tail["tgtF"], tail["mF"], tail["rF"], tail["out"])
@@ -1182,9 +1184,8 @@ class FusionEngine:
             pending = None
         else:
             ops.adamw_flat(a.params[:n], a.grads[:n], a.exp_avg[:n], a.exp_avg_sq[:n], self.lr_t, self.step_t,
-                           beta1=betas[0], beta2=betas[1], eps=eps, weight_decay=weight_decay, grad_scale=grad_scale)
-        if pending is not None:                     # (no carrier launch on this path: the reduction goes alone)
-            ops.losses_finalize(pending)
+                           beta1=betas[0], beta2=betas[1], eps=eps, weight_decay=weight_decay, grad_scale=grad_scale,
+                           loss_fin=pending)
         if self.tp is not None and not skip_depth and not depth_cols_first:
             t = self.tp                             # depth_projection.weight: only this rank's pixel columns are live
             ops.adamw_2d(t.w, t.g, t.m, t.v, self.lr_t, self.step_t, beta1=betas[0], beta2=betas[1], eps=eps,

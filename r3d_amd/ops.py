@@ -619,21 +619,29 @@ def losses_ws_floats(B, S, Q):
     return int(_lib.load().r3d_losses_ws_floats(B, S, Q))
 
 
-def adamw_flat(p, g, m, v, lr_t, step_t, *, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, grad_scale=1.0):
+def adamw_flat(p, g, m, v, lr_t, step_t, *, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, grad_scale=1.0, loss_fin=None):
     lib = _lib.load()
     n = p.numel()
     assert g.numel() == n and m.numel() == n and v.numel() == n
     assert lr_t.dtype == torch.float32 and step_t.dtype == torch.int64
+    if loss_fin is not None:               # the deferred loss reduction rides as workgroup 0 (r3d_adamw_flat_fin)
+        check(lib.r3d_adamw_flat_fin(_p(p), _p(g), _p(m), _p(v), n, _p(lr_t), _p(step_t), beta1, beta2, eps, weight_decay,
+                                     grad_scale, C.byref(loss_fin), _stream()), "r3d_adamw_flat_fin")
+        return
     check(lib.r3d_adamw_flat(_p(p), _p(g), _p(m), _p(v), n, _p(lr_t), _p(step_t), beta1, beta2, eps, weight_decay, grad_scale,
                              _stream()), "r3d_adamw_flat")
 
 
-def loss_finalize_job(part, B, S, Q, has_seg, dur_den, loss_out, counts):
-    """r3d_loss_finalize_job for the partials a decoder_tail_losses(defer_finalize=True) launch left in `part`."""
+def loss_finalize_job(part, B, S, Q, has_seg, dur_den, loss_out, counts, acc_loss=None, acc_counts=None):
+    """r3d_loss_finalize_job for the partials a decoder_tail_losses(defer_finalize=True) launch left in `part`.
+    acc_loss (float64[4]) / acc_counts (int64[4]): running sums the reduction also adds this step's values to."""
     from ._lib import LossFinalizeJob
     j = LossFinalizeJob()
     j.part, j.B, j.S, j.Q, j.has_seg = part.data_ptr(), B, S, Q, 1 if has_seg else 0
     j.dur_den, j.loss_out, j.counts = _pv(dur_den), loss_out.data_ptr(), counts.data_ptr()
+    if acc_loss is not None:
+        assert acc_loss.dtype == torch.float64 and acc_counts.dtype == torch.int64 and acc_loss.numel() == 4
+        j.acc_loss, j.acc_counts = acc_loss.data_ptr(), acc_counts.data_ptr()
     return j
 
 

@@ -503,3 +503,12 @@ def test_deferred_loss_reduction_in_the_adamw_launch():
         assert torch.equal(a["counts"], b["counts"]) and a["step"] == b["step"] == 2 and a["off"] == b["off"]
         assert torch.equal(a["grads"], b["grads"]) and torch.equal(a["params"], b["params"])
         assert float(a["loss"][3]) > 0 and int(a["counts"][1]) > 0
+    # the stand-alone entry point on the partials the last (deferred) step left, with the running sums it can feed
+    from r3d_amd import ops
+    w = eng.last["w"]
+    loss2, cnt2 = torch.zeros(4, device="cuda"), torch.zeros(4, dtype=torch.int64, device="cuda")
+    accl, accc = torch.ones(4, dtype=torch.float64, device="cuda"), torch.full((4,), 5, dtype=torch.int64, device="cuda")
+    ops.losses_finalize(ops.loss_finalize_job(w.loss_ws, w.B, w.S, eng.Q, True, eng.dur_den, loss2, cnt2, accl, accc))
+    torch.cuda.synchronize()
+    assert torch.equal(loss2, b["loss"]) and torch.equal(cnt2, b["counts"])
+    assert torch.equal(accl, 1.0 + loss2.double()) and torch.equal(accc, 5 + cnt2)
