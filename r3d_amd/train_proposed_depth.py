@@ -157,14 +157,17 @@ class _GraphedSteps:
         wd, betas, eps = hyper
         # forward -> losses -> backward back to back: the decoder tail, the losses and the tail's backward are one launch
         # (defer_tail), and the loss statistics -- with their epoch sums -- are reduced by one workgroup of the AdamW launch
-        keep = (eng.defer_tail, eng.defer_loss_reduce, eng.loss_acc)
-        eng.defer_tail, eng.defer_loss_reduce, eng.loss_acc = True, True, (self.acc_loss, self.acc_cnt)
+        fused = hasattr(eng, "defer_loss_reduce")            # (the depth-as-query engine keeps its separate launches)
+        if fused:
+            keep = (eng.defer_tail, eng.defer_loss_reduce, eng.loss_acc)
+            eng.defer_tail, eng.defer_loss_reduce, eng.loss_acc = True, True, (self.acc_loss, self.acc_cnt)
         try:
             eng.forward(feats, depth, lab, "train", training=training)
             loss, counts = eng.losses(lab, tgt, dur, tick=True)
             folded = getattr(eng, "_loss_pending", None) is not None
         finally:
-            eng.defer_tail, eng.defer_loss_reduce, eng.loss_acc = keep
+            if fused:
+                eng.defer_tail, eng.defer_loss_reduce, eng.loss_acc = keep
         eng.backward()
         eng.adamw(lr, wd, betas=betas, eps=eps, ticked=True)     # (no dropout prefill: every captured step generates its
         if not folded:                                            #  own masks, so graphs of different shapes can interleave)
