@@ -734,3 +734,55 @@ def test_erank_blocked_vs_svdvals(ops, R, Cc):
     assert abs(float(er.detach()) - O.effective_rank(x)) < 0.5
     sc = float(xr.grad.abs().max())
     assert float((xg.grad.cpu().double() - xr.grad).abs().max()) < 2e-3 * sc
+
+
+def test_attention_cores_as_riders_equal_their_own_launches(ops):
+    """The small attention core carried as extra workgroups of r3d_gemm_ln_mha_fwd / r3d_layernorm_bwd_multi_mha
+    (mha_small.h: one (clip, head) unit per wave) writes bit for bit what r3d_mha_core_fwd / _bwd write on their own, and
+    leaves the host launch's results untouched."""
+    B, heads, Q, dh, H = 8, 8, 8, 16, 128
+    BQ = B * Q
+    qkv = dev(rnd(BQ, 3 * H, seed=1))
+    mask = dev((torch.rand(B * heads * Q * Q, generator=torch.Generator().manual_seed(2)) > 0.1).to(torch.uint8))
+    f = lambda *sh: torch.full(sh, float("nan"), device="cuda")      # noqa: E731
+    # ---- forward: alone ...
+    p0, o0 = f(B * heads * Q * Q), f(BQ, H)
+    ops.mha_core_fwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], p0, o0, B, heads, Q, Q, dh, drop_mask=mask, drop_scale=1 / 0.9)
+    # ... and riding beside a linear + LayerNorm job
+    M, K = 64, 128
+    a, wgt, g, b = dev(rnd(M, K, seed=3)), dev(rnd(H, K, seed=4, scale=K ** -0.5)), dev(1 + 0.2 * rnd(H, seed=5)), dev(0.1 * rnd(H, seed=6))
+    outs = []
+    for ride in (False, True):
+        pre, y, mean, rstd = f(M, H), f(M, H), f(M), f(M)
+        p1, o1 = f(B * heads * Q * Q), f(BQ, H)
+        job = dict(a=a, w=wgt, pre=pre, gamma=g, beta=b, y=y, mean=mean, rstd=rstd)
+        assert ops.gemm_ln_mha_supported(heads, Q, Q, dh) and not ops.gemm_ln_mha_supported(heads, Q, Q, 32)
+        ops.gemm_ln_fwd([job], mha=dict(q=qkv[:, :H], k=qkv[:, H:2 * H], v=qkv[:, 2 * H:], probs=p1, o=o1, B=B, heads=heads,
+                                        Lq=Q, Lk=Q, dh=dh, drop_mask=mask, drop_scale=1 / 0.9) if ride else None)
+        outs.append((pre, y, mean, rstd, p1, o1))
+    torch.cuda.synchronize()
+    for t0, t1 in zip(outs[0][:4], outs[1][:4]):
+        assert torch.equal(t0, t1)
+    assert torch.equal(outs[1][4], p0) and torch.equal(outs[1][5], o0)
+    # ---- backward
+    d_o = dev(rnd(BQ, H, seed=7))
+    dq0 = f(BQ, 3 * H)
+    ops.mha_core_bwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], p0, d_o, dq0[:, :H], dq0[:, H:2 * H], dq0[:, 2 * H:], B, heads,
+                     Q, Q, dh, drop_mask=mask, drop_scale=1 / 0.9)
+    rows = 256
+    x, dy = dev(rnd(rows, H, seed=8)), dev(rnd(rows, H, seed=9))
+    yl, ml, rl = f(rows, H), f(rows), f(rows)
+    ops.layernorm_fwd(x, g, b, yl, ml, rl)
+    res = []
+    for ride in (False, True):
+        dx, dg, db = f(rows, H), f(H), f(H)
+        part = torch.zeros(max(ops.layernorm_bwd_ws_floats(rows, H), 4), device="cuda")
+        dq1 = f(BQ, 3 * H)
+        ops.layernorm_bwd_multi([dict(dy=dy, x=x, mean=ml, rstd=rl, gamma=g, beta=b, dx=dx, dgamma=dg, dbeta=db, partial=part)],
+                                mha=dict(q=qkv[:, :H], k=qkv[:, H:2 * H], v=qkv[:, 2 * H:], probs=p0, d_o=d_o, dq=dq1[:, :H],
+                                         dk=dq1[:, H:2 * H], dv=dq1[:, 2 * H:], B=B, heads=heads, Lq=Q, Lk=Q, dh=dh,
+                                         drop_mask=mask, drop_scale=1 / 0.9) if ride else None)
+        res.append((dx, part, dq1))
+    torch.cuda.synchronize()
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert torch.equal(res[1][2], dq0)
