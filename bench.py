@@ -273,6 +273,11 @@ def main():
     ap.add_argument("--split-k4h", action="store_true",
                     help="the K = 4H input-gradient products as two half-K problems summed by the LayerNorm backward "
                          "(measured neutral; off by default)")
+    ap.add_argument("--no-fuser-chain", action="store_true",
+                    help="the fuser block's row-local chain as grouped GEMM / gemm_ln launches instead of the one-launch "
+                         "chain kernels (A/B)")
+    ap.add_argument("--erank-main-stream", action="store_true",
+                    help="with --erank-weight: the Jacobi forward in stream order instead of on the side stream (A/B)")
     ap.add_argument("--no-paired", action="store_true",
                     help="every GEMM of the fuser / query-branch chains through the planner on its own (no shared launches)")
     ap.add_argument("--no-defer-loss", action="store_true",
@@ -340,6 +345,8 @@ def main():
     eng.use_side_stream = a.side_stream
     eng.use_fused_decoder = a.fused_decoder
     eng.use_gemm_ln = not a.no_gemm_ln
+    eng.use_fuser_chain = not a.no_fuser_chain
+    eng.erank_side_stream = not a.erank_main_stream
     if a.no_paired:
         eng.use_paired_launches = False
     eng.fold_rowsums = not a.no_fold_rowsums

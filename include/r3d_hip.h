@@ -254,6 +254,61 @@ typedef struct r3d_mha_job {
 int r3d_gemm_ln_mha_supported(int heads, int Lq, int Lk, int dh);
 int r3d_gemm_ln_mha_fwd(const r3d_gemm_ln_job* jobs, int njobs, int H, const r3d_mha_job* mha, void* stream);
 
+/* ---- the SA-Fuser block and its row-local neighbourhood as ONE launch (csrc/fuser_chain.hip; hidden = 128) -------------
+ * Fuser role, 16 token rows (8 frames) per workgroup:  V = h1 Wv^T stored pair-swapped (the closed form of the masked
+ * 2-token attention, model/futr_safuser_tokenfusion.py:68-72,77) -> x1 = x0 + vsw Wproj^T + b -> h2 = norm2(x1) ->
+ * u = h2 W1^T + b1, f1 = GELU(u) -> x3 = x1 (+ x0 when add_xres) + f1 W2^T + b2 -> y = fuser.norm(x3) ->
+ * fused = mean of the token pair (model/extras/transformerblock.py:118-135, model/futr_safuser_tokenfusion.py:83-94) ->
+ * seg = fused Wseg^T + b (:228-232), cakv = (fused + pos[frame %% S]) Wkv^T + b (model/extras/transformer.py:300-302).
+ * Query role, 2 clips per workgroup (decoder layer 0 with tgt = 0, transformer.py:289-293,300):
+ * sa_qkv = qpos Win^T + b -> attention core (probabilities p_sa, dropout drop_sa) -> t1_pre = dropout(sa_o Wout^T + b) ->
+ * t1 = norm1(t1_pre) -> caq = (t1 + qpos) Wq^T + b.
+ * All matrices row-major and dense: activations [2N, 128] (u, f1: [2N, 512]; fused [N, 128]; seg [N, K]; cakv [N, 256];
+ * sa_qkv [B*Q, 384]), weights as nn.Linear stores them ([out, in]).  y may be NULL.  Requirements:
+ * r3d_fuser_chain_supported. */
+typedef struct r3d_fuser_chain_fwd_args {
+    const float* x0; const float* h1;
+    const float* wv; const float* wproj; const float* bproj; const float* g2; const float* be2;
+    const float* w1; const float* b1; const float* w2; const float* b2; const float* gf; const float* bef;
+    const float* pos; const float* wkv; const float* bkv; const float* wseg; const float* bseg;
+    float* vsw; float* x1; float* h2; float* m2; float* r2; float* u; float* f1; float* x3; float* y; float* mf; float* rf;
+    float* fused; float* seg; float* cakv;
+    const float* qpos; const float* w_in; const float* b_in; const float* w_out; const float* b_out; const float* g1;
+    const float* be1; const float* wq; const float* bq;
+    const uint8_t* drop_sa; const uint8_t* drop_d1; float drop_scale;
+    float* sa_qkv; float* p_sa; float* sa_o; float* t1_pre; float* t1; float* m1; float* r1; float* caq;
+    int32_t N, S, K, H, add_xres, B, Q, heads;
+} r3d_fuser_chain_fwd_args;
+int r3d_fuser_chain_supported(int N, int H, int K, int B, int Q, int heads);
+int r3d_fuser_chain_fwd(const r3d_fuser_chain_fwd_args* a, void* stream);
+/* The adjoint of r3d_fuser_chain_fwd, one launch.  Fuser role: d(memory + pos) = d_cakv Wkv (stored in d_fused: the
+ * positional embedding's gradient) + d_seg Wseg (+ d_extra [N,128], optional: the effective-rank penalty's gradient) ->
+ * fuser.norm backward (half of a frame's gradient to each token row) -> d_u = (d_x3 W2) GELU'(u) -> d_h2 = d_u W1 ->
+ * norm2 backward + d_x3 -> d_v = unswap(d_x1 Wproj) -> d_h1 = d_v Wv -> norm1 backward + d_x1 (+ d_x3 when add_xres) ->
+ * embd_drop -> token-exchange backward (masks m_rgb / m_dep [128], ReLU gate of the RGB embedding) -> depth LayerNorm +
+ * ReLU backward (autograd of model/futr_safuser_tokenfusion.py:83-94,56-62,183,195-197).  Stored for the weight-gradient
+ * launch: d_x3, d_u, d_x1, d_v (d_h2, d_h1 optional).  LayerNorm parameter-gradient partials: part_nf / part_n2
+ * [2N/4][2][128] (one (dgamma, dbeta) pair per 4 rows), part_n1 / part_dep [N][2][128] (one per frame).
+ * Query role: caqin = d_caq Wq -> decoder norm1 backward (dy = caqin + d_t1_res; partials part_d1 [B*Q/4][2][128]) ->
+ * sap = dropout' -> sao = sap Wout -> attention core backward (saqkv) -> sain = saqkv Win (transformer.py:289-293,300). */
+typedef struct r3d_fuser_chain_bwd_args {
+    const float* d_cakv; const float* d_seg; const float* d_extra; const float* wkv; const float* wseg;
+    const float* x3; const float* mf; const float* rf; const float* gf;
+    const float* w2; const float* u; const float* w1; const float* x1; const float* m2; const float* r2; const float* g2;
+    const float* wproj; const float* wv; const float* x0; const float* m1; const float* r1; const float* g1n;
+    const uint8_t* drop_x0; const float* m_rgb; const float* m_dep; const float* rgb; const float* dep_pre;
+    const float* mean_d; const float* rstd_d; const float* lnd_g; const float* lnd_b;
+    float* d_fused; float* d_x3; float* d_u; float* d_h2; float* d_x1; float* d_v; float* d_h1; float* d_rgb_pre;
+    float* d_dep_pre; float* part_nf; float* part_n2; float* part_n1; float* part_dep;
+    const float* d_caq; const float* d_t1_res; const float* wq; const float* t1_pre; const float* m1d; const float* r1d;
+    const float* g1d; const uint8_t* drop_d1; const float* w_out; const float* sa_qkv; const float* p_sa;
+    const uint8_t* drop_sa; const float* w_in;
+    float* caqin; float* t1pre_out; float* sap; float* sao; float* saqkv; float* sain; float* part_d1;
+    float drop_scale;
+    int32_t N, S, K, H, add_xres, B, Q, heads;
+} r3d_fuser_chain_bwd_args;
+int r3d_fuser_chain_bwd(const r3d_fuser_chain_bwd_args* a, void* stream);
+
 /* ---- token selection / exchange: CMFuser.token_fusion (model/futr_safuser_tokenfusion.py:33-66) ------------- */
 /* out[c] = sum_r |x[r,c]| in fp64 (the eval-mode score before the division by B*T, :49-50). */
 int r3d_colabssum(const float* x, int ld, int rows, int cols, double* out, void* stream);
@@ -453,11 +508,24 @@ int r3d_erank_jacobi(const float* x, int ld, int64_t batch_stride, int batch, in
 int r3d_erank_blocked_sizes(int R, int C, int max_sweeps, int64_t* out);
 int r3d_erank_blocked(const float* x, int ld, int R, int C, float* sigma, float* af_t, int* ctrl, float* stats,
                       int max_sweeps, void* stream);
+/* The same with the input optionally given transposed (x_transposed != 0: x is [C][ld] = X^T of the [R, C] matrix that
+ * is decomposed): the rank-regularised training step decomposes fused^T without a transposition pass when the token
+ * matrix has fewer rows than columns. */
+int r3d_erank_blocked_t(const float* x, int ld, int x_transposed, int R, int C, float* sigma, float* af_t, int* ctrl,
+                        float* stats, int max_sweeps, void* stream);
 /* coef[k] = gout * d erank / d sigma_k / sigma_k^3; zero for negligible sigma and, with max_rank = min(R, C) > 0, for
  * everything but the max_rank largest (a rank-deficient X has no defined singular vectors beyond its rank). */
 int r3d_erank_bwd_coef(const float* sigma, const float* stats, const float* gout, float* coef, int C, int max_rank,
                        void* stream);
 int r3d_scale_rows(float* x, int ld, int rows, int cols, const float* coef, void* stream);
+/* The backward in its well-conditioned form: U = (X V) Sigma^-1, V^T = Sigma^-1 (2 I - U^T U) U^T X (one Neumann term of
+ * (U^T U)^-1: the plain V^T = Sigma^-1 U^T X amplifies the residual coupling of a small column with a large one by
+ * sigma_j / sigma_i), dX = U diag(g) V^T.  r3d_erank_bwd_coef2: cg[k] = gout * (d erank / d sigma_k) / sigma_k,
+ * inv[k] = 1 / sigma_k (zero where r3d_erank_bwd_coef's coefficient is).  r3d_erank_bwd_fix: w[r,:] = cg[r] (2 w[r,:] - p[r,:])
+ * on dense [rows, cols] matrices.  The host composes the four GEMMs (r3d_amd/erank.py: erank_backward). */
+int r3d_erank_bwd_coef2(const float* sigma, const float* stats, const float* gout, float* cg, float* inv, int C, int max_rank,
+                        void* stream);
+int r3d_erank_bwd_fix(float* w, const float* p, const float* cg, int rows, int cols, void* stream);
 /* r3d_erank_jacobi that also carries the right singular basis (batch == 1): every rotation is applied to the rows of
  * V^T as well, vt_out [C][C] = (V0 V')^T.  vt_in = V0^T from an earlier decomposition of a nearby matrix and x = X V0
  * (NULL: identity): a warm start, 3-5 sweeps instead of 10-11.  Matrix and basis must fit the LDS together

@@ -129,3 +129,36 @@ def make_batch(B, S, n_class, pad_idx, seed, n_query=8, input_dim=2048, depth_hw
             dur[b, k:] = np.float32(pad_idx)
     return [feats.astype(np.float32), depth.astype(np.float32), lab.astype(np.int64),
             dur.astype(np.float32), tgt.astype(np.int64)]
+
+
+# ----------------------------------------------------------------------------------------
+# per-video files for the inference loop
+# ----------------------------------------------------------------------------------------
+def make_video(T, n_actions, seed, input_dim=2048, depth_hw=(24, 32)):
+    """One synthetic video in the form the reference's predict() reads (evaluation/predict_utkinects.py:262-272):
+    features [T, input_dim] f32, depth [T, 1, H, W] f32 in [0,1), and T ground-truth lines '<image>,<label>,<tag>' whose
+    labels are piecewise constant (segments of 3..10 frames) over the names act00 .. act<n_actions-1>."""
+    base = (seed & 0xFFFFFF) << 8
+    Hh, Ww = depth_hw
+    feats = (np.float32(np.sqrt(3.0)) * symmetric(T * input_dim, base + 11)).reshape(T, input_dim)
+    depth = uniform01(T * Hh * Ww, base + 12).reshape(T, 1, Hh, Ww)
+    seg_len = 3 + randint(T, 8, base + 13)
+    seg_lab = randint(T, n_actions, base + 14)
+    labels, k = [], 0
+    while len(labels) < T:
+        labels += [int(seg_lab[k])] * int(seg_len[k])
+        k += 1
+    labels = labels[:T]
+    lines = [f"img_{t:05d}.png,act{labels[t]:02d},x" for t in range(T)]
+    return feats.astype(np.float32), depth.astype(np.float32), lines
+
+
+def write_video_files(root, name, feats, depth, lines):
+    """Lays one video out as the reference's dataset directories (predict_utkinects.py:231-233)."""
+    import os
+    for d in ("groundTruth", "features_img", "features_depth"):
+        os.makedirs(os.path.join(root, d), exist_ok=True)
+    with open(os.path.join(root, "groundTruth", f"{name}.txt"), "w") as fh:
+        fh.write("\n".join(lines) + "\n")
+    np.save(os.path.join(root, "features_img", f"{name}.npy"), feats)
+    np.save(os.path.join(root, "features_depth", f"{name}.npy"), depth)

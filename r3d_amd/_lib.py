@@ -66,6 +66,25 @@ class GemmLnJob(C.Structure):
                 ("pair_out", C.c_void_p), ("M", C.c_int32), ("K", C.c_int32)]
 
 
+class FuserChainFwdArgs(C.Structure):
+    """struct r3d_fuser_chain_fwd_args"""
+    _PTRS = ("x0 h1 wv wproj bproj g2 be2 w1 b1 w2 b2 gf bef pos wkv bkv wseg bseg vsw x1 h2 m2 r2 u f1 x3 y mf rf fused seg "
+             "cakv qpos w_in b_in w_out b_out g1 be1 wq bq drop_sa drop_d1").split()
+    _PTRS2 = "sa_qkv p_sa sa_o t1_pre t1 m1 r1 caq".split()
+    _fields_ = ([(n, C.c_void_p) for n in _PTRS] + [("drop_scale", C.c_float)] + [(n, C.c_void_p) for n in _PTRS2] +
+                [(n, C.c_int32) for n in "N S K H add_xres B Q heads".split()])
+
+
+class FuserChainBwdArgs(C.Structure):
+    """struct r3d_fuser_chain_bwd_args"""
+    _PTRS = ("d_cakv d_seg d_extra wkv wseg x3 mf rf gf w2 u w1 x1 m2 r2 g2 wproj wv x0 m1 r1 g1n drop_x0 m_rgb m_dep rgb "
+             "dep_pre mean_d rstd_d lnd_g lnd_b d_fused d_x3 d_u d_h2 d_x1 d_v d_h1 d_rgb_pre d_dep_pre part_nf part_n2 "
+             "part_n1 part_dep d_caq d_t1_res wq t1_pre m1d r1d g1d drop_d1 w_out sa_qkv p_sa drop_sa w_in caqin t1pre_out "
+             "sap sao saqkv sain part_d1").split()
+    _fields_ = ([(n, C.c_void_p) for n in _PTRS] + [("drop_scale", C.c_float)] +
+                [(n, C.c_int32) for n in "N S K H add_xres B Q heads".split()])
+
+
 class MhaJob(C.Structure):
     """struct r3d_mha_job"""
     _fields_ = [("q", C.c_void_p), ("ldq", C.c_int32), ("k", C.c_void_p), ("ldk", C.c_int32), ("v", C.c_void_p),
@@ -131,6 +150,9 @@ _SIGNATURES = {
     "r3d_gemm_grouped_launch": ([_P, _P, C.POINTER(C.c_int32), _I, _I, _I, _I, _P], C.c_int),
     "r3d_gemm_ln_supported": ([_I, _I, _I], C.c_int),
     "r3d_gemm_ln_fwd": ([_P, _I, _I, _P], C.c_int),
+    "r3d_fuser_chain_supported": ([_I, _I, _I, _I, _I, _I], C.c_int),
+    "r3d_fuser_chain_fwd": ([_P, _P], C.c_int),
+    "r3d_fuser_chain_bwd": ([_P, _P], C.c_int),
     "r3d_gemm_ln_mha_supported": ([_I, _I, _I, _I], C.c_int),
     "r3d_gemm_ln_mha_fwd": ([_P, _I, _I, _P, _P], C.c_int),
     "r3d_layernorm_fwd_multi": ([_P, _I, _P], C.c_int),
@@ -186,7 +208,10 @@ _SIGNATURES = {
     "r3d_erank_jacobi": ([_P, _I, _L, _I, _I, _I, _I, _P, _P, _P, _I, _P], C.c_int),
     "r3d_erank_blocked_sizes": ([_I, _I, _I, _P], C.c_int),
     "r3d_erank_blocked": ([_P, _I, _I, _I, _P, _P, _P, _P, _I, _P], C.c_int),
+    "r3d_erank_blocked_t": ([_P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P], C.c_int),
     "r3d_erank_bwd_coef": ([_P, _P, _P, _P, _I, _I, _P], C.c_int),
+    "r3d_erank_bwd_coef2": ([_P, _P, _P, _P, _P, _I, _I, _P], C.c_int),
+    "r3d_erank_bwd_fix": ([_P, _P, _P, _I, _I, _P], C.c_int),
     "r3d_scale_rows": ([_P, _I, _I, _I, _P, _P], C.c_int),
     "r3d_posenc_fwd": ([_P, _I, _P, _I, _I, _P, _F, _P, _I, _I, _I, _P], C.c_int),
     "r3d_posenc_bwd": ([_P, _I, _P, _F, _P, _I, _P, _I, _I, _I, _P], C.c_int),

@@ -371,12 +371,22 @@ struct ErankBlk {
     int* ctrl;
 };
 
-__global__ __launch_bounds__(256) void erank_blk_init_kernel(const float* __restrict__ x, int ld, ErankBlk g) {
+// xt != 0: x holds the TRANSPOSE of the matrix to decompose ([C][ld], row c = column c of the matrix) -- the layout
+// `at` wants, so the copy needs no transposition (the engine decomposes fused^T when the token matrix is wide).
+__global__ __launch_bounds__(256) void erank_blk_init_kernel(const float* __restrict__ x, int ld, ErankBlk g, int xt) {
     __shared__ float tile[32][33];
     __shared__ float red[4];
     const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
     float part = 0.f;
+    if (xt) {
+        for (int k = ty; k < 32; k += 8) {
+            const int c = c0 + k, r = r0 + tx;
+            const float v = (r < g.R && c < g.C) ? x[(size_t)c * ld + r] : 0.f;
+            if (c < g.nreal * g.b && r < g.Rp) g.at[(size_t)c * g.Rp + r] = v;
+            part += v * v;
+        }
+    } else {
     for (int k = ty; k < 32; k += 8) {
         const int r = r0 + k, c = c0 + tx;
         const float v = (r < g.R && c < g.C) ? x[(size_t)r * ld + c] : 0.f;
@@ -387,6 +397,7 @@ __global__ __launch_bounds__(256) void erank_blk_init_kernel(const float* __rest
     for (int k = ty; k < 32; k += 8) {
         const int c = c0 + k, r = r0 + tx;
         if (c < g.nreal * g.b && r < g.Rp) g.at[(size_t)c * g.Rp + r] = tile[tx][k];      // rows R..Rp-1: zeros
+    }
     }
     part = wave_sum(part);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
@@ -508,6 +519,38 @@ __global__ __launch_bounds__(256) void erank_coef_kernel(const float* sigma, con
         c = (gout ? *gout : 1.f) * g / (s * s * s);
     }
     coef[k] = c;
+}
+
+// The well-conditioned form of the backward (see r3d_erank_bwd_coef2): cg[k] = gout * (d erank / d sigma_k) / sigma_k and
+// inv[k] = 1 / sigma_k, both zero where erank_coef_kernel's coefficient is zero.
+__global__ __launch_bounds__(256) void erank_coef2_kernel(const float* sigma, const float* stats, const float* gout,
+                                                          float* cg, float* inv, int C, int max_rank) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= C) return;
+    const float er = stats[0], H = stats[1], total = stats[2];
+    const float s = sigma[k];
+    float smax = 0.f;
+    int larger = 0;
+    for (int j = 0; j < C; ++j) {
+        smax = fmaxf(smax, sigma[j]);
+        larger += (sigma[j] > s || (sigma[j] == s && j < k)) ? 1 : 0;
+    }
+    float c = 0.f, iv = 0.f;
+    if (s > 1e-6f * smax && s > 0.f && (max_rank <= 0 || larger < max_rank)) {
+        const float p = s / total;
+        const float g = -er * (logf(p) + H) / total;
+        c = (gout ? *gout : 1.f) * g / s;
+        iv = 1.f / s;
+    }
+    cg[k] = c;
+    inv[k] = iv;
+}
+
+// w[r, :] = cg[r] * (2 w[r, :] - p[r, :])
+__global__ __launch_bounds__(256) void erank_bwd_fix_kernel(float* w, const float* p, const float* cg, int rows, int cols) {
+    const size_t total = (size_t)rows * cols;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256)
+        w[e] = cg[e / cols] * (2.f * w[e] - p[e]);
 }
 
 __global__ __launch_bounds__(256) void scale_rows_kernel(float* x, int ld, int rows, int cols, const float* coef) {
@@ -686,9 +729,19 @@ static int erank_blk_sweeps(const ErankBlk& g, int ms, int64_t lds, hipStream_t 
  * columns R..Rp-1 of every row are zero padding); ctrl is integer scratch; sizes from r3d_erank_blocked_sizes.
  * sigma [C], stats [4] as r3d_erank_jacobi.  Enqueues 3 + max_sweeps * (nblk + 1) launches on the stream (default
  * max_sweeps 16 -- 8 to 10 are used at the BASELINE shapes; launches after convergence return at once but still cost ~3 us each), never synchronises. */
+R3D_EXPORT int r3d_erank_blocked_t(const float* x, int ld, int x_transposed, int R, int C, float* sigma, float* af_t,
+                                   int* ctrl, float* stats, int max_sweeps, void* stream);
 R3D_EXPORT int r3d_erank_blocked(const float* x, int ld, int R, int C, float* sigma, float* af_t, int* ctrl, float* stats,
                                  int max_sweeps, void* stream) {
-    R3D_REQUIRE(x && sigma && af_t && ctrl && stats && R > 0 && C > 0 && ld >= C);
+    return r3d_erank_blocked_t(x, ld, 0, R, C, sigma, af_t, ctrl, stats, max_sweeps, stream);
+}
+
+/* r3d_erank_blocked with the input optionally given transposed: x_transposed != 0 -> x is [C][ld] and holds X^T (row c
+ * = column c of the [R, C] matrix that is decomposed).  The training step uses it to decompose fused^T when the token
+ * matrix has fewer rows than columns (the Jacobi works on the orientation with the fewer columns). */
+R3D_EXPORT int r3d_erank_blocked_t(const float* x, int ld, int x_transposed, int R, int C, float* sigma, float* af_t,
+                                   int* ctrl, float* stats, int max_sweeps, void* stream) {
+    R3D_REQUIRE(x && sigma && af_t && ctrl && stats && R > 0 && C > 0 && ld >= (x_transposed ? R : C));
     R3D_REQUIRE(r3d_aligned16(af_t));
     const int b = erank_blk_b(R);
     const int Rp = erank_rp(R);
@@ -701,7 +754,7 @@ R3D_EXPORT int r3d_erank_blocked(const float* x, int ld, int R, int C, float* si
     hipError_t e = hipMemsetAsync(ctrl, 0, sizeof(int) * (4 + ms), st);
     if (e != hipSuccess) return (int)e;
     ErankBlk g{af_t, R, Rp, C, b, nblk, nreal, ctrl};
-    hipLaunchKernelGGL(erank_blk_init_kernel, dim3(r3d_cdiv(nreal * b, 32), r3d_cdiv(Rp, 32)), dim3(256), 0, st, x, ld, g);
+    hipLaunchKernelGGL(erank_blk_init_kernel, dim3(r3d_cdiv(nreal * b, 32), r3d_cdiv(Rp, 32)), dim3(256), 0, st, x, ld, g, x_transposed ? 1 : 0);
     const int rp4 = Rp / 4;
     int rc;
     if (rp4 <= 64) rc = erank_blk_sweeps<1>(g, ms, lds, st);
@@ -722,6 +775,33 @@ R3D_EXPORT int r3d_erank_bwd_coef(const float* sigma, const float* stats, const 
     R3D_REQUIRE(sigma && stats && coef && C > 0);
     hipLaunchKernelGGL(erank_coef_kernel, dim3(r3d_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, sigma, stats, gout,
                        coef, C, max_rank);
+    R3D_LAUNCH_CHECK();
+    return R3D_OK;
+}
+
+/* The backward in its well-conditioned form.  With U = (X V) Sigma^-1 (the rotated columns, normalised) the gradient of a
+ * function of the singular values is U diag(g) V^T; the sweep does not carry V, and V^T = Sigma^-1 U^T X picks up, for a
+ * small sigma_i, the residual coupling e_ij of column i with every large column j amplified by sigma_j / sigma_i (the
+ * two-GEMM form Af diag(g / sigma^3) Af^T X has exactly that error: 0.4 of the gradient's scale with LAPACK's fp32
+ * vectors at the BASELINE shapes).  One Neumann term of (U^T U)^-1 removes it:  V^T = Sigma^-1 (2 I - U^T U) U^T X up to
+ * e^2 sigma_j / sigma_i.  The host composes: scale_rows(af_t, inv) -> W = U^T X -> G = U^T U -> P = G W ->
+ * r3d_erank_bwd_fix: W <- diag(cg) (2 W - P) -> dX = U W.  r3d_erank_bwd_coef2 fills cg[k] = gout * (d erank / d sigma_k)
+ * / sigma_k and inv[k] = 1 / sigma_k (both zero where r3d_erank_bwd_coef's coefficient is). */
+R3D_EXPORT int r3d_erank_bwd_coef2(const float* sigma, const float* stats, const float* gout, float* cg, float* inv, int C,
+                                   int max_rank, void* stream) {
+    R3D_REQUIRE(sigma && stats && cg && inv && C > 0);
+    hipLaunchKernelGGL(erank_coef2_kernel, dim3(r3d_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, sigma, stats, gout, cg,
+                       inv, C, max_rank);
+    R3D_LAUNCH_CHECK();
+    return R3D_OK;
+}
+
+/* w[r, :] = cg[r] * (2 w[r, :] - p[r, :]); w and p dense [rows, cols]. */
+R3D_EXPORT int r3d_erank_bwd_fix(float* w, const float* p, const float* cg, int rows, int cols, void* stream) {
+    R3D_REQUIRE(w && p && cg && rows > 0 && cols > 0);
+    const size_t total = (size_t)rows * cols;
+    const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+    hipLaunchKernelGGL(erank_bwd_fix_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, p, cg, rows, cols);
     R3D_LAUNCH_CHECK();
     return R3D_OK;
 }

@@ -207,6 +207,10 @@ class FusionEngine:
         # hidden = 128: nn.Linear -> dropout -> residuals -> LayerNorm sites run as ONE row-complete launch (gemm_ln.hip)
         # instead of GEMM + LayerNorm: a dependent launch and a memory round trip less per site
         self.use_gemm_ln = True
+        # hidden = 128, one decoder layer: the whole row-local neighbourhood of the SA-Fuser block (V projection + pair swap,
+        # attn.proj, norm2, MLP, fuser.norm, pair mean, segmentation head, key/value projection) and the layer-0 query
+        # self-attention sub-layer as ONE launch per direction (csrc/fuser_chain.hip) instead of 5 + 8
+        self.use_fuser_chain = True
         # fused training flows (forward -> losses(tick=True) -> backward -> adamw(ticked=True)) may set this: the loss
         # kernel then leaves the reduction of its per-unit partials (loss / counter statistics only the host reads) to
         # one extra workgroup of the AdamW launch -- w.loss / w.counts are valid after adamw(), not after losses()
@@ -240,6 +244,14 @@ class FusionEngine:
         # at lr 1e-3 from a random init the tokens move 20-100 % per step and no basis survives (measured: 1.54 vs
         # 1.27 ms/step at the headline shape), so it is opt-in
         self.erank_warm_start = False
+        self.erank_max_sweeps = 16        # blocked (two-level) Jacobi: sweeps enqueued per step (8-10 are used; the rest no-op)
+        # the Jacobi forward depends on the fused tokens only: it is enqueued on a second stream as soon as they exist (a
+        # parallel branch of the step's hipGraph) and joined where its backward adds into the fuser's upstream gradient --
+        # the decoder's forward, the losses and the decoder's backward run beside it
+        self.erank_side_stream = True
+        self.er_stream = torch.cuda.Stream(self.device)
+        self.ws_er = ops.GemmWorkspace(self.device)
+        self._er_pending = False
         self.shapes = {}
         self.train_mask = None            # cached train-mode selection (data independent)
         self.drop_seed = 0x5EED
@@ -308,6 +320,7 @@ class FusionEngine:
         assert x_rgb.shape[1] == self.D and x_dep.shape[1] == self.P, (x_rgb.shape, x_dep.shape, self.D, self.P)
         assert x_rgb.is_contiguous() and x_dep.is_contiguous()
         w = self._shape(B, S, need_grad)
+        self._erank_join()                 # (a forward whose backward never ran: its sweep still reads the workspace)
         drop = training and need_grad and self.dropout_enabled
         if drop:
             if self._drop_ready is w:     # the previous step's AdamW launch already filled the pool for this offset
@@ -479,6 +492,8 @@ class FusionEngine:
                          res2=None if self.bn else w.x0, ws=self.ws)        # (the BN-blend variant has no x_res, :97,101)
                 ops.layernorm_fwd(w.x3, a.p("fuser.norm.weight"), a.p("fuser.norm.bias"), w.y, w.mf, w.rf,
                                   pair_out=w.fused)
+        if not paired:
+            self._erank_fork(w)
         # ---- segmentation head (:228-232); with the composed decoder it shares a launch with the layer-0 key/value
         # projection (both read `fused`, neither depends on the other)
         if paired:
@@ -500,13 +515,29 @@ class FusionEngine:
         else:
             self._decoder_unfused(w, key_labels, dm, dsc, multi, main, s2, sa_block, paired)
         er = self.erank_weight != 0.0 and hasattr(w, "glayers")
-        if er:
+        if er and not w.__dict__.get("_er_forked", False):
             self._erank_forward(w)
+        w._er_forked = False
         self.last = dict(w=w, x_rgb=x_rgb, x_dep=x_dep, mask=mask, idx=idx, drop=drop, mode=mode, tp=tp, seam=seam, erank=er,
                          paired=paired, bn_training=bool(fw.get("bn_training", False)))
         return dict(seg=w.seg.view(B, S, K), action=w.actdur[:, :K].view(B, Q, K), duration=w.actdur[:, K].view(B, Q))
 
     # ---- effective-rank penalty on the fused token matrix [N, H] (erank.hip; Appendix A.11) ------------------------------
+    def _erank_fork(self, w):
+        """Called where the fused tokens have just been enqueued: the Jacobi forward goes to the side stream."""
+        if self.erank_weight == 0.0 or not hasattr(w, "glayers") or not self.erank_side_stream:
+            return
+        self.er_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.er_stream):
+            self._erank_forward(w)
+        w._er_forked = True
+        self._er_pending = True
+
+    def _erank_join(self):
+        if self._er_pending:
+            torch.cuda.current_stream().wait_stream(self.er_stream)
+            self._er_pending = False
+
     def _erank_forward(self, w):
         """Jacobi forward on the fused tokens.  Warm start (erank_warm_start): the sweep runs on X V0, V0 the right
         singular basis the previous step's sweep left behind (the kernel applies its rotations to V too; identity on the
@@ -516,35 +547,56 @@ class FusionEngine:
         N, H = w.N, self.H
         if not hasattr(w, "er_sigma"):
             f = lambda *s: torch.empty(*s, dtype=torch.float32, device=self.device)     # noqa: E731
-            if not ops.erank_fits(N, H):
-                raise NotImplementedError("erank_weight: the fused [N, H] matrix must fit one CU's LDS "
-                                          f"({N}x{H}); use r3d_amd.erank.effective_rank for measurement at this size")
-            w.er_sigma, w.er_stats, w.er_af = f(1, H), f(1, 4), f(1, H, N)
-            w.er_coef, w.er_t1, w.er_gout = f(H), f(H, H), f(1)
-            w.er_vt = torch.eye(H, dtype=torch.float32, device=self.device)      # V0^T
-            w.er_vraw, w.er_vg, w.er_gv, w.er_xw = f(H, H), f(H, H), f(H, H), f(N, H)
-        if self.erank_warm_start and ops.erank_fits_warm(N, H):
-            ops.gemm(GEMM_NT, w.fused, w.er_vt, w.er_xw, ws=self.ws)            # X V0
+            w.er_gout = f(1)
+            w.er_blk = None
+            if ops.erank_fits(N, H):
+                w.er_sigma, w.er_stats, w.er_af = f(1, H), f(1, 4), f(1, H, N)
+                w.er_vt = torch.eye(H, dtype=torch.float32, device=self.device)      # V0^T
+                w.er_vraw, w.er_vg, w.er_gv, w.er_xw = f(H, H), f(H, H), f(H, H), f(N, H)
+            else:
+                # beyond one CU's LDS (cfg4 / cfg5 shapes): the two-level block Jacobi with the columns in HBM, on the
+                # orientation with the fewer columns (the singular values of X and X^T are the same) -- fused^T is
+                # handed over as it lies in memory, no transposition pass
+                w.er_flip = N < H
+                R, Cc = (H, N) if w.er_flip else (N, H)
+                w.er_blk = ops.ErankBlockedBufs(R, Cc, self.device, max_sweeps=self.erank_max_sweeps)
+                w.er_sigma, w.er_stats = w.er_blk.sigma.view(1, Cc), w.er_blk.stats.view(1, 4)
+        if w.er_blk is not None:
+            ops.erank_blocked_into(w.fused, w.er_blk, transposed=w.er_flip)
+        elif self.erank_warm_start and ops.erank_fits_warm(N, H):
+            wsx = self.ws_er
+            ops.gemm(GEMM_NT, w.fused, w.er_vt, w.er_xw, ws=wsx)            # X V0
             ops.erank_jacobi_warm(w.er_xw, w.er_sigma, w.er_stats, w.er_vraw, vt_in=w.er_vt, af_t=w.er_af)
             # the carried basis is a product of ever more rotations: one Newton-Schulz step per use keeps its departure
             # from orthogonality at rounding level (V^T <- 1.5 V^T - 0.5 (V^T V) V^T)
-            ops.gemm(GEMM_NT, w.er_vraw, w.er_vraw, w.er_vg, ws=self.ws)
-            ops.gemm(GEMM_NN, w.er_vg, w.er_vraw, w.er_gv, ws=self.ws)
+            ops.gemm(GEMM_NT, w.er_vraw, w.er_vraw, w.er_vg, ws=wsx)
+            ops.gemm(GEMM_NN, w.er_vg, w.er_vraw, w.er_gv, ws=wsx)
             ops.erank_vt_polish(w.er_vraw, w.er_gv, w.er_vt)
         else:
             ops.erank_jacobi(w.fused, w.er_sigma, w.er_stats, af_t=w.er_af)
 
-    def _erank_backward(self, w, ws):
-        """d_fused2 += d(-erank_weight * erank)/d(fused) = Af diag(coef) (Af^T X): two GEMMs and a row scale."""
+    def _erank_backward(self, w, ws, dst=None):
+        """d_fused2 += d(-erank_weight * erank)/d(fused)  (dst given: dst = that gradient, written, not accumulated): U diag(g)
+        V^T from the rotated columns the sweep left behind, in the Neumann-corrected form of r3d_amd.erank.ErankBackward;
+        when the sweep ran on fused^T (wide token matrices) the same products in the transposed orientation."""
+        from .erank import ErankBackward
+        if not hasattr(w, "er_bwd"):
+            w.er_bwd = ErankBackward(w.N, self.H, w.er_blk is not None and w.er_flip, self.device)
         w.er_gout.fill_(-float(self.erank_weight))
-        ops.erank_bwd_coef(w.er_sigma[0], w.er_stats[0], w.er_gout, w.er_coef, max_rank=min(w.N, self.H))
-        ops.gemm(GEMM_NN, w.er_af[0], w.fused, w.er_t1, ws=ws)                  # Af^T X = Sigma^2 V^T
-        ops.scale_rows(w.er_t1, w.er_coef)
-        ops.gemm(GEMM_TN, w.er_af[0], w.er_t1, w.d_fused2, accumulate=True, ws=ws)
+        A = w.er_blk.af_t if w.er_blk is not None else w.er_af[0]
+        w.er_bwd.run(w.fused, A, w.er_sigma[0], w.er_stats[0], w.er_gout, dst if dst is not None else w.d_fused2,
+                     dst is None, ws)
 
     def erank_value(self):
         """Effective rank of the last forward's fused tokens (device scalar; valid when erank_weight != 0)."""
+        self._erank_join()
         return self.last["w"].er_stats[0, 0]
+
+    def _chain_shape_ok(self, w):
+        return bool(not self.bn and self.dh == 16 and ops.fuser_chain_supported(w.N, self.H, self.K, w.B, self.Q, self.heads))
+
+    def _chain_ok(self, w):
+        return bool(self.use_fuser_chain and self._chain_shape_ok(w))
 
     def _gln(self, rows, K):
         return self.use_gemm_ln and ops.gemm_ln_supported(rows, K, self.H)
@@ -554,6 +606,26 @@ class FusionEngine:
         (transformer.py:289-293,300): independent GEMMs share a launch."""
         a, H, Q, S, B, BQ, heads, dh = self.arena, self.H, self.Q, w.S, w.B, w.BQ, self.heads, self.dh
         c, pl = w.layers[0], "transformer.decoder.layers.0."
+        if self._chain_ok(w):
+            key = ("fwd_chain", bool(drop))
+            if key not in w.tables:
+                wi, bi = a.p(pl + "multihead_attn.in_proj_weight"), a.p(pl + "multihead_attn.in_proj_bias")
+                w.tables[key] = ops.FuserChainFwd(
+                    x0=w.x0, h1=w.h1, wv=wv, wproj=a.p(pre + "attn.proj.weight"), bproj=a.p(pre + "attn.proj.bias"),
+                    g2=a.p(pre + "norm2.weight"), be2=a.p(pre + "norm2.bias"), w1=a.p(pre + "mlp.mlp.0.weight"),
+                    b1=a.p(pre + "mlp.mlp.0.bias"), w2=a.p(pre + "mlp.mlp.2.weight"), b2=a.p(pre + "mlp.mlp.2.bias"),
+                    gf=a.p("fuser.norm.weight"), bef=a.p("fuser.norm.bias"), pos=pos.contiguous(), wkv=wi[H:], bkv=bi[H:],
+                    wseg=a.p("fc_seg.weight"), bseg=a.p("fc_seg.bias"), vsw=w.vsw, x1=w.x1, h2=w.h2, m2=w.m2, r2=w.r2, u=w.u,
+                    f1=w.f1, x3=w.x3, y=w.y, mf=w.mf, rf=w.rf, fused=w.fused, seg=w.seg, cakv=c["cakv"],
+                    qpos=qpos, w_in=a.p(pl + "self_attn.in_proj_weight"), b_in=a.p(pl + "self_attn.in_proj_bias"),
+                    w_out=a.p(pl + "self_attn.out_proj.weight"), b_out=a.p(pl + "self_attn.out_proj.bias"),
+                    g1=a.p(pl + "norm1.weight"), be1=a.p(pl + "norm1.bias"), wq=wi[:H], bq=bi[:H],
+                    drop_sa=dm("sa_p0"), drop_d1=dm("d1_0"), drop_scale=dsc, sa_qkv=c["sa_qkv"], p_sa=c["p_sa"],
+                    sa_o=c["sa_o"], t1_pre=c["t1_pre"], t1=c["t1"], m1=c["m1"], r1=c["r1"], caq=c["caq"],
+                    N=w.N, S=S, K=self.K, H=H, add_xres=0 if self.bn else 1, B=B, Q=Q, heads=heads)
+            w.tables[key].launch()
+            self._erank_fork(w)
+            return
         key = ("fwd_pairs", bool(drop))
         if key not in w.tables:
             wi, bi = a.p(pl + "multihead_attn.in_proj_weight"), a.p(pl + "multihead_attn.in_proj_bias")
@@ -607,6 +679,7 @@ class FusionEngine:
                      rstd=c["r1"]),
                 dict(x=w.x3, gamma=a.p("fuser.norm.weight"), beta=a.p("fuser.norm.bias"), y=w.y, mean=w.mf, rstd=w.rf,
                      pair_out=w.fused)])
+        self._erank_fork(w)
         g3.launch()
 
     def _decoder_unfused(self, w, key_labels, dm, dsc, multi, main, s2, sa_block, paired=False):
@@ -834,6 +907,23 @@ class FusionEngine:
         Js = [(w.lnp_seam["n1"], -N, H) + j[3:] if j[0] is w.lnp["n1"] else
               ((w.lnp_seam["dep"], -N, H) + j[3:] if j[0] is w.lnp["dep"] else j) for j in J]
         w.ln_group_seam = ops.LnFinalizeGroup(Js)
+        Jc = None
+        if self._chain_shape_ok(w):
+            # the chain backward (csrc/fuser_chain.hip) leaves one (dgamma, dbeta) pair per 4 rows for the fuser's norm /
+            # norm2 and the decoder's norm1, and one per frame (the seam's layout) for norm1 / the depth LayerNorm
+            f = lambda n_: torch.empty(n_, dtype=torch.float32, device=self.device)     # noqa: E731
+            w.chain_parts = dict(nf=f(2 * N // 4 * 2 * H), n2=f(2 * N // 4 * 2 * H), d1=f(BQ // 4 * 2 * H))
+            w.d_extra = torch.empty(N, H, dtype=torch.float32, device=self.device)
+            rep = [(w.lnp["nf"], w.chain_parts["nf"], -(2 * N // 4)), (w.lnp["n2"], w.chain_parts["n2"], -(2 * N // 4)),
+                   (w.lnp["n1"], w.lnp_seam["n1"], -N), (w.lnp["dep"], w.lnp_seam["dep"], -N),
+                   (w.lnp["d1_0"], w.chain_parts["d1"], -(BQ // 4))]
+
+            def swap(j):
+                for old_, new_, rows_ in rep:
+                    if j[0] is old_:
+                        return (new_, rows_, H) + j[3:]
+                return j
+            Jc = [swap(j) for j in J]
         Jb = None
         if self.bn:                            # norm1's partials come from r3d_bn_blend_bwd (one per frame)
             Jb = [(w.lnp_seam["n1"], -N, H) + j[3:] if j[0] is w.lnp["n1"] else j for j in J]
@@ -864,7 +954,8 @@ class FusionEngine:
             o = (dg.data_ptr() - a.grads.data_ptr()) // 4
             return (part[:blocks * 2 * Hh].view(blocks, 2 * Hh), None, 1, a.grads[o:o + 2 * Hh].view(1, 2 * Hh))
         w.tail_groups, w.tail_jobs = {}, {}
-        for name, jobs in (("plain", J), ("seam", Js)) + ((("bn", Jb),) if Jb is not None else ()):
+        for name, jobs in ((("plain", J), ("seam", Js)) + ((("bn", Jb),) if Jb is not None else ()) +
+                           ((("chain", Jc),) if Jc is not None else ())):
             conv = [as_rowsum(j) for j in jobs]
             if all(c is not None for c in conv):
                 w.tail_groups[name] = ops.RowsumGroup(R + conv)
@@ -1007,7 +1098,35 @@ class FusionEngine:
                 dy, dy2 = gl["sain"], gl["t1pre"]
         # ---- fuser; d(memory) = decoder part (d_fused, kept for the positional-embedding gradient :190) + seg head part
         pre = "fuser.blocks.0."
-        if st.get("paired"):
+        chain = bool(st.get("paired") and self._chain_ok(w))
+        if chain:
+            # everything from the decoder's memory-side input gradients to the two embeddings' pre-activation gradients,
+            # and the query-side branch, in ONE launch (csrc/fuser_chain.hip)
+            c, gl, pl = w.layers[0], w.glayers[0], "transformer.decoder.layers.0."
+            er = bool(st.get("erank"))
+            key = ("bwd_chain", bool(drop), er)
+            if key not in w.tables:
+                wi0 = a.p(pl + "multihead_attn.in_proj_weight")
+                w.tables[key] = ops.FuserChainBwd(
+                    d_cakv=gl["cakv"], d_seg=w.d_seg, d_extra=w.d_extra if er else None, wkv=wi0[H:], wseg=a.p("fc_seg.weight"),
+                    x3=w.x3, mf=w.mf, rf=w.rf, gf=a.p("fuser.norm.weight"), w2=a.p(pre + "mlp.mlp.2.weight"), u=w.u,
+                    w1=a.p(pre + "mlp.mlp.0.weight"), x1=w.x1, m2=w.m2, r2=w.r2, g2=a.p(pre + "norm2.weight"),
+                    wproj=a.p(pre + "attn.proj.weight"), wv=a.p(pre + "attn.qkv.weight")[2 * H:], x0=w.x0, m1=w.m1, r1=w.r1,
+                    g1n=a.p(pre + "norm1.weight"), drop_x0=dmf("x0"), m_rgb=st["mask"][0], m_dep=st["mask"][1], rgb=w.rgb,
+                    dep_pre=w.dep_pre, mean_d=w.mean_d, rstd_d=w.rstd_d, lnd_g=a.p("depth_layernorm.weight"),
+                    lnd_b=a.p("depth_layernorm.bias"), d_fused=w.d_fused, d_x3=w.d_x3, d_u=w.d_u, d_h2=w.d_h2, d_x1=w.d_x1,
+                    d_v=w.d_v, d_h1=w.d_h1, d_rgb_pre=w.d_rgb_pre, d_dep_pre=w.d_dep_pre, part_nf=w.chain_parts["nf"],
+                    part_n2=w.chain_parts["n2"], part_n1=w.lnp_seam["n1"], part_dep=w.lnp_seam["dep"],
+                    d_caq=gl["caq"], d_t1_res=gl["t2pre"], wq=wi0[:H], t1_pre=c["t1_pre"], m1d=c["m1"], r1d=c["r1"],
+                    g1d=a.p(pl + "norm1.weight"), drop_d1=dmf("d1_0"), w_out=a.p(pl + "self_attn.out_proj.weight"),
+                    sa_qkv=c["sa_qkv"], p_sa=c["p_sa"], drop_sa=dmf("sa_p0"), w_in=a.p(pl + "self_attn.in_proj_weight"),
+                    caqin=gl["caqin"], t1pre_out=gl["t1pre"], sap=gl["sap"], sao=gl["sao"], saqkv=gl["saqkv"], sain=gl["sain"],
+                    part_d1=w.chain_parts["d1"], drop_scale=dsc, N=N, S=S, K=K, H=H, add_xres=1, B=B, Q=Q, heads=heads)
+            if er:
+                self._erank_join()
+                self._erank_backward(w, ws, dst=w.d_extra)
+            w.tables[key].launch()
+        elif st.get("paired"):
             # the query-side branch (cross-attention query projection, norm1, self-attention: parameter gradients only
             # for a one-layer decoder) and the memory-side chain into the fuser are independent: their GEMMs share launches
             c, gl, pl = w.layers[0], w.glayers[0], "transformer.decoder.layers.0."
@@ -1047,6 +1166,7 @@ class FusionEngine:
             gb1, gb2, gb3 = w.tables[key]
             gb1.launch()
             if st.get("erank"):
+                self._erank_join()
                 self._erank_backward(w, ws)
             def lnj(site, dy, x, mean, rstd, gname, bname, dx, **kw):
                 return dict(dy=dy, x=x, mean=mean, rstd=rstd, gamma=a.p(gname), beta=a.p(bname), dx=dx, dgamma=a.g(gname),
@@ -1067,14 +1187,17 @@ class FusionEngine:
                 gb3.launch()
         else:
             if st.get("erank"):
+                self._erank_join()
                 self._erank_backward(w, ws)
             ln_bwd("nf", w.d_fused, w.x3, w.mf, w.rf, "fuser.norm.weight", "fuser.norm.bias", w.d_x3, pair_in=True,
                    dy2=w.d_fused2)
             ops.gemm(GEMM_NN, w.d_x3, a.p(pre + "mlp.mlp.2.weight"), w.d_u, aux=w.u, mul=2, ws=ws)
             ops.gemm(GEMM_NN, w.d_u, a.p(pre + "mlp.mlp.0.weight"), w.d_h2, ws=ws)
-        ride_bwd = bool(st.get("paired") and self.ride_attention_bwd and H <= 128 and
+        ride_bwd = bool(st.get("paired") and not chain and self.ride_attention_bwd and H <= 128 and
                         ops.gemm_ln_mha_supported(heads, Q, Q, dh))
-        if ride_bwd:
+        if chain:
+            pass
+        elif ride_bwd:
             c0, gl0 = w.layers[0], w.glayers[0]
             ops.layernorm_bwd_multi(
                 [dict(dy=w.d_h2, x=w.x1, mean=w.m2, rstd=w.r2, gamma=a.p(pre + "norm2.weight"), beta=a.p(pre + "norm2.bias"),
@@ -1087,7 +1210,7 @@ class FusionEngine:
         else:
             ln_bwd("n2", w.d_h2, w.x1, w.m2, w.r2, pre + "norm2.weight", pre + "norm2.bias", w.d_x1, add1=w.d_x3,
                    dy2=w.d_h2b if (st.get("paired") and self.split_k4h and H < 256) else None)
-        if ride_bwd:
+        if ride_bwd or chain:
             pass
         elif st.get("paired"):
             w.tables[("bwd_vh1",)].launch()
@@ -1095,7 +1218,9 @@ class FusionEngine:
             ops.gemm(GEMM_NN, w.d_x1, a.p(pre + "attn.proj.weight"), w.d_v, c_row_xor=1, ws=ws)     # un-swap
             ops.gemm(GEMM_NN, w.d_v, a.p(pre + "attn.qkv.weight")[2 * H:], w.d_h1, ws=ws)
         mask = st["mask"]
-        if st["seam"]:                      # norm1 backward + exchange backward + depth LayerNorm backward: one launch
+        if chain:
+            pass
+        elif st["seam"]:                    # norm1 backward + exchange backward + depth LayerNorm backward: one launch
             ops.embed_fuse_bwd(w.d_h1, w.x0, w.m1, w.r1, a.p(pre + "norm1.weight"), w.d_x1, w.d_x3, dmf("x0"), dsc, mask[0],
                                mask[1], w.rgb, w.dep_pre, w.mean_d, w.rstd_d, a.p("depth_layernorm.weight"),
                                a.p("depth_layernorm.bias"), w.d_rgb_pre, w.d_dep_pre, w.lnp_seam["n1"], w.lnp_seam["dep"])
@@ -1127,12 +1252,13 @@ class FusionEngine:
         if not joined:
             main.wait_stream(s2)
         # ---- everything that only feeds parameter gradients: 2 launches + the broadcast-parameter sums
-        tname = "bn" if self.bn else ("seam" if st["seam"] else "plain")
+        tname = "chain" if chain else ("bn" if self.bn else ("seam" if st["seam"] else "plain"))
         both = self._wgrad_with_sums(w, tname) if (self.fold_rowsums and self.L == 1) else None
         wg = both if both is not None else w.wgrad_group
         wg.set_b(w.rgb_wgrad_idx, st["x_rgb"])
         wg.launch()
         tail = w.tail_groups.get(tname)
+        assert not chain or both is not None or tail is not None, "chain backward: its partial layout needs the row-sum tail"
         if both is not None:               # (the sums below rode in the weight-gradient launch)
             pass
         elif tail is not None:             # pos_embedding (:190), depth_projection.bias, query_embed (top layer) and

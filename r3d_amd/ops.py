@@ -334,6 +334,63 @@ def gemm_ln_fwd(jobs, mha=None):
     check(_lib.load().r3d_gemm_ln_fwd(arr, len(jobs), H, _stream()), "r3d_gemm_ln_fwd")
 
 
+def fuser_chain_supported(N, H, K, B, Q, heads):
+    return bool(_lib.load().r3d_fuser_chain_supported(N, H, K, B, Q, heads))
+
+
+class FuserChainFwd:
+    """The argument block of r3d_fuser_chain_fwd (csrc/fuser_chain.hip), built once per workspace: every operand is a
+    dense row-major tensor whose address is fixed for the life of the workspace (the dropout masks are optional)."""
+
+    def __init__(self, **t):
+        from ._lib import FuserChainFwdArgs
+        a = FuserChainFwdArgs()
+        dims = {k: t.pop(k) for k in ("N", "S", "K", "H", "add_xres", "B", "Q", "heads")}
+        a.drop_scale = float(t.pop("drop_scale", 1.0))
+        opt = {"y", "drop_sa", "drop_d1"}
+        for name in FuserChainFwdArgs._PTRS + FuserChainFwdArgs._PTRS2:
+            v = t.pop(name, None)
+            if v is None:
+                assert name in opt, name
+                continue
+            assert v.is_cuda and v.is_contiguous(), name
+            assert v.dtype == (torch.uint8 if name.startswith("drop_") else torch.float32), name
+            setattr(a, name, v.data_ptr())
+        assert not t, t.keys()
+        for k, v in dims.items():
+            setattr(a, k, int(v))
+        self.args = a
+
+    def launch(self):
+        check(_lib.load().r3d_fuser_chain_fwd(C.byref(self.args), _stream()), "r3d_fuser_chain_fwd")
+
+
+class FuserChainBwd:
+    """The argument block of r3d_fuser_chain_bwd, built once per workspace (see FuserChainFwd)."""
+
+    def __init__(self, **t):
+        from ._lib import FuserChainBwdArgs
+        a = FuserChainBwdArgs()
+        dims = {k: t.pop(k) for k in ("N", "S", "K", "H", "add_xres", "B", "Q", "heads")}
+        a.drop_scale = float(t.pop("drop_scale", 1.0))
+        opt = {"d_extra", "drop_x0", "drop_d1", "drop_sa", "d_h2", "d_h1", "t1pre_out"}
+        for name in FuserChainBwdArgs._PTRS:
+            v = t.pop(name, None)
+            if v is None:
+                assert name in opt, name
+                continue
+            assert v.is_cuda and v.is_contiguous(), name
+            assert v.dtype == (torch.uint8 if name.startswith("drop_") else torch.float32), name
+            setattr(a, name, v.data_ptr())
+        assert not t, t.keys()
+        for k, v in dims.items():
+            setattr(a, k, int(v))
+        self.args = a
+
+    def launch(self):
+        check(_lib.load().r3d_fuser_chain_bwd(C.byref(self.args), _stream()), "r3d_fuser_chain_bwd")
+
+
 def layernorm_bwd_multi(jobs, mha=None):
     """jobs: up to 4 dicts with the arguments of layernorm_bwd (dy, x, mean, rstd, gamma, beta, dx, dgamma, dbeta,
     partial required; pair_in, relu, dy2, add1, add2, dx2, drop_mask, drop_scale optional).
@@ -717,11 +774,52 @@ def erank_blocked(x, max_sweeps=16):
     return sigma, stats, af_t[:, :R]
 
 
+class ErankBlockedBufs:
+    """Pre-allocated outputs / scratch of r3d_erank_blocked_t for one [R, C] matrix (the training step calls it every step,
+    inside a hipGraph): sigma [C], stats [4], af_t [Cpad, Rp] (rows = rotated columns (X V)^T), ctrl."""
+
+    def __init__(self, R, Cc, device, max_sweeps=16):
+        import ctypes
+        sz = (ctypes.c_int64 * 4)()
+        check(_lib.load().r3d_erank_blocked_sizes(R, Cc, max_sweeps, ctypes.cast(sz, ctypes.c_void_p)), "r3d_erank_blocked_sizes")
+        self.R, self.C, self.Rp, self.max_sweeps = R, Cc, int(sz[2]), max_sweeps
+        self.af_full = torch.zeros(sz[0] // self.Rp, self.Rp, dtype=torch.float32, device=device)
+        self.ctrl = torch.zeros(sz[1], dtype=torch.int32, device=device)
+        self.sigma = torch.empty(Cc, dtype=torch.float32, device=device)
+        self.stats = torch.empty(4, dtype=torch.float32, device=device)
+
+    @property
+    def af_t(self):
+        """[C, R] view (row stride Rp) of the rotated columns."""
+        return self.af_full[:self.C, :self.R]
+
+
+def erank_blocked_into(x, bufs, transposed=False):
+    """Decomposes X [R, C] = x (or x^T when transposed: x is then [C, R] row-major) into bufs; enqueue only."""
+    if transposed:
+        assert x.shape == (bufs.C, bufs.R) and x.stride(1) == 1
+    else:
+        assert x.shape == (bufs.R, bufs.C) and x.stride(1) == 1
+    check(_lib.load().r3d_erank_blocked_t(_p(x), x.stride(0), 1 if transposed else 0, bufs.R, bufs.C, _p(bufs.sigma),
+                                          _p(bufs.af_full), _p(bufs.ctrl), _p(bufs.stats), bufs.max_sweeps, _stream()),
+          "r3d_erank_blocked_t")
+
+
 def erank_bwd_coef(sigma, stats, gout, coef, max_rank=0):
     """max_rank = min(R, C) of the decomposed matrix: singular values beyond it are rounding noise."""
     lib = _lib.load()
     check(lib.r3d_erank_bwd_coef(_p(sigma), _p(stats), _p(gout), _p(coef), sigma.numel(), max_rank, _stream()),
           "r3d_erank_bwd_coef")
+
+
+def erank_bwd_coef2(sigma, stats, gout, cg, inv, max_rank=0):
+    check(_lib.load().r3d_erank_bwd_coef2(_p(sigma), _p(stats), _p(gout), _p(cg), _p(inv), sigma.numel(), max_rank, _stream()),
+          "r3d_erank_bwd_coef2")
+
+
+def erank_bwd_fix(w, p, cg):
+    assert w.is_contiguous() and p.is_contiguous() and w.shape == p.shape and cg.numel() == w.shape[0]
+    check(_lib.load().r3d_erank_bwd_fix(_p(w), _p(p), _p(cg), w.shape[0], w.shape[1], _stream()), "r3d_erank_bwd_fix")
 
 
 def scale_rows(x, coef):

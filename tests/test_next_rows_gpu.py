@@ -149,3 +149,25 @@ def test_train_harness_matches_reference_capture(tmp_path, capsys):
     assert sorted(os.listdir(tmp_path)) == fx["ckpt_files"]
     sd = torch.load(os.path.join(tmp_path, "seed_1_best.ckpt"), weights_only=True)
     assert list(sd.keys()) == fx["ckpt_keys"]
+
+
+def test_predict_over_synthetic_videos_matches_fixture(tmp_path, capsys):
+    """predict() with the reference's signature (evaluation/predict_utkinects.py:215, main_darai.py:164) driving the HIP model
+    over three synthetic per-video .npy + ground-truth files: labels / anticipated frames equal the oracle's, the per-class
+    counts equal the reference's own utils.eval_file (tests/golden/make_predict_golden.py), the MoC lines are the
+    reference's text."""
+    import json
+    import os
+    from oracle import synth
+    from r3d_amd.model.futr_safuser_tokenfusion import FUTR
+    from tests.test_utils_cpu import check_predict_against_fixture
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "predict_golden.npz"))
+    m = json.loads(str(fx["meta"]))
+    a = argparse.Namespace(input_dim=2048, seg=True, anticipate=True, max_pos_len=2000, input_type="i3d_transcript")
+    model = FUTR(m["K"], m["H"], m["K"] + 1, torch.device("cuda"), a, n_query=m["Q"], n_head=m["heads"],
+                 num_encoder_layers=2, num_decoder_layers=1, depth_pixels=m["pix"][0] * m["pix"][1])
+    names = [(n, tuple(p.shape)) for n, p in model.named_parameters()]
+    params = {n: torch.from_numpy(v) for n, v in synth.fill_state(names).items()}
+    model.load_state_dict(params, strict=False)
+    model = model.to("cuda")
+    check_predict_against_fixture(model, tmp_path, capsys, torch.device("cuda"))
