@@ -276,6 +276,9 @@ def main():
     ap.add_argument("--no-fuser-chain", action="store_true",
                     help="the fuser block's row-local chain as grouped GEMM / gemm_ln launches instead of the one-launch "
                          "chain kernels (A/B)")
+    ap.add_argument("--no-decoder-chain", action="store_true",
+                    help="the decoder layer's query side as separate attention / GEMM / LayerNorm / loss launches instead of "
+                         "the one-launch decoder chain kernel (A/B)")
     ap.add_argument("--erank-main-stream", action="store_true",
                     help="with --erank-weight: the Jacobi forward in stream order instead of on the side stream (A/B)")
     ap.add_argument("--no-paired", action="store_true",
@@ -346,6 +349,7 @@ def main():
     eng.use_fused_decoder = a.fused_decoder
     eng.use_gemm_ln = not a.no_gemm_ln
     eng.use_fuser_chain = not a.no_fuser_chain
+    eng.use_decoder_chain = not a.no_decoder_chain
     eng.erank_side_stream = not a.erank_main_stream
     if a.no_paired:
         eng.use_paired_launches = False

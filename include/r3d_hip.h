@@ -278,6 +278,8 @@ typedef struct r3d_fuser_chain_fwd_args {
     const uint8_t* drop_sa; const uint8_t* drop_d1; float drop_scale;
     float* sa_qkv; float* p_sa; float* sa_o; float* t1_pre; float* t1; float* m1; float* r1; float* caq;
     int32_t N, S, K, H, add_xres, B, Q, heads;
+    uint64_t* timeline;      /* profiling aid, normally NULL: wave 0 of the first workgroup of each role stores wall_clock64()
+                                (100 MHz) at its stage boundaries -- fuser role [0..15], query role [16..31] */
 } r3d_fuser_chain_fwd_args;
 int r3d_fuser_chain_supported(int N, int H, int K, int B, int Q, int heads);
 int r3d_fuser_chain_fwd(const r3d_fuser_chain_fwd_args* a, void* stream);
@@ -306,6 +308,7 @@ typedef struct r3d_fuser_chain_bwd_args {
     float* caqin; float* t1pre_out; float* sap; float* sao; float* saqkv; float* sain; float* part_d1;
     float drop_scale;
     int32_t N, S, K, H, add_xres, B, Q, heads;
+    uint64_t* timeline;      /* as in r3d_fuser_chain_fwd_args */
 } r3d_fuser_chain_bwd_args;
 int r3d_fuser_chain_bwd(const r3d_fuser_chain_bwd_args* a, void* stream);
 
@@ -459,6 +462,34 @@ typedef struct r3d_tail_losses_args {
 } r3d_tail_losses_args;
 int r3d_decoder_tail_losses_supported(int H, int n_head, int Q, int rows);
 int r3d_decoder_tail_losses(const r3d_tail_losses_args* a, float* ws, void* stream);
+
+/* ---- the decoder layer's query side as ONE launch (csrc/decoder_chain.hip; hidden 128, 8 queries, 8 heads, <= 64 keys) ----
+ * One workgroup per clip.  phases (bit mask):
+ *   1  forward : cross-attention core on (caq, cakv[:, :128] = keys, cakv[:, 128:] = values; key j of clip b padded iff
+ *                key_label[b][j] == pad_idx; probabilities p_ca, dropout drop_ca) -> t2_pre = dropout(ca_o Wo^T + bo) + t1 ->
+ *                t2 = norm2(t2_pre) -> ff1 = dropout(relu(t2 W1^T + b1)) -> t3_pre = dropout(ff1 W2^T + b2) + t2
+ *                (model/extras/transformer.py:300-306,325-328)
+ *   2  tail    : r3d_decoder_tail_losses on the clip (norm3 -> decoder.norm -> heads -> the three losses -> back to d_t3pre /
+ *                d_ff2); `tail` and `ws` as for that entry point; tail->x must be t3_pre, tail->dx / dx2 must be d_t3pre / d_ff2
+ *   4  backward: d_ff1 = (d_ff2 W2) relu' dropout' -> d t2 = d_ff1 W1 + d_t3pre -> norm2 backward (d_t2pre; LayerNorm parameter
+ *                partials part_d2 [B*Q/4][2][128], one pair per 4 rows) -> d_cap = dropout' -> d_cao = d_cap Wo -> attention core
+ *                backward (d_caq [B*Q,128], d_cakv [B*S,256])
+ * 7 = the training step's whole decoder after the key/value projection in one launch; 1 and 4 stand alone.  Matrices dense
+ * row-major; dropout masks optional (NULL). */
+typedef struct r3d_decoder_chain_args {
+    const float* caq; const float* cakv; const int64_t* key_label; float* p_ca; const uint8_t* drop_ca; float* ca_o;
+    const float* wo; const float* bo; const uint8_t* drop_d2; const float* t1; float* t2_pre; const float* g2; const float* be2;
+    float* t2; float* m2; float* r2; const float* w1; const float* b1; const uint8_t* drop_ff; float* ff1;
+    const float* w2; const float* b2; const uint8_t* drop_d3; float* t3_pre;
+    const float* d_t3pre; const float* d_ff2; float* d_ff1; float* d_t2pre; float* d_cap; float* d_cao; float* d_caq;
+    float* d_cakv; float* part_d2;
+    float drop_scale;
+    int32_t pad_idx, B, S, H, Q, heads, phases;
+    uint64_t* timeline;      /* profiling aid, normally NULL: wave 0 of clip 0 stores wall_clock64() (100 MHz) at its stage
+                                boundaries [0..31] */
+} r3d_decoder_chain_args;
+int r3d_decoder_chain_supported(int H, int Q, int heads, int S);
+int r3d_decoder_chain(const r3d_decoder_chain_args* d, const r3d_tail_losses_args* tail, float* ws, void* stream);
 
 /* ---- optimiser / dropout masks: main_darai.py:135, train/train_proposed_depth.py:215 -------------------------- */
 /* torch.optim.AdamW semantics over flat arenas of n floats (n % 4 == 0, 16-byte aligned); g is multiplied by

@@ -72,7 +72,7 @@ class FuserChainFwdArgs(C.Structure):
              "cakv qpos w_in b_in w_out b_out g1 be1 wq bq drop_sa drop_d1").split()
     _PTRS2 = "sa_qkv p_sa sa_o t1_pre t1 m1 r1 caq".split()
     _fields_ = ([(n, C.c_void_p) for n in _PTRS] + [("drop_scale", C.c_float)] + [(n, C.c_void_p) for n in _PTRS2] +
-                [(n, C.c_int32) for n in "N S K H add_xres B Q heads".split()])
+                [(n, C.c_int32) for n in "N S K H add_xres B Q heads".split()] + [("timeline", C.c_void_p)])
 
 
 class FuserChainBwdArgs(C.Structure):
@@ -82,7 +82,15 @@ class FuserChainBwdArgs(C.Structure):
              "part_n1 part_dep d_caq d_t1_res wq t1_pre m1d r1d g1d drop_d1 w_out sa_qkv p_sa drop_sa w_in caqin t1pre_out "
              "sap sao saqkv sain part_d1").split()
     _fields_ = ([(n, C.c_void_p) for n in _PTRS] + [("drop_scale", C.c_float)] +
-                [(n, C.c_int32) for n in "N S K H add_xres B Q heads".split()])
+                [(n, C.c_int32) for n in "N S K H add_xres B Q heads".split()] + [("timeline", C.c_void_p)])
+
+
+class DecoderChainArgs(C.Structure):
+    """struct r3d_decoder_chain_args"""
+    _PTRS = ("caq cakv key_label p_ca drop_ca ca_o wo bo drop_d2 t1 t2_pre g2 be2 t2 m2 r2 w1 b1 drop_ff ff1 w2 b2 drop_d3 "
+             "t3_pre d_t3pre d_ff2 d_ff1 d_t2pre d_cap d_cao d_caq d_cakv part_d2").split()
+    _fields_ = ([(n, C.c_void_p) for n in _PTRS] + [("drop_scale", C.c_float)] +
+                [(n, C.c_int32) for n in "pad_idx B S H Q heads phases".split()] + [("timeline", C.c_void_p)])
 
 
 class MhaJob(C.Structure):
@@ -153,6 +161,8 @@ _SIGNATURES = {
     "r3d_fuser_chain_supported": ([_I, _I, _I, _I, _I, _I], C.c_int),
     "r3d_fuser_chain_fwd": ([_P, _P], C.c_int),
     "r3d_fuser_chain_bwd": ([_P, _P], C.c_int),
+    "r3d_decoder_chain_supported": ([_I, _I, _I, _I], C.c_int),
+    "r3d_decoder_chain": ([_P, _P, _P, _P], C.c_int),
     "r3d_gemm_ln_mha_supported": ([_I, _I, _I, _I], C.c_int),
     "r3d_gemm_ln_mha_fwd": ([_P, _I, _I, _P, _P], C.c_int),
     "r3d_layernorm_fwd_multi": ([_P, _I, _P], C.c_int),

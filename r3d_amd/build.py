@@ -16,7 +16,7 @@ OUT_DIR = os.path.join(HERE, "_build")
 LIB = os.path.join(OUT_DIR, "libr3d_hip.so")
 ARCH = "gfx950"
 SOURCES = ["abi.hip", "gemm_f32.hip", "rowops.hip", "fusion.hip", "attention.hip", "decoder.hip", "losses.hip", "optim.hip", "embed.hip", "tail.hip", "bnfuse.hip",
-           "erank.hip", "posenc.hip", "gemm_bf3.hip", "gemm_ln.hip", "fuser_chain.hip"]
+           "erank.hip", "posenc.hip", "gemm_bf3.hip", "gemm_ln.hip", "fuser_chain.hip", "decoder_chain.hip"]
 FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall",
          "-Wno-unused-function", "-Wno-pass-failed"]
 

@@ -25,20 +25,12 @@
 //
 // Intermediates the weight-gradient launch and the backward need (vsw, x1, h2, u, f1, x3, row statistics, ...) are stored
 // from the accumulator layout as they are produced.
-#include "common.h"
+#include "chain_common.h"
 #include "mha_small.h"
 #include "../../include/r3d_hip.h"
 
 namespace r3d {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int kFcH = 128;                   // hidden size this file is compiled for
-constexpr int kFcRows = 16;                 // token rows per workgroup
-constexpr int kFcP1 = kFcH + 4;             // LDS pitch of a [16][128] activation tile (conflict-free 16-byte operand reads)
-constexpr int kFcP4 = 4 * kFcH + 4;         // ... of the [16][512] MLP activation
-constexpr int kFcWP = kFcH + 4;             // ... of a wave's 16 x 128 weight chunk
-constexpr float kFcEps = 1e-5f;
 constexpr int kFcBufH = 0;
 constexpr int kFcBufV = kFcBufH + kFcRows * kFcP1;
 constexpr int kFcBufF = kFcBufV + kFcRows * kFcP1;
@@ -48,93 +40,6 @@ constexpr int kFcLdsFloats = kFcRed + 2 * 8 * kFcRows;
 constexpr int kFcLdsBytes = kFcLdsFloats * 4;
 static_assert(mha_small_lds_floats(16, 8) <= 16 * kFcWP, "the query role's attention units borrow the wave's weight region");
 static_assert(mha_small_bwd_lds_floats(16, 8) <= 16 * kFcWP, "the query role's attention units borrow the wave's weight region");
-
-__device__ __forceinline__ float fc_row16_sum(float v) {
-    v += dpp_mov_f<0x128>(v);
-    v += dpp_mov_f<0x124>(v);
-    v += dpp_mov_f<0x122>(v);
-    v += dpp_mov_f<0x121>(v);
-    return v;
-}
-
-// One 16-row x 128-k weight chunk in flight: lane l of load i holds 16 bytes of row 2i + (l >> 5) at k = 4 (l & 31).
-// Rows >= nvalid read row nvalid - 1 (heads whose row count is not a multiple of 16): every load is unconditional.
-struct FcW { f32x4 v[8]; };
-__device__ __forceinline__ void fc_wload(FcW& r, const float* w, int ldw, int nvalid, int lane) {
-    const float* p = w + 4 * (lane & 31);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        int row = 2 * i + (lane >> 5);
-        row = row < nvalid ? row : nvalid - 1;
-        r.v[i] = *reinterpret_cast<const f32x4*>(p + (size_t)row * ldw);
-    }
-}
-__device__ __forceinline__ void fc_wstore(const FcW& r, float* wl, int lane) {
-    float* p = wl + (lane >> 5) * kFcWP + 4 * (lane & 31);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(p + 2 * i * kFcWP) = r.v[i];
-}
-// operand registers of one 128-deep chunk (lane = row li, k group q; see gemm_ln.hip: the k order inside a 16-deep step
-// is permuted identically on both operands, so one 16-byte read feeds four MFMAs)
-struct FcOp { f32x4 v[8]; };
-__device__ __forceinline__ void fc_opload(FcOp& o, const float* rowk) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) o.v[j] = *reinterpret_cast<const f32x4*>(rowk + 16 * j);
-}
-__device__ __forceinline__ void fc_mfma(const FcOp& a, const FcOp& b, f32x4& acc0, f32x4& acc1) {
-#pragma unroll
-    for (int j = 0; j < 8; j += 2) {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j][0], b.v[j][0], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j + 1][0], b.v[j + 1][0], acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j][1], b.v[j][1], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j + 1][1], b.v[j + 1][1], acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j][2], b.v[j][2], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j + 1][2], b.v[j + 1][2], acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j][3], b.v[j][3], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j + 1][3], b.v[j + 1][3], acc1, 0, 0, 0);
-    }
-}
-// chunk product: B operand from the wave's weight region, A operand already in registers
-__device__ __forceinline__ void fc_chunk(const FcOp& a, const float* wr, f32x4& acc0, f32x4& acc1) {
-    FcOp b;
-    fc_opload(b, wr);
-    fc_mfma(a, b, acc0, acc1);
-}
-
-// LayerNorm of 16 complete rows held in the accumulator layout (lane: column c of the wave's tile, rows 4q .. 4q + 3):
-// 16 lanes by DPP, 8 waves through LDS, two-pass mean / variance as nn.LayerNorm.  Two workgroup barriers.
-__device__ __forceinline__ void fc_layernorm(const float (&v)[4], float (*red)[8][kFcRows], int wave, int li, int q,
-                                             float (&mean)[4], float (&rstd)[4]) {
-    float s[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) s[i] = fc_row16_sum(v[i]);
-    if (li == 0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) red[0][wave][4 * q + i] = s[i];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        float m = 0.f;
-#pragma unroll
-        for (int w8 = 0; w8 < 8; ++w8) m += red[0][w8][4 * q + i];
-        mean[i] = m * (1.0f / (float)kFcH);
-        const float d = v[i] - mean[i];
-        s[i] = fc_row16_sum(d * d);
-    }
-    if (li == 0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) red[1][wave][4 * q + i] = s[i];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        float m2 = 0.f;
-#pragma unroll
-        for (int w8 = 0; w8 < 8; ++w8) m2 += red[1][w8][4 * q + i];
-        rstd[i] = 1.0f / sqrtf(m2 * (1.0f / (float)kFcH) + kFcEps);
-    }
-}
 
 typedef r3d_fuser_chain_fwd_args FcFwd;
 
@@ -153,6 +58,7 @@ __device__ __forceinline__ void fc_fwd_fuser(const FcFwd& A, const int wg, float
     const int c = wave * 16 + li;                         // this lane's column of a 128-wide stage
     constexpr int H = kFcH;
     const int nseg_t = (A.K + 15) >> 4;                   // stage-5 tiles: 16 key/value tiles, then the segmentation head's
+    R3D_CHAIN_MARK(A.timeline, wg == 0, 0);
     const int nt5 = 16 + nseg_t;
 
     // ---- weight chunks 0, 1 and the A rows of stage 1
@@ -176,6 +82,7 @@ __device__ __forceinline__ void fc_fwd_fuser(const FcFwd& A, const int wg, float
     fc_wload(s0, A.w1 + (size_t)((4 * wave + 0) * 16) * H, H, 16, lane);             // c2: fc1 tile 0
     __syncthreads();
 
+    R3D_CHAIN_MARK(A.timeline, wg == 0, 1);
     const float* wr = wl + li * kFcWP + 4 * q;
     FcOp a;
     f32x4 acc0, acc1;
@@ -196,6 +103,7 @@ __device__ __forceinline__ void fc_fwd_fuser(const FcFwd& A, const int wg, float
         bufV[rs * kFcP1 + c] = v;
     }
     __syncthreads();
+    R3D_CHAIN_MARK(A.timeline, wg == 0, 2);
     // ---- stage 2: x1 = x0 + vsw . Wproj^T + b ; h2 = norm2(x1)
     fc_opload(a, bufV + li * kFcP1 + 4 * q);
     acc0 = zero; acc1 = zero;
@@ -220,6 +128,7 @@ __device__ __forceinline__ void fc_fwd_fuser(const FcFwd& A, const int wg, float
         if (wave == 0 && li == 0) { A.m2[row0 + r] = mean[i]; A.r2[row0 + r] = rstd[i]; }
     }
     __syncthreads();
+    R3D_CHAIN_MARK(A.timeline, wg == 0, 3);
     // ---- stage 3: u = h2 . W1^T + b1 ; f1 = GELU(u)   (4 column tiles per wave, A operand read once)
     fc_opload(a, bufH + li * kFcP1 + 4 * q);
 #pragma unroll
@@ -245,6 +154,7 @@ __device__ __forceinline__ void fc_fwd_fuser(const FcFwd& A, const int wg, float
         }
     }
     __syncthreads();
+    R3D_CHAIN_MARK(A.timeline, wg == 0, 4);
     // ---- stage 4: x3 = x1 (+ x0) + f1 . W2^T + b2 ; y = fuser.norm(x3) ; fused = mean over the token pair
     acc0 = zero; acc1 = zero;
     {
@@ -289,6 +199,7 @@ __device__ __forceinline__ void fc_fwd_fuser(const FcFwd& A, const int wg, float
     const int cseg = (has12 ? t5c - 16 : 0) * 16 + li;
     const float bsg = A.bseg[cseg < A.K ? cseg : A.K - 1];
     __builtin_amdgcn_sched_barrier(0);
+    R3D_CHAIN_MARK(A.timeline, wg == 0, 5);
     float x3[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -314,6 +225,7 @@ __device__ __forceinline__ void fc_fwd_fuser(const FcFwd& A, const int wg, float
         bufV[(8 + 2 * q + 1) * kFcP1 + c] = fu1 + pos1;
     }
     __syncthreads();
+    R3D_CHAIN_MARK(A.timeline, wg == 0, 6);
     // ---- stage 5: cakv = (fused + pos) . Wkv^T + b (output rows 8-15) ; seg = fused . Wseg^T + b (output rows 0-7)
     fc_opload(a, bufV + li * kFcP1 + 4 * q);
     const int fr = (row0 >> 1) + ((4 * q) & 7);            // frame of this lane's first output row in either half
@@ -343,6 +255,7 @@ __device__ __forceinline__ void fc_fwd_fuser(const FcFwd& A, const int wg, float
             for (int i = 0; i < 4; ++i) A.seg[(size_t)(fr + i) * A.K + cseg] = (acc0[i] + acc1[i]) + bsg;
         }
     }
+    R3D_CHAIN_MARK(A.timeline, wg == 0, 7);
     // segmentation heads with more than 128 classes would need tiles beyond wave + 16: refused by the host
 }
 
@@ -360,6 +273,7 @@ __device__ __forceinline__ void fc_fwd_query(const FcFwd& A, const int wgq, floa
     constexpr int H = kFcH;
     const int row0 = wgq * kFcRows;
     const int c = wave * 16 + li;
+    R3D_CHAIN_MARK(A.timeline, wgq == 0, 16);
     FcW s0, s1;
     fc_wload(s0, A.w_in + (size_t)(wave * 16) * H, H, 16, lane);                      // c0..c2: in_proj tiles w, w+8, w+16
     fc_wload(s1, A.w_in + (size_t)((wave + 8) * 16) * H, H, 16, lane);
@@ -398,6 +312,7 @@ __device__ __forceinline__ void fc_fwd_query(const FcFwd& A, const int wgq, floa
         for (int i = 0; i < 4; ++i)
             A.sa_qkv[(size_t)(row0 + 4 * q + i) * (3 * H) + (wave + 8 * t) * 16 + li] = (acc0[i] + acc1[i]) + b_in[t];
     }
+    R3D_CHAIN_MARK(A.timeline, wgq == 0, 17);
     __syncthreads();                                        // q / k / v rows of both clips are written (workgroup scope)
     // ---- attention core: (clip, head) units, head = wave
     {
@@ -414,8 +329,10 @@ __device__ __forceinline__ void fc_fwd_query(const FcFwd& A, const int wgq, floa
         const f32x4 so = *reinterpret_cast<const f32x4*>(A.sa_o + (size_t)(row0 + (tid >> 5)) * H + 4 * (tid & 31));
         *reinterpret_cast<f32x4*>(bufV + (tid >> 5) * kFcP1 + 4 * (tid & 31)) = so;
     }
+    R3D_CHAIN_MARK(A.timeline, wgq == 0, 18);
     fc_wstore(s1, wl, lane);                                // c3 (the attention units are done with the region)
     __syncthreads();
+    R3D_CHAIN_MARK(A.timeline, wgq == 0, 19);
     // ---- out_proj -> dropout -> (+ tgt = 0) -> norm1
     fc_opload(a, bufV + li * kFcP1 + 4 * q);
     acc0 = zero; acc1 = zero;
@@ -439,12 +356,14 @@ __device__ __forceinline__ void fc_fwd_query(const FcFwd& A, const int wgq, floa
         if (wave == 0 && li == 0) { A.m1[row0 + r] = mean[i]; A.r1[row0 + r] = rstd[i]; }
     }
     __syncthreads();
+    R3D_CHAIN_MARK(A.timeline, wgq == 0, 20);
     // ---- cross-attention query projection: caq = (t1 + query_pos) . Wq^T + b
     fc_opload(a, bufH + li * kFcP1 + 4 * q);
     acc0 = zero; acc1 = zero;
     fc_chunk(a, wr, acc0, acc1);
 #pragma unroll
     for (int i = 0; i < 4; ++i) A.caq[(size_t)(row0 + 4 * q + i) * H + c] = (acc0[i] + acc1[i]) + b_q;
+    R3D_CHAIN_MARK(A.timeline, wgq == 0, 21);
 }
 
 __global__ __launch_bounds__(512) void fuser_chain_fwd_kernel(const FcFwd A) {
@@ -462,68 +381,12 @@ __global__ __launch_bounds__(512) void fuser_chain_fwd_kernel(const FcFwd A) {
 // 128 k-rows x 16 columns, staged k-major in the wave's region (pitch 20 floats: the four k groups of an MFMA operand
 // read land on disjoint banks) and read back with 32 scalar LDS loads in the same (k group, k) register layout the NT
 // chunks use, so the MFMA sequence is shared.
-constexpr int kFbWP = 20;
 constexpr int kFbWl = kFcBufF + kFcRows * kFcP4;
 constexpr int kFbRed = kFbWl + 8 * 128 * kFbWP;
 constexpr int kFbLdsFloats = kFbRed + 2 * 2 * 8 * kFcRows;
 constexpr int kFbLdsBytes = kFbLdsFloats * 4;
 static_assert(mha_small_bwd_lds_floats(16, 8) <= 128 * kFbWP, "attention units borrow the wave's weight region");
 static_assert(kFbLdsBytes <= 160 * 1024, "LDS");
-
-// lane l of load i: 16 bytes of k-row (l >> 2) + 16 i at column 4 (l & 3); k-rows >= kvalid read row kvalid - 1 (the A
-// operand is zero there)
-__device__ __forceinline__ void fb_wload(FcW& r, const float* w, int ldw, int kvalid, int lane) {
-    const float* p = w + 4 * (lane & 3);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        int k = (lane >> 2) + 16 * i;
-        k = k < kvalid ? k : kvalid - 1;
-        r.v[i] = *reinterpret_cast<const f32x4*>(p + (size_t)k * ldw);
-    }
-}
-__device__ __forceinline__ void fb_wstore(const FcW& r, float* wl, int lane) {
-    float* p = wl + (lane >> 2) * kFbWP + 4 * (lane & 3);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(p + 16 * i * kFbWP) = r.v[i];
-}
-__device__ __forceinline__ void fb_chunk(const FcOp& a, const float* wl, int li, int q, f32x4& acc0, f32x4& acc1) {
-    FcOp b;
-    const float* p = wl + (4 * q) * kFbWP + li;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) b.v[j][t] = p[(16 * j + t) * kFbWP];
-    }
-    fc_mfma(a, b, acc0, acc1);
-}
-
-// Two simultaneous sums over the 128 columns for NR row slots per lane group (slot = NR q + i): 16 lanes by DPP, the 8
-// waves through LDS; one workgroup barrier.  red: [2][8][16] floats.
-template <int NR>
-__device__ __forceinline__ void fb_rowsum2(const float (&a)[NR], const float (&b)[NR], float* red, int wave, int li, int q,
-                                           float (&sa)[NR], float (&sb)[NR]) {
-#pragma unroll
-    for (int i = 0; i < NR; ++i) { sa[i] = fc_row16_sum(a[i]); sb[i] = fc_row16_sum(b[i]); }
-    if (li == 0) {
-#pragma unroll
-        for (int i = 0; i < NR; ++i) {
-            red[(0 * 8 + wave) * kFcRows + NR * q + i] = sa[i];
-            red[(1 * 8 + wave) * kFcRows + NR * q + i] = sb[i];
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < NR; ++i) {
-        float x = 0.f, y = 0.f;
-#pragma unroll
-        for (int w8 = 0; w8 < 8; ++w8) {
-            x += red[(0 * 8 + w8) * kFcRows + NR * q + i];
-            y += red[(1 * 8 + w8) * kFcRows + NR * q + i];
-        }
-        sa[i] = x * (1.0f / (float)kFcH);
-        sb[i] = y * (1.0f / (float)kFcH);
-    }
-}
 
 typedef r3d_fuser_chain_bwd_args FcBwd;
 
@@ -543,6 +406,7 @@ __device__ __forceinline__ void fc_bwd_fuser(const FcBwd& A, const int wg, float
     const int f0 = (row0 >> 1) + 2 * q;                    // the two frames of this lane's rows 4q .. 4q + 3
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 
+    R3D_CHAIN_MARK(A.timeline, wg == 0, 0);
     // ---- weight chunks c0, c1 and the A operand of stage 0: row r <- [d_cakv[frame r >> 1] | d_seg[frame] | 0]
     FcW s0, s1;
     fb_wload(s0, A.wkv + n0, H, 128, lane);                                          // c0: Wkv k-rows 0..127
@@ -584,6 +448,7 @@ __device__ __forceinline__ void fc_bwd_fuser(const FcBwd& A, const int wg, float
     FcOp a;
     f32x4 acc0 = zero, acc1 = zero;
     const float* ar = bufF + li * kFcP4 + 4 * q;
+    R3D_CHAIN_MARK(A.timeline, wg == 0, 1);
     // ---- stage 0: d(memory + pos) = d_cakv . Wkv  (kept: pos_embedding's gradient), then + d_seg . Wseg
     fc_opload(a, ar);
     fb_chunk(a, wl, li, q, acc0, acc1);                                               // c0
@@ -605,6 +470,7 @@ __device__ __forceinline__ void fc_bwd_fuser(const FcBwd& A, const int wg, float
     fb_wstore(s1, wl, lane);
     fb_wload(s1, A.w2 + (4 * wave + 2) * 16, 4 * H, 128, lane);                       // c5
     __builtin_amdgcn_sched_barrier(0);
+    R3D_CHAIN_MARK(A.timeline, wg == 0, 2);
     // ---- stage 1: fuser.norm backward; each token row of a pair receives half of the frame's gradient (:94)
     float dx3[4];
     {
@@ -635,6 +501,7 @@ __device__ __forceinline__ void fc_bwd_fuser(const FcBwd& A, const int wg, float
         for (int i = 0; i < 4; ++i) uv[t][i] = A.u[(size_t)(row0 + 4 * q + i) * (4 * H) + (4 * wave + t) * 16 + li];
     }
     __syncthreads();
+    R3D_CHAIN_MARK(A.timeline, wg == 0, 3);
     // ---- stage 2: d_u = (d_x3 . W2) * GELU'(u)
     fc_opload(a, bufH + li * kFcP1 + 4 * q);
 #pragma unroll
@@ -663,6 +530,7 @@ __device__ __forceinline__ void fc_bwd_fuser(const FcBwd& A, const int wg, float
     }
     const float g2 = A.g2[c];
     __syncthreads();
+    R3D_CHAIN_MARK(A.timeline, wg == 0, 4);
     // ---- stage 3: d_h2 = d_u . W1 ; norm2 backward ; d_x1 = that + d_x3 (the residual x3 = x1 + ...)
     acc0 = zero; acc1 = zero;
     fc_opload(a, ar);
@@ -726,6 +594,7 @@ __device__ __forceinline__ void fc_bwd_fuser(const FcBwd& A, const int wg, float
         mdv[j] = A.mean_d[f0 + j]; rdv[j] = A.rstd_d[f0 + j];
     }
     __syncthreads();
+    R3D_CHAIN_MARK(A.timeline, wg == 0, 5);
     // ---- stage 4: d_vsw = d_x1 . Wproj, un-swapped into d_v (gradient of the V projection's output rows)
     fc_opload(a, bufV + li * kFcP1 + 4 * q);
     acc0 = zero; acc1 = zero;
@@ -741,6 +610,7 @@ __device__ __forceinline__ void fc_bwd_fuser(const FcBwd& A, const int wg, float
         bufH[rs * kFcP1 + c] = v;
     }
     __syncthreads();
+    R3D_CHAIN_MARK(A.timeline, wg == 0, 6);
     // ---- stage 5: d_h1 = d_v . Wv ; norm1 backward + both residual gradients ; embd_drop ; exchange ; depth LN + ReLU
     fc_opload(a, bufH + li * kFcP1 + 4 * q);
     acc0 = zero; acc1 = zero;
@@ -788,6 +658,7 @@ __device__ __forceinline__ void fc_bwd_fuser(const FcBwd& A, const int wg, float
         for (int j = 0; j < 2; ++j)
             A.d_dep_pre[(size_t)(f0 + j) * H + c] = rdv[j] * (g[j] - s1v[j] - xh[j] * s2v[j]);
     }
+    R3D_CHAIN_MARK(A.timeline, wg == 0, 7);
 }
 
 // query role: backward of the layer-0 query self-attention sub-layer and the cross-attention's query projection.  With

@@ -211,6 +211,10 @@ class FusionEngine:
         # attn.proj, norm2, MLP, fuser.norm, pair mean, segmentation head, key/value projection) and the layer-0 query
         # self-attention sub-layer as ONE launch per direction (csrc/fuser_chain.hip) instead of 5 + 8
         self.use_fuser_chain = True
+        # ... and the decoder layer's query side (cross-attention core, out_proj + norm2, FFN; in the training step also the
+        # tail, the losses and the way back to the cross-attention's input gradients) as ONE launch (csrc/decoder_chain.hip)
+        # instead of 4 + 1 + 5
+        self.use_decoder_chain = True
         # fused training flows (forward -> losses(tick=True) -> backward -> adamw(ticked=True)) may set this: the loss
         # kernel then leaves the reduction of its per-unit partials (loss / counter statistics only the host reads) to
         # one extra workgroup of the AdamW launch -- w.loss / w.counts are valid after adamw(), not after losses()
@@ -510,6 +514,7 @@ class FusionEngine:
         else:
             ops.gemm(GEMM_NT, w.fused, a.p("fc_seg.weight"), w.seg, bias=a.p("fc_seg.bias"), ws=self.ws)
         # ---- decoder (transformer.py:75-128,161-191,281-330); memory = fused, encoder bypassed (:77-78)
+        self.last_drop_flag = bool(drop)
         if fused_dec:
             self._decoder_fused(w, key_labels, drop, dsc)
         else:
@@ -597,6 +602,30 @@ class FusionEngine:
 
     def _chain_ok(self, w):
         return bool(self.use_fuser_chain and self._chain_shape_ok(w))
+
+    def _dec_chain_ok(self, w):
+        return bool(self.use_decoder_chain and self.L == 1 and self.dh == 16 and w.BQ <= 1024 and
+                    ops.decoder_chain_supported(self.H, self.Q, self.heads, w.S))
+
+    def _dec_chain(self, w, drop):
+        """The argument block of the decoder chain kernel for this workspace (one per dropout state)."""
+        key = ("dec_chain", bool(drop))
+        if key not in w.tables:
+            a, H = self.arena, self.H
+            c, pl = w.layers[0], "transformer.decoder.layers.0."
+            dk = (lambda k: w.drop[k]) if drop else (lambda k: None)
+            gl = w.glayers[0] if hasattr(w, "glayers") else None
+            g = (lambda k: gl[k]) if gl is not None else (lambda k: None)
+            w.tables[key] = ops.DecoderChain(
+                caq=c["caq"], cakv=c["cakv"], p_ca=c["p_ca"], drop_ca=dk("ca_p0"), ca_o=c["ca_o"],
+                wo=a.p(pl + "multihead_attn.out_proj.weight"), bo=a.p(pl + "multihead_attn.out_proj.bias"), drop_d2=dk("d2_0"),
+                t1=c["t1"], t2_pre=c["t2_pre"], g2=a.p(pl + "norm2.weight"), be2=a.p(pl + "norm2.bias"), t2=c["t2"], m2=c["m2"],
+                r2=c["r2"], w1=a.p(pl + "linear1.weight"), b1=a.p(pl + "linear1.bias"), drop_ff=dk("ff_0"), ff1=c["ff1"],
+                w2=a.p(pl + "linear2.weight"), b2=a.p(pl + "linear2.bias"), drop_d3=dk("d3_0"), t3_pre=c["t3_pre"],
+                d_t3pre=g("t3pre"), d_ff2=g("ff2"), d_ff1=g("ff1"), d_t2pre=g("t2pre"), d_cap=g("cap"), d_cao=g("cao"),
+                d_caq=g("caq"), d_cakv=g("cakv"), part_d2=w.lnp["d2_0"] if gl is not None else None,
+                drop_scale=1.0 / (1.0 - DROP_P), pad_idx=self.pad_idx, B=w.B, S=w.S, H=H, Q=self.Q, heads=self.heads)
+        return w.tables[key]
 
     def _gln(self, rows, K):
         return self.use_gemm_ln and ops.gemm_ln_supported(rows, K, self.H)
@@ -700,6 +729,28 @@ class FusionEngine:
             else:
                 sa_block(l, tgt, self.ws)
             # (paired: the layer-0 sub-layer ran inside _forward_paired)
+            w._dec_deferred = False
+            if paired and self._dec_chain_ok(w):
+                # cross-attention core -> out_proj + norm2 -> FFN -> t3_pre: one launch (csrc/decoder_chain.hip) -- or none
+                # here at all: in a training step (defer_tail) the launch inside losses() runs this forward half, the tail,
+                # the losses and the backward half together
+                drop_now = self.last_drop_flag
+                w._tail_done = False
+                w._tail_deferred = bool(self.use_fused_tail and self.defer_tail and self._fw["mode"] == "train" and
+                                        hasattr(w, "glayers") and ops.tail_losses_supported(H, self.K + 1, Q, BQ))
+                w._dec_key_labels = key_labels
+                if w._tail_deferred:
+                    w._dec_deferred = True
+                    return
+                self._dec_chain(w, drop_now).launch(1, key_label=key_labels)
+                if self.use_fused_tail:
+                    ops.decoder_tail_fwd(c["t3_pre"], a.p(pl + "norm3.weight"), a.p(pl + "norm3.bias"),
+                                         a.p("transformer.decoder.norm.weight"), a.p("transformer.decoder.norm.bias"),
+                                         self.w_head, self.b_head, c["t3"], c["m3"], c["r3"], w.tgtF, w.mF, w.rF, w.actdur)
+                    return
+                ops.layernorm_fwd(c["t3_pre"], a.p(pl + "norm3.weight"), a.p(pl + "norm3.bias"), c["t3"], c["m3"], c["r3"])
+                tgt = c["t3"]
+                continue
             ops.mha_core_fwd(c["caq"], c["cakv"][:, :H], c["cakv"][:, H:], c["p_ca"], c["ca_o"], B, heads, Q, S, dh,
                              key_labels=key_labels, pad_idx=self.pad_idx, drop_mask=dm(f"ca_p{l}"), drop_scale=dsc)
             if self._gln(BQ, H):      # out_proj -> dropout -> + tgt -> norm2 (transformer.py:304-306): one launch
@@ -789,8 +840,16 @@ class FusionEngine:
                         gF=a.p("transformer.decoder.norm.weight"), bF=a.p("transformer.decoder.norm.bias"),
                         w_head=self.w_head, b_head=self.b_head, t3=c["t3"], m3=c["m3"], r3=c["r3"], tgtF=w.tgtF, mF=w.mF,
                         rF=w.rF, out=w.actdur)
+            dec = None
+            if getattr(w, "_dec_deferred", False):
+                w._dec_deferred = False
+                dec = self._dec_chain(w, self.last["drop"])
+                if not (with_grad and not val_mode):         # (no gradient wanted: only the forward half is due)
+                    dec.launch(1, key_label=w._dec_key_labels)
+                    dec = None
             if with_grad and not val_mode:
-                # forward tail + losses + backward tail: one launch (losses.hip: tail_losses_kernel)
+                # forward tail + losses + backward tail: one launch (losses.hip: tail_losses_kernel) -- with `dec` the
+                # decoder's whole query side around it as well (decoder_chain.hip, phases 7)
                 drop = self.last["drop"]
                 defer = bool(self.defer_loss_reduce and tick)
                 ops.decoder_tail_losses(**tail, seg=w.seg, past_label=past_label, target=target, target_dur=target_dur,
@@ -799,8 +858,10 @@ class FusionEngine:
                                         counts=w.counts, tick_a=ta, tick_b=tb,
                                         drop=w.drop[f"d3_{Lm}"] if drop else None, drop_scale=1.0 / (1.0 - DROP_P),
                                         dx=w.glayers[Lm]["t3pre"], dx2=w.glayers[Lm]["ff2"], wsF=w.lnp["final"],
-                                        ws3=w.lnp[f"d3_{Lm}"], ws=w.loss_ws, defer_finalize=defer)
+                                        ws3=w.lnp[f"d3_{Lm}"], ws=w.loss_ws, defer_finalize=defer, chain=dec,
+                                        chain_key_label=w._dec_key_labels if dec is not None else None)
                 w._tail_done = True
+                w._dec_bwd_done = dec is not None
                 acc = self.loss_acc if self.loss_acc is not None else (None, None)
                 self._loss_pending = ops.loss_finalize_job(w.loss_ws, w.B, w.S, self.Q, True, self.dur_den, w.loss, w.counts,
                                                            acc_loss=acc[0], acc_counts=acc[1]) if defer else None
@@ -1045,13 +1106,21 @@ class FusionEngine:
                    "transformer.decoder.norm.bias", w.d_t)
         dy, dy2 = w.d_t, None                 # gradient w.r.t. t3 of the current layer (= dy + dy2)
         first_fused = True
+        dec_done = bool(getattr(w, "_dec_bwd_done", False)) and not ext_grads     # losses() ran the decoder's backward half
+        w._dec_bwd_done = False
+        dec_chain = bool(paired and self._dec_chain_ok(w))
         for l in reversed(range(self.L)):
             c, gl, pl = w.layers[l], w.glayers[l], f"transformer.decoder.layers.{l}."
             p = lambda n: a.p(pl + n)         # noqa: E731
+            if dec_done:
+                break
             # norm3 -> (t2 residual, FFN)
             if not (tail and l == self.L - 1):
                 ln_bwd(f"d3_{l}", dy, c["t3_pre"], c["m3"], c["r3"], pl + "norm3.weight", pl + "norm3.bias", gl["t3pre"],
                        dy2=dy2, dx2=gl["ff2"], drop_mask=dm(f"d3_{l}", BQ, H), drop_scale=dsc)
+            if dec_chain:                      # FFN / norm2 / out_proj input gradients + attention core backward: one launch
+                self._dec_chain(w, drop).launch(4)
+                break
             ops.gemm(GEMM_NN, gl["ff2"], p("linear2.weight"), gl["ff1"], drop_mask=dm(f"ff_{l}", BQ, 4 * H),
                      drop_scale=dsc, aux=c["ff1"], mul=1, ws=ws)
             split = self.split_k4h and H < 256 and H % 4 == 0

@@ -391,6 +391,44 @@ class FuserChainBwd:
         check(_lib.load().r3d_fuser_chain_bwd(C.byref(self.args), _stream()), "r3d_fuser_chain_bwd")
 
 
+def decoder_chain_supported(H, Q, heads, S):
+    return bool(_lib.load().r3d_decoder_chain_supported(H, Q, heads, S))
+
+
+class DecoderChain:
+    """The argument block of r3d_decoder_chain (csrc/decoder_chain.hip), built once per workspace; key_label is re-pointed
+    per call (the step's label tensor)."""
+
+    def __init__(self, **t):
+        from ._lib import DecoderChainArgs
+        a = DecoderChainArgs()
+        dims = {k: t.pop(k) for k in ("pad_idx", "B", "S", "H", "Q", "heads")}
+        a.drop_scale = float(t.pop("drop_scale", 1.0))
+        opt = {"key_label", "drop_ca", "drop_d2", "drop_ff", "drop_d3", "d_t3pre", "d_ff2", "d_ff1", "d_t2pre", "d_cap", "d_cao",
+               "d_caq", "d_cakv", "part_d2"}
+        for name in DecoderChainArgs._PTRS:
+            v = t.pop(name, None)
+            if v is None:
+                assert name in opt, name
+                continue
+            assert v.is_cuda and v.is_contiguous(), name
+            want = torch.uint8 if name.startswith("drop_") else (torch.int64 if name == "key_label" else torch.float32)
+            assert v.dtype == want, name
+            setattr(a, name, v.data_ptr())
+        assert not t, t.keys()
+        for k, v in dims.items():
+            setattr(a, k, int(v))
+        self.args = a
+
+    def launch(self, phases, key_label=None, tail=None, ws=None):
+        """tail: a filled TailLossesArgs (phases & 2), ws: the loss scratch."""
+        a = self.args
+        a.phases = int(phases)
+        a.key_label = None if key_label is None else key_label.data_ptr()
+        check(_lib.load().r3d_decoder_chain(C.byref(a), C.byref(tail) if tail is not None else None, _p(ws), _stream()),
+              "r3d_decoder_chain")
+
+
 def layernorm_bwd_multi(jobs, mha=None):
     """jobs: up to 4 dicts with the arguments of layernorm_bwd (dy, x, mean, rstd, gamma, beta, dx, dgamma, dbeta,
     partial required; pair_in, relu, dy2, add1, add2, dx2, drop_mask, drop_scale optional).
@@ -647,7 +685,8 @@ def tail_losses_supported(H, n_head, Q, rows):
 
 def decoder_tail_losses(*, x, g3, b3, gF, bF, w_head, b_head, t3, m3, r3, tgtF, mF, rF, out, seg, past_label, target,
                         target_dur, B, S, Q, K, pad_idx, exclude_idx, dur_den, grad_scale, d_seg, d_out, loss_out, counts,
-                        tick_a, tick_b, drop, drop_scale, dx, dx2, wsF, ws3, ws, defer_finalize=False):
+                        tick_a, tick_b, drop, drop_scale, dx, dx2, wsF, ws3, ws, defer_finalize=False, chain=None,
+                        chain_key_label=None):
     """r3d_decoder_tail_fwd + r3d_losses_fwd_bwd + r3d_decoder_tail_bwd in one launch (training step).
     defer_finalize: leave the reduction of the loss partials (ws) to losses_finalize() / adamw_flat_dropout(loss_fin=...)."""
     from ._lib import TailLossesArgs
@@ -669,6 +708,9 @@ def decoder_tail_losses(*, x, g3, b3, gF, bF, w_head, b_head, t3, m3, r3, tgtF, 
     a.B, a.S, a.Q, a.K, a.pad_idx, a.exclude_idx = B, S, Q, K, pad_idx, exclude_idx
     a.grad_scale, a.drop_scale = grad_scale, drop_scale
     a.defer_finalize = 1 if defer_finalize else 0
+    if chain is not None:              # the whole query side of the decoder layer around the tail: one launch
+        chain.launch(7, key_label=chain_key_label, tail=a, ws=ws)
+        return
     check(_lib.load().r3d_decoder_tail_losses(C.byref(a), _p(ws), _stream()), "r3d_decoder_tail_losses")
 
 

@@ -226,7 +226,8 @@ class _ShardedSteps:
         self.rs.stage(x2d, buf[3], self.pad_idx, s)
 
     def _fill(self, st, s, batch, token):
-        """(current stream) batch -> slot s buffers (host-to-device or device-to-device), then its staging."""
+        """(current stream = the side stream) batch -> slot s buffers (host-to-device or device-to-device), then its staging."""
+        assert torch.cuda.current_stream() == self.side
         for dst, src in zip(st["buf"][s], batch):
             dst.copy_(src, non_blocking=True)
         if self.use_graphs and st["S"][s] is None and st["staged"][s] is not None:
@@ -252,10 +253,15 @@ class _ShardedSteps:
         ev_pre.record(main)                                 # everything the caller produced so far (device-resident batches)
         eng.set_lr(lr)
         if st["staged"][s] != cur_token:                    # not pre-staged: first batch of an epoch / of this shape
+            # (ragged loaders -- pad_sequence pads to the batch's longest clip -- come here whenever the shape changes.)
+            # Staged on the SIDE stream like every look-ahead: the staging may be captured on this visit, and a hipGraph
+            # cannot be captured on the default stream, where train() runs
             self.ev_step[(self.t - 1) % 4].synchronize()    # (the step that last read this slot is long done; be safe)
-            self._fill(st, s, cur, cur_token)
-        else:
-            main.wait_event(st["ev_side"][s])
+            self.side.wait_event(ev_pre)
+            with torch.cuda.stream(self.side):
+                self._fill(st, s, cur, cur_token)
+                st["ev_side"][s].record(self.side)
+        main.wait_event(st["ev_side"][s])
         buf = st["buf"][s]
 
         def run():

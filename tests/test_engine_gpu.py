@@ -318,6 +318,44 @@ def test_fuser_chain_kernel_equals_composed_launches(tag, training):
         close_rel(res[1]["grads"][o:o + k], res[0]["grads"][o:o + k], f"{tag}/chain grad {n}", rtol=5e-4)
 
 
+@pytest.mark.parametrize("tag,training,defer", [("step_cfg2", False, False), ("step_cfg2", True, False), ("step_cfg2", True, True),
+                                                 ("step_cfg2_zm", False, True)])
+def test_decoder_chain_kernel_equals_composed_launches(tag, training, defer):
+    """csrc/decoder_chain.hip (the decoder layer's query side: cross-attention core, out_proj + norm2, FFN -- and with
+    defer_tail the tail, the losses and the backward half in the same launch) against the launches it replaces: stored
+    activations, outputs, losses, input gradients and every parameter gradient (identical dropout masks when training)."""
+    fx = load_fixture(tag)
+    model = build_model(fx)
+    model.train(training)
+    eng = model.engine()
+    d = [t.cuda() for t in fixture_batch(fx)]
+    res = []
+    lnames = ("p_ca", "ca_o", "t2_pre", "t2", "m2", "r2", "ff1", "t3_pre", "t3", "m3", "r3")
+    gnames = ("t3pre", "ff2", "ff1", "t2pre", "cap", "cao", "caq", "cakv")
+    for chain in (False, True):
+        eng.use_decoder_chain = chain
+        eng.defer_tail = defer and chain
+        eng.forward(d[0], d[1], d[2], "train", training=training)          # same drop_offset -> same masks
+        w = eng.last["w"]
+        assert bool(getattr(w, "_dec_deferred", False)) == (defer and chain)
+        eng.losses(d[2], d[4], d[3])
+        eng.backward()
+        torch.cuda.synchronize()
+        acts = {k: w.layers[0][k].clone() for k in lnames}
+        acts.update({"g_" + k: w.glayers[0][k].clone() for k in gnames})
+        acts.update(actdur=w.actdur.clone(), tgtF=w.tgtF.clone(), d_seg=w.d_seg.clone(), d_actdur=w.d_actdur.clone())
+        res.append(dict(acts=acts, grads=eng.arena.grads.clone(), loss=w.loss.clone(), counts=w.counts.clone()))
+    eng.defer_tail = False
+    for k in res[0]["acts"]:
+        close_rel(res[1]["acts"][k], res[0]["acts"][k], f"{tag}/decoder chain {k}", rtol=5e-5)
+    close_rel(res[1]["loss"], res[0]["loss"], "loss", rtol=1e-5)
+    assert torch.equal(res[1]["counts"], res[0]["counts"])
+    a = eng.arena
+    for n in a.live_names:
+        o, k, _ = a.offsets[n]
+        close_rel(res[1]["grads"][o:o + k], res[0]["grads"][o:o + k], f"{tag}/decoder chain grad {n}", rtol=5e-4)
+
+
 def test_adamw_in_weight_gradient_epilogue_equals_flat_adamw():
     """backward(fused_adamw=...) updates depth_projection.weight inside its weight-gradient GEMM; parameters and both
     moments must match the flat AdamW launch on the stored gradient up to the well-conditioned criterion (a rounding
@@ -354,7 +392,9 @@ def test_adamw_in_weight_gradient_epilogue_equals_flat_adamw():
                                    dict(use_fused_tail=False, use_paired_launches=False, use_fused_embed=False),
                                    dict(use_side_stream=True), dict(use_fused_decoder=True), dict(use_gemm_ln=False),
                                    dict(use_gemm_ln=False, use_paired_launches=False), dict(fold_rowsums=False), dict(ride_attention=False),
-                                   dict(ride_attention_bwd=True), dict(split_k4h=True), dict(use_fuser_chain=False)])
+                                   dict(ride_attention_bwd=True), dict(split_k4h=True), dict(use_fuser_chain=False),
+                                   dict(use_decoder_chain=False), dict(use_decoder_chain=False, use_fuser_chain=False),
+                                   dict(use_decoder_chain=True, use_fused_tail=False)])
 @pytest.mark.parametrize("tag,training", [("step_cfg2", True), ("step_k122_dec2", False)])
 def test_launch_fusion_paths_agree(tag, training, flags):
     """Every launch-fusion switch of the engine (decoder tail kernel, paired GEMM launches, embedding seam, side stream,

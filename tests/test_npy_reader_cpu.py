@@ -22,8 +22,15 @@ def _files(tmp_path, n_videos=3, D=16, hw=(6, 8)):
 
 
 def _reference_collate(files, clips):
-    feats = [torch.tensor(np.load(c[0])[c[2]:c[3]][::c[4]], dtype=torch.float32) for c in clips]
-    depth = [torch.tensor(np.load(c[1])[c[2]:c[3]][::c[4]], dtype=torch.float32) for c in clips]
+    """np.load -> [depth: trim to the recording's frame range, basedataset_darai_depth.py:112-114] -> observed slice ->
+    sample rate -> torch.tensor -> pad_sequence per tensor (:118-130,176,199-203)."""
+    feats, depth = [], []
+    for c in clips:
+        f, d = np.load(c[0]), np.load(c[1])
+        if len(c) > 5:
+            d = d[c[5]:(c[6] if len(c) > 6 else None)]
+        feats.append(torch.tensor(f[c[2]:c[3]][::c[4]], dtype=torch.float32))
+        depth.append(torch.tensor(d[c[2]:c[3]][::c[4]], dtype=torch.float32))
     pad = torch.nn.utils.rnn.pad_sequence
     return pad(feats, batch_first=True, padding_value=0), pad(depth, batch_first=True, padding_value=0)
 
@@ -54,3 +61,28 @@ def test_npy_empty_and_out_of_range_clips(tmp_path):
     f, d = rd.batch([(files[0][0], files[0][1], T - 2, T + 50, 1), (files[0][0], files[0][1], 4, 4, 1)])
     assert f.shape[:2] == (2, 2) and torch.equal(f[0], torch.from_numpy(files[0][2][T - 2:]))
     assert float(f[1].abs().sum()) == 0.0 and float(d[1].abs().sum()) == 0.0
+
+
+def test_npy_depth_trim_and_short_depth_file(tmp_path):
+    """The reference trims the per-recording depth file to the sequence's frame range before the observed slice
+    (basedataset_darai_depth.py:112-114) and pads features and depth independently (:199-203): a depth offset, and a depth
+    file that ends before the slice does (features 30 frames, depth 18, clip 10:26:2 -> 8 feature rows, 4 depth rows)."""
+    rng = np.random.default_rng(9)
+    f = rng.standard_normal((30, 16)).astype(np.float32)
+    d_long = rng.random((60, 1, 6, 8)).astype(np.float32)
+    d_short = rng.random((18, 1, 6, 8)).astype(np.float32)
+    for name, arr in (("f", f), ("dl", d_long), ("ds", d_short)):
+        np.save(tmp_path / f"{name}.npy", arr)
+    fp, dl, ds = (str(tmp_path / f"{n}.npy") for n in ("f", "dl", "ds"))
+    rd = NpyClipReader(pin=False, workers=0)
+    clips = [(fp, dl, 0, 20, 2, 25, 56), (fp, dl, 3, 12, 1, 7), (fp, ds, 10, 26, 2)]
+    got_f, got_d = rd.batch(clips)
+    ref_f, ref_d = _reference_collate(None, clips)
+    assert got_f.shape == ref_f.shape and got_d.shape == ref_d.shape
+    assert torch.equal(got_f, ref_f) and torch.equal(got_d, ref_d)
+    assert got_f.shape[1] == 10 and got_d.shape[1] == 10
+    only = [clips[2]]
+    got_f, got_d = rd.batch(only)
+    ref_f, ref_d = _reference_collate(None, only)
+    assert got_f.shape[1] == 8 and got_d.shape[1] == 4
+    assert torch.equal(got_f, ref_f) and torch.equal(got_d, ref_d)

@@ -470,7 +470,7 @@ def test_train_loop_pixel_shard_lookahead_equals_eager_two_ranks():
         assert status == "ok", f"rank {rank}: {info}"
 
 
-def _train_sharded_graph_worker(port, q):
+def _train_sharded_graph_worker(port, q, case="equal"):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
         torch.cuda.set_device(0)
@@ -482,6 +482,12 @@ def _train_sharded_graph_worker(port, q):
         fx = load_fixture("step_tiny")
         m = fx["meta"]
         batches = [fixture_batch(fx, seed=300 + 10 * s) for s in range(6)]
+        epochs = 2
+        if case == "ragged":                  # pad_sequence pads to the batch's longest clip: shapes alternate S, S - 1
+            batches = [b if i % 2 == 0 else [b[0][:, :-1].contiguous(), b[1][:, :-1].contiguous(), b[2][:, :-1].contiguous(),
+                                              b[3], b[4]] for i, b in enumerate(batches)]
+        elif case == "short_epochs":          # two batches per epoch: the first batch of every epoch is never pre-staged
+            batches, epochs = batches[:2], 4
         val = [[t[:1] for t in fixture_batch(fx, seed=999)]]
         finals = []
         for rehearse in (False, True):
@@ -489,7 +495,7 @@ def _train_sharded_graph_worker(port, q):
                 dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
                 os.environ["R3D_REHEARSE_DIST"] = "1"
             model = _model(fx)
-            args = argparse.Namespace(epochs=2, input_type="i3d_transcript", seg=True, anticipate=True, task="long",
+            args = argparse.Namespace(epochs=epochs, input_type="i3d_transcript", seg=True, anticipate=True, task="long",
                                       min_batch=1, graph_steps=True, pixel_shard=rehearse)
 
             class NoSched:
@@ -518,12 +524,15 @@ def _train_sharded_graph_worker(port, q):
             dist.destroy_process_group()
 
 
-def test_train_loop_pixel_shard_graphed_one_rank_equals_single_gpu():
+@pytest.mark.parametrize("case", ["equal", "ragged", "short_epochs"])
+def test_train_loop_pixel_shard_graphed_one_rank_equals_single_gpu(case):
     """train(--pixel_shard) on the sharded one-graph RcclStep (step graphs + staging graphs, two slots, look-ahead),
-    rehearsed with a one-rank RCCL communicator, ends with the parameters of the plain one-GPU loop."""
+    rehearsed with a one-rank RCCL communicator, ends with the parameters of the plain one-GPU loop -- with equal batch
+    shapes, with shapes that alternate (a ragged loader: un-staged batches whose staging is captured on the spot) and with
+    two-batch epochs (the first batch of every epoch is never pre-staged)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=_train_sharded_graph_worker, args=(_free_port(), q))
+    p = ctx.Process(target=_train_sharded_graph_worker, args=(_free_port(), q, case))
     p.start()
     rank, status, info = q.get(timeout=600)
     p.join(timeout=60)
