@@ -24,6 +24,9 @@ CFG = dict(B=8, S=16, H=128, K=17, D=2048, P=224 * 224, Q=8, heads=8, n_dec=1, n
 # BASELINE.json's other configurations at their per-GPU shapes: parity-test cases (tests/test_engine_gpu.py), selectable
 # here with --config for profiling only -- the headline line is always cfg2
 OTHER = dict(cfg3=dict(S=32), cfg4=dict(S=64, H=512), cfg5=dict(S=16, H=1024))
+# algorithmic work of ONE per-GPU step ("Totals"): bytes and FLOPs
+STEP_WORK = dict(cfg2=dict(bytes=346e6, flops=3.95e9), cfg3=dict(bytes=407e6, flops=7.84e9),
+                 cfg4=dict(bytes=1.88e9, flops=84.1e9))
 NAMES = dict(cfg2="DARai RGB+Depth futr_safuser_tokenfusion, batch=8 per GPU, 16-frame clips, hidden=128, n_class=17, "
                   "depth 224x224 (BASELINE.json configs[1])")
 
@@ -78,26 +81,41 @@ def time_kernel(fn, iters=20, warm=5, reps=5):
 
 
 def kernel_rooflines(eng, c):
-    """Live HIP-event timing of the three heavy kernels with the step's real operands (after the timed region)."""
+    """Live HIP-event timing of the three heavy kernels with the step's real operands (after the timed region).  The labels
+    name the kernels that run in the step (rocprofv3 names in profiles/r03_*_kernel_stats.csv)."""
     from r3d_amd import ops
     from r3d_amd._lib import GEMM_NT, GEMM_TN
+    from r3d_amd.engine import DROP_P
     st, a, w = eng.last, eng.arena, eng.last["w"]
     N, H, P = c["B"] * c["S"], c["H"], c["P"]
+    bf3 = eng.depth_prec == 1
     out = {}
     t = time_kernel(lambda: ops.gemm(GEMM_TN, w.d_dep_pre, st["x_dep"], a.g("depth_projection.weight"), ws=eng.ws,
                                      prec=eng.depth_prec))
-    out["depth_projection_wgrad (gemm_f32 TN)"] = dict(seconds=t, flops=2.0 * N * P * H, bytes=4.0 * (N * P + N * H + H * P))
+    out["depth_projection_wgrad (" + ("wgrad_panel_bf3_kernel / gemm_bf3_tn_kernel: bf16x3 split, fp32 accumulate"
+                                      if bf3 else "gemm_f32 TN") + ")"] = dict(
+        seconds=t, flops=2.0 * N * P * H, bytes=4.0 * (N * P + N * H + H * P))
 
     def fwd():
         d = ops.gemm(GEMM_NT, st["x_dep"], a.p("depth_projection.weight"), w.dep_pre, ws=eng.ws, defer_reduce=True,
                      prec=eng.depth_prec)
         return d
     t = time_kernel(fwd)
-    out["depth_projection_fwd (gemm_f32 NT split-K)"] = dict(seconds=t, flops=2.0 * N * P * H, bytes=4.0 * (N * P + H * P + N * H))
+    out["depth_projection_fwd (" + ("gemm_bf3_nt_kernel split-K: bf16x3 split, fp32 accumulate" if bf3
+                                    else "gemm_f32 NT split-K") + ")"] = dict(
+        seconds=t, flops=2.0 * N * P * H, bytes=4.0 * (N * P + H * P + N * H))
     lr_t, step_t = eng.lr_t, eng.step_t
     scratch = [a.params[:a.n_live].clone(), a.exp_avg.clone(), a.exp_avg_sq.clone()]
-    t = time_kernel(lambda: ops.adamw_flat(scratch[0], a.grads, scratch[1], scratch[2], lr_t, step_t, weight_decay=c["wd"]))
-    out["adamw_flat"] = dict(seconds=t, flops=0.0, bytes=28.0 * a.n_live)
+    if st["drop"]:
+        # the variant the training step runs: AdamW + the next step's dropout masks in one launch
+        pool, off = w.drop_pool.clone(), eng.drop_offset.clone()
+        t = time_kernel(lambda: ops.adamw_flat_dropout(scratch[0], a.grads, scratch[1], scratch[2], lr_t, step_t, pool, DROP_P,
+                                                       eng.drop_seed, off, weight_decay=c["wd"]))
+        label = "adamw (adamw_dropout kernel: AdamW over the flat arenas + the next step's dropout masks)"
+    else:
+        t = time_kernel(lambda: ops.adamw_flat(scratch[0], a.grads, scratch[1], scratch[2], lr_t, step_t, weight_decay=c["wd"]))
+        label = "adamw (adamw_kernel over the flat arenas)"
+    out[label] = dict(seconds=t, flops=0.0, bytes=28.0 * a.n_live)
     return out
 
 
@@ -145,55 +163,64 @@ def erank_field(eng):
                      "erank_weight = 0 (the reference's loss, SURVEY.md F1)")
 
 
+PMC_TABLE = os.path.join("profiles", "r03_pmc_hbm.json")
+
+
 def pmc_traffic(kernel_label):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE
-    in separate runs, gfx950 correction applied: tools/pmc_summary.py -> profiles/r01_pmc_hbm.json).  A profiler cannot
-    run inside the timed process, so this is the figure of the committed profile of the same command, or None."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_hbm.json")
-    key = {"adamw_flat": "adamw_kernel", "depth_projection_wgrad (gemm_f32 TN)": "wgrad_panel_kernel",
-           "depth_projection_fwd (gemm_f32 NT split-K)": "gemm_f32_kernel<0, 0, 64, 64, 64, 2, 2, 2, true>"}.get(kernel_label)
+    in separate runs, gfx950 correction applied: tools/pmc_summary.py -> profiles/r03_pmc_hbm.json).  A profiler cannot
+    run inside the timed process, so this is the figure of the committed profile of the same command (the line says so in
+    roofline.traffic_source), or None."""
+    path = os.path.join(ROOT, PMC_TABLE)
+    key = "adamw" if kernel_label.startswith("adamw") else ("wgrad_panel_bf3" if "wgrad" in kernel_label else "gemm_bf3_nt")
     try:
         tab = json.load(open(path))
     except OSError:
         return None
     for k, v in tab.items():
-        if key and key in k:
+        if key in k:
             return v["hbm_bytes"]
     return None
 
 
-def cpu_baseline(c, budget_s=15.0):
-    """The oracle (CPU restatement, 'port') timed on this box's host cores on a bounded sample of the same workload."""
+def cpu_baseline(c, budget_s=8.0):
+    """The oracle (CPU restatement, 'port') timed on this box's host cores on a bounded sample of the same workload, at 16
+    threads (one GPU's share of the host), 64 and every core available to the process; the best is `value`, all are stated."""
     from oracle import futr_oracle as O, synth
-    # a 1-GPU box shares its host: 16 cores is this rank's CPU share (more threads only add contention)
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = max(1, min(16, avail))
-    torch.set_num_threads(cores)
-    # parameters: same architecture, random init (values do not matter for timing)
     import argparse as ap
     from r3d_amd.model.futr_safuser_tokenfusion import FUTR
     args = ap.Namespace(input_dim=c["D"], seg=True, anticipate=True, max_pos_len=2000, input_type="i3d_transcript")
     m = FUTR(c["K"], c["H"], c["K"] + 1, torch.device("cpu"), args, n_query=c["Q"], n_head=c["heads"],
              num_encoder_layers=c["n_enc"], num_decoder_layers=c["n_dec"])
     params = {n: p.detach().clone() for n, p in m.named_parameters()}
-    tr = O.CpuTrainer(params, c["K"] + 1, c["heads"], c["n_dec"], c["lr"], c["wd"])
     batch = [torch.from_numpy(x) for x in synth.make_batch(c["B"], c["S"], c["K"], c["K"] + 1, 1)]
-    tr.step(batch)                                                    # warm-up
-    t0, n = time.perf_counter(), 0
-    while True:
-        tr.step(batch)
-        n += 1
-        if time.perf_counter() - t0 > budget_s or n >= 400:
-            break
-    dt = time.perf_counter() - t0
-    return dict(value=c["B"] * n / dt, unit="clips/s", cores=cores, kind="port", host_cores=os.cpu_count(),
-                host_cores_available=avail,
-                sample=f"{n} full CPU training steps (fwd+3 losses+autograd bwd+AdamW) of the same B={c['B']},S={c['S']},"
-                       f"H={c['H']} workload in {dt:.1f}s, torch {torch.__version__} CPU, {cores} threads "
-                       f"(box: {os.cpu_count()} cores, {avail} available to this process)")
+    runs = []
+    for cores in sorted({max(1, min(16, avail)), max(1, min(64, avail)), avail}):
+        torch.set_num_threads(cores)
+        tr = O.CpuTrainer({k: v.clone() for k, v in params.items()}, c["K"] + 1, c["heads"], c["n_dec"], c["lr"], c["wd"])
+        tr.step(batch)                                                    # warm-up
+        t0, n = time.perf_counter(), 0
+        while True:
+            tr.step(batch)
+            n += 1
+            if time.perf_counter() - t0 > budget_s or n >= 400:
+                break
+        dt = time.perf_counter() - t0
+        runs.append(dict(cores=cores, value=c["B"] * n / dt, steps=n, seconds=dt))
+    best = max(runs, key=lambda r: r["value"])
+    return dict(value=best["value"], unit="clips/s", cores=best["cores"], kind="port", host_cores=os.cpu_count(),
+                host_cores_available=avail, by_threads={str(r["cores"]): r["value"] for r in runs},
+                sample="; ".join(f"{r['steps']} full CPU training steps (fwd+3 losses+autograd bwd+AdamW) of the same "
+                                 f"B={c['B']},S={c['S']},H={c['H']} workload in {r['seconds']:.1f}s on {r['cores']} threads"
+                                 for r in runs) + f"; torch {torch.__version__} CPU; box: {os.cpu_count()} cores, {avail} "
+                                                  f"available to this process")
+
+
+PROBE = dict(ran=False, rc=None)
 
 
 def rccl_probe_child(a, timeout_s=300):
@@ -218,14 +245,17 @@ def rccl_probe_child(a, timeout_s=300):
     except OSError as e:
         print(f"[bench] probe child could not start: {e}", file=sys.stderr, flush=True)
         return False
+    PROBE["ran"] = True
     try:
         rc = p.wait(timeout=timeout_s)
+        PROBE["rc"] = rc
         if rc != 0:
             print(f"[bench] probe child exited with {rc}; using torch.distributed exchanges", file=sys.stderr, flush=True)
         return rc == 0
     except subprocess.TimeoutExpired:
         p.kill()
         p.wait()
+        PROBE["rc"] = "timeout"
         print("[bench] probe child timed out; using torch.distributed exchanges", file=sys.stderr, flush=True)
         return False
 
@@ -624,6 +654,18 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    single = None
+    if run_many and not dist_on and not a.probe_child:
+        # A/B beside the headline: the same K steps replayed as ONE step per hipGraph launch -- what train()'s _GraphedSteps
+        # does per batch (it copies a fresh batch into the static buffers before every replay); the headline replays
+        # --steps-per-graph consecutive steps per launch over the resident batch
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            run_step()
+        torch.cuda.synchronize()
+        d1 = time.perf_counter() - t1
+        single = dict(ms_per_step=d1 / a.steps * 1e3, value=c["B"] * a.steps / d1, launch="hipGraph (1 step/graph)")
     w = eng.last["w"]
     loss_now = [float(x) for x in w.loss.cpu()]
     if a.probe_child:                       # the rehearsal: success = the one-graph RCCL step ran and stayed finite
@@ -642,12 +684,16 @@ def main():
             roof = dict(bound="hbm", achieved=dom["bytes"] / dom["seconds"] / 1e9, peak=8000.0, unit="GB/s")
         roof["frac"] = roof["achieved"] / roof["peak"]
         roof["traffic"] = pmc_traffic(name) if a.config == "cfg2" else None     # measured HBM bytes per launch (PMC)
+        roof["traffic_source"] = (PMC_TABLE + " (rocprofv3 --pmc passes of this command, committed; not measured in this run)"
+                                  if roof["traffic"] is not None else None)
         roof["algorithmic_bytes"] = dom["bytes"]
         roof["kernel"] = name
         roof["us_per_launch"] = dom["seconds"] * 1e6
         out = dict(metric="training clips/sec (RGB+Depth fusion, DARai) at 1/2/4/8 GPUs; effective-rank match",
                    value=world * c["B"] * a.steps / dt, unit="clips/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
-                   ms_per_step=dt / a.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32",
+                   ms_per_step=dt / a.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None,
+                   dtype="f32" + (" (depth products: bf16x3 split on the bf16 matrix cores, fp32 accumulate)"
+                                  if eng.depth_prec == 1 else ""),
                    data="synthetic",
                    config=dict(workload=NAMES.get(a.config, f"{a.config} per-GPU shape B={c['B']} S={c['S']} H={c['H']} "
                                                                   "(profiling only, not the headline workload)"),
@@ -658,6 +704,25 @@ def main():
                    kernels={k: dict(us=v["seconds"] * 1e6, GBps=v["bytes"] / v["seconds"] / 1e9,
                                     TFLOPs=v["flops"] / v["seconds"] / 1e12) for k, v in kr.items()},
                    final_losses=loss_now)
+        # the whole step against ITS bound (algorithmic bytes and FLOPs of one step of this configuration)
+        if a.config in STEP_WORK:
+            wk = STEP_WORK[a.config]
+            t_step = dt / a.steps
+            hbm_t, mfma_t = wk["bytes"] / 8.0e12, wk["flops"] / 157.3e12
+            out["roofline_step"] = dict(bound="hbm" if hbm_t >= mfma_t else "mfma", algorithmic_bytes=wk["bytes"],
+                                        algorithmic_flops=wk["flops"], achieved_GBps=wk["bytes"] / t_step / 1e9,
+                                        achieved_TFLOPs=wk["flops"] / t_step / 1e12,
+                                        frac=max(hbm_t, mfma_t) / t_step, per="GPU step",
+                                        note="SURVEY.md 8(d) totals / ms_per_step against 8 TB/s and 157.3 TFLOP/s (fp32 MFMA)")
+        if single is not None:
+            out["single_step_graph"] = single
+        if dist_on:
+            from r3d_amd import rccl as _rccl
+            flow = ("rccl-graph" if rs is not None else ("torch-collectives" if launch.startswith("hipGraph") else "eager"))
+            out["multi_gpu"] = dict(world=world, rccl_ranks=(rs.comm.nranks() if rs is not None else None),
+                                    torch_distributed_ranks=dist.get_world_size() if dist.is_initialized() else 1,
+                                    flow=flow, mode=mode, probe_child_ran=PROBE["ran"], probe_child_rc=PROBE["rc"],
+                                    torch_collectives_forced=bool(a.torch_collectives))
         try:
             out["erank"] = erank_field(eng)
         except Exception as e:                                # noqa: BLE001  (the headline number must still print)

@@ -312,6 +312,21 @@ typedef struct r3d_fuser_chain_bwd_args {
 } r3d_fuser_chain_bwd_args;
 int r3d_fuser_chain_bwd(const r3d_fuser_chain_bwd_args* a, void* stream);
 
+/* ---- build-defined THREE-modality fuser pieces (csrc/fuser3.hip; BASELINE configs[4]; the reference's CMFuser is
+ * two-token, model/futr_safuser_tokenfusion.py:74-81 -- SURVEY.md 8(d): checked against the build's own CPU restatement) ----
+ * Rows frame-major: the tokens of frame n are rows 3n, 3n + 1, 3n + 2.
+ * exchange3: x0[3n + m] = (mask[m] ? x_{(m+1) %% 3}[n] : x_m[n]) * keep  (mask [3][C] 1.0 / 0.0, drop_mask optional [3N, C]);
+ * attn3: attention over a frame's three tokens with the -inf diagonal (every token attends to the two others), qkv [3N, 3C] =
+ *        [q | k | v] per row, C / heads <= 128, probs [N][heads][3][2]; triple_mean: torch.mean over the three tokens. */
+int r3d_token_exchange3_fwd(const float* xa, const float* xb, const float* xc, const float* mask, const uint8_t* drop_mask,
+                            float drop_scale, float* x0, int N, int C, void* stream);
+int r3d_token_exchange3_bwd(const float* dx0, const float* mask, const uint8_t* drop_mask, float drop_scale, float* da, float* db,
+                            float* dc, int N, int C, void* stream);
+int r3d_attn3_fwd(const float* qkv, float* probs, float* out, int N, int C, int heads, void* stream);
+int r3d_attn3_bwd(const float* qkv, const float* d_out, float* d_qkv, int N, int C, int heads, void* stream);
+int r3d_triple_mean_fwd(const float* y, float* out, int N, int C, void* stream);
+int r3d_triple_mean_bwd(const float* d_out, float* dy, int N, int C, void* stream);
+
 /* ---- token selection / exchange: CMFuser.token_fusion (model/futr_safuser_tokenfusion.py:33-66) ------------- */
 /* out[c] = sum_r |x[r,c]| in fp64 (the eval-mode score before the division by B*T, :49-50). */
 int r3d_colabssum(const float* x, int ld, int rows, int cols, double* out, void* stream);

@@ -317,6 +317,35 @@ def cm_fuser(p, rgb, dep, mode, n_head):
     return fused, dict(idx_rgb=idx_rgb, idx_dep=idx_dep, score_rgb=s_rgb, score_dep=s_dep)
 
 
+def cm_fuser_m(p, xs, mode, n_head):
+    """BUILD-DEFINED M-modality extension of CMFuser.forward (BASELINE.json configs[4]) -- **parity
+    unpinned**: the reference's CMFuser is two-token (futr_safuser_tokenfusion.py:74-81 hard-codes 'rgb' / 'depth' and a
+    2 x 2 mask), so no reference output exists for M = 3.  Every line that generalises is kept: the per-modality scores and
+    k = C // 4 of token_fusion (:40-54), the exchange with the NEXT modality cyclically (m takes the selected channels of
+    (m + 1) mod M -- for M = 2 exactly :56-60), generate_cross_attention_mask(M) (-inf diagonal, :68-72; fuser_block builds
+    it for any M), Block, + x_res, norm, mean over the M tokens (:83-94).  For M = 2 this function IS cm_fuser
+    (tests/test_oracle_golden.py checks it bit for bit), which the reference fixtures pin."""
+    B, T, C = xs[0].shape
+    M = len(xs)
+    k = C // 4
+    if mode == "train":
+        scores = [torch.full((C,), 1.0 / (B * T * C), dtype=torch.float32) for _ in xs]
+    else:
+        scores = [x.detach().abs().mean(dim=(0, 1)) for x in xs]
+    idx = [torch.from_numpy(select_smallest(s_.numpy(), k)) for s_ in scores]
+    ex = []
+    for m in range(M):
+        mk = torch.zeros(C, dtype=torch.bool)
+        mk[idx[m]] = True
+        ex.append(torch.where(mk, xs[(m + 1) % M], xs[m]))
+    x = torch.stack(ex, dim=2).reshape(B * T, M, C)
+    x_res = x
+    x = fuser_block(p, x, n_head)
+    x = x + x_res
+    x = layer_norm(x, p["fuser.norm.weight"], p["fuser.norm.bias"])
+    return x.mean(dim=1).view(B, T, C), dict(idx=idx, scores=scores)
+
+
 def decoder(p, memory, pos, query_pos, key_padding_mask, n_head, n_layers, capture=None):
     """Transformer.forward with the encoder bypassed (model/extras/transformer.py:75-128) ->
     TransformerDecoder (:161-191) -> TransformerDecoderLayer.forward_post (:281-330), post-norm.

@@ -161,6 +161,12 @@ _SIGNATURES = {
     "r3d_fuser_chain_supported": ([_I, _I, _I, _I, _I, _I], C.c_int),
     "r3d_fuser_chain_fwd": ([_P, _P], C.c_int),
     "r3d_fuser_chain_bwd": ([_P, _P], C.c_int),
+    "r3d_token_exchange3_fwd": ([_P, _P, _P, _P, _P, _F, _P, _I, _I, _P], C.c_int),
+    "r3d_token_exchange3_bwd": ([_P, _P, _P, _F, _P, _P, _P, _I, _I, _P], C.c_int),
+    "r3d_attn3_fwd": ([_P, _P, _P, _I, _I, _I, _P], C.c_int),
+    "r3d_attn3_bwd": ([_P, _P, _P, _I, _I, _I, _P], C.c_int),
+    "r3d_triple_mean_fwd": ([_P, _P, _I, _I, _P], C.c_int),
+    "r3d_triple_mean_bwd": ([_P, _P, _I, _I, _P], C.c_int),
     "r3d_decoder_chain_supported": ([_I, _I, _I, _I], C.c_int),
     "r3d_decoder_chain": ([_P, _P, _P, _P], C.c_int),
     "r3d_gemm_ln_mha_supported": ([_I, _I, _I, _I], C.c_int),

@@ -16,7 +16,7 @@ OUT_DIR = os.path.join(HERE, "_build")
 LIB = os.path.join(OUT_DIR, "libr3d_hip.so")
 ARCH = "gfx950"
 SOURCES = ["abi.hip", "gemm_f32.hip", "rowops.hip", "fusion.hip", "attention.hip", "decoder.hip", "losses.hip", "optim.hip", "embed.hip", "tail.hip", "bnfuse.hip",
-           "erank.hip", "posenc.hip", "gemm_bf3.hip", "gemm_ln.hip", "fuser_chain.hip", "decoder_chain.hip"]
+           "erank.hip", "posenc.hip", "gemm_bf3.hip", "gemm_ln.hip", "fuser_chain.hip", "decoder_chain.hip", "fuser3.hip"]
 FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall",
          "-Wno-unused-function", "-Wno-pass-failed"]
 
@@ -37,6 +37,9 @@ def _deps_mtime():
 def build(force=False, verbose=True):
     os.makedirs(OUT_DIR, exist_ok=True)
     hipcc = _hipcc()
+    extra = os.environ.get("R3D_EXTRA_DEFS", "").split()      # profiling builds only (tools/*probe*): e.g. -DR3D_FC_PROBE=3
+    if extra:
+        force = True
     hdr = _deps_mtime()
     jobs = []
     for src in SOURCES:
@@ -47,7 +50,7 @@ def build(force=False, verbose=True):
 
     def compile_one(job):
         s, o = job
-        cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+        cmd = [hipcc] + FLAGS + extra + ["-c", s, "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {s}:\n{r.stderr}")

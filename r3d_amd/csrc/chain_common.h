@@ -10,6 +10,17 @@ namespace r3d {
 // profiling aid: thread 0 of the chosen workgroup stores the 100 MHz wall clock at a stage boundary
 #define R3D_CHAIN_MARK(TL, WG_OK, K) do { if ((TL) && (WG_OK) && threadIdx.x == 0) (TL)[(K)] = wall_clock64(); } while (0)
 
+// An optional dropout keep-mask as an UNCONDITIONAL load (a load under a branch -- even a uniform `if (ptr)` -- is waited
+// for on the spot): an absent mask reads a valid fallback address with stride 0; the raw byte stays in a register and is
+// turned into the keep factor only where it is used, so that the prologue's loads need no arithmetic and no wait.
+struct FcMaskSrc {
+    const uint8_t* p; size_t ld; bool on;
+    __device__ __forceinline__ FcMaskSrc(const uint8_t* m, const void* fallback, size_t ld_)
+        : p(m ? m : reinterpret_cast<const uint8_t*>(fallback)), ld(m ? ld_ : 0), on(m != nullptr) {}
+    __device__ __forceinline__ uint8_t raw(size_t row, int col) const { return p[row * ld + (on ? col : 0)]; }
+    __device__ __forceinline__ float keep(uint8_t b, float scale) const { return on ? scale * (float)b : 1.f; }
+};
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kFcH = 128;                   // hidden size this file is compiled for

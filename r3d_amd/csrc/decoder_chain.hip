@@ -61,16 +61,17 @@ __device__ __forceinline__ void dc_fwd(const DcArgs& D, const int b, float* lds)
     FcW s0, s1;
     fc_wload(s0, D.wo + (size_t)(wave * 16) * H, H, 16, lane);
     fc_wload(s1, D.w1 + (size_t)((4 * wave + 0) * 16) * H, H, 16, lane);
-    float t1v[4], keep2[4], keep3[4], keepf[4][4];
+    const FcMaskSrc md2(D.drop_d2, D.g2, H), md3(D.drop_d3, D.g2, H), mff(D.drop_ff, D.g2, 4 * H);
+    float t1v[4];
+    uint8_t kb2[4], kb3[4], kbf[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const size_t r = (size_t)(row0 + ((4 * q + i) & 7));
         t1v[i] = D.t1[r * H + c];
-        keep2[i] = D.drop_d2 ? D.drop_scale * (float)D.drop_d2[r * H + c] : 1.f;
-        keep3[i] = D.drop_d3 ? D.drop_scale * (float)D.drop_d3[r * H + c] : 1.f;
+        kb2[i] = md2.raw(r, c);
+        kb3[i] = md3.raw(r, c);
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-            keepf[t][i] = D.drop_ff ? D.drop_scale * (float)D.drop_ff[r * (4 * H) + (4 * wave + t) * 16 + li] : 1.f;
+        for (int t = 0; t < 4; ++t) kbf[t][i] = mff.raw(r, (4 * wave + t) * 16 + li);
     }
     const float b_o = D.bo[c], g2 = D.g2[c], be2 = D.be2[c], b_2 = D.b2[c];
     float b_1[4];
@@ -105,7 +106,7 @@ __device__ __forceinline__ void dc_fwd(const DcArgs& D, const int b, float* lds)
     float t2p[4], mean[4], rstd[4], t2v[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        t2p[i] = ((acc0[i] + acc1[i]) + b_o) * keep2[i] + t1v[i];
+        t2p[i] = ((acc0[i] + acc1[i]) + b_o) * md2.keep(kb2[i], D.drop_scale) + t1v[i];
         if (live) D.t2_pre[(size_t)(row0 + 4 * q + i) * H + c] = t2p[i];
     }
     fc_layernorm(t2p, red, wave, li, q, mean, rstd);
@@ -136,7 +137,7 @@ __device__ __forceinline__ void dc_fwd(const DcArgs& D, const int b, float* lds)
         const int cu = (4 * wave + t) * 16 + li;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float f = fmaxf((acc0[i] + acc1[i]) + b_1[t], 0.f) * keepf[t][i];
+            const float f = fmaxf((acc0[i] + acc1[i]) + b_1[t], 0.f) * mff.keep(kbf[t][i], D.drop_scale);
             if (live) D.ff1[(size_t)(row0 + 4 * q + i) * (4 * H) + cu] = f;
             bufF[(4 * q + i) * kFcP4 + cu] = live ? f : 0.f;
         }
@@ -167,7 +168,7 @@ __device__ __forceinline__ void dc_fwd(const DcArgs& D, const int b, float* lds)
     if (live) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            D.t3_pre[(size_t)(row0 + 4 * q + i) * H + c] = ((acc0[i] + acc1[i]) + b_2) * keep3[i] + t2v[i];
+            D.t3_pre[(size_t)(row0 + 4 * q + i) * H + c] = ((acc0[i] + acc1[i]) + b_2) * md3.keep(kb3[i], D.drop_scale) + t2v[i];
     }
 }
 
@@ -189,20 +190,21 @@ __device__ __forceinline__ void dc_bwd(const DcArgs& D, const int b, float* lds)
     fb_wload(s0, D.w2 + (4 * wave + 0) * 16, 4 * H, 128, lane);
     fb_wload(s1, D.w2 + (4 * wave + 1) * 16, 4 * H, 128, lane);
     dc_stage_rows(bufA, D.d_ff2, row0, tid);
-    float gate[4][4], res[4], t2pv[4], m2v[4], r2v[4], keep2[4];
+    const FcMaskSrc md2(D.drop_d2, D.g2, H), mff(D.drop_ff, D.g2, 4 * H);
+    float ffv[4][4], res[4], t2pv[4], m2v[4], r2v[4];
+    uint8_t kb2[4], kbf[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const size_t r = (size_t)(row0 + ((4 * q + i) & 7));
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const size_t e = r * (4 * H) + (4 * wave + t) * 16 + li;
-            const float kf = D.drop_ff ? D.drop_scale * (float)D.drop_ff[e] : 1.f;
-            gate[t][i] = D.ff1[e] > 0.f ? kf : 0.f;          // ReLU' (the stored activation is post-ReLU, post-dropout) x dropout
+            ffv[t][i] = D.ff1[r * (4 * H) + (4 * wave + t) * 16 + li];
+            kbf[t][i] = mff.raw(r, (4 * wave + t) * 16 + li);
         }
         res[i] = D.d_t3pre[r * H + c];
         t2pv[i] = D.t2_pre[r * H + c];
         m2v[i] = D.m2[r]; r2v[i] = D.r2[r];
-        keep2[i] = D.drop_d2 ? D.drop_scale * (float)D.drop_d2[r * H + c] : 1.f;
+        kb2[i] = md2.raw(r, c);
     }
     const float g2 = D.g2[c];
     __builtin_amdgcn_sched_barrier(0);
@@ -227,7 +229,8 @@ __device__ __forceinline__ void dc_bwd(const DcArgs& D, const int b, float* lds)
         const int cu = (4 * wave + t) * 16 + li;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float gv = (acc0[i] + acc1[i]) * gate[t][i];
+            // ReLU' (the stored activation is post-ReLU, post-dropout) x dropout'
+            const float gv = ffv[t][i] > 0.f ? (acc0[i] + acc1[i]) * mff.keep(kbf[t][i], D.drop_scale) : 0.f;
             if (live) D.d_ff1[(size_t)(row0 + 4 * q + i) * (4 * H) + cu] = gv;
             bufF[(4 * q + i) * kFcP4 + cu] = live ? gv : 0.f;
         }
@@ -278,8 +281,9 @@ __device__ __forceinline__ void dc_bwd(const DcArgs& D, const int b, float* lds)
         for (int i = 0; i < 4; ++i) {
             const float o = r2v[i] * (g[i] - s1v[i] - xh[i] * s2v[i]);
             const size_t e = (size_t)(row0 + 4 * q + i) * H + c;
-            if (live) { D.d_t2pre[e] = o; D.d_cap[e] = o * keep2[i]; }
-            bufA[(4 * q + i) * kFcP1 + c] = live ? o * keep2[i] : 0.f;
+            const float ok = o * md2.keep(kb2[i], D.drop_scale);
+            if (live) { D.d_t2pre[e] = o; D.d_cap[e] = ok; }
+            bufA[(4 * q + i) * kFcP1 + c] = live ? ok : 0.f;
         }
     }
     __syncthreads();
@@ -308,6 +312,10 @@ __device__ __forceinline__ void dc_bwd(const DcArgs& D, const int b, float* lds)
 __global__ __launch_bounds__(512) void decoder_chain_kernel(const DcArgs D, const r3d_tail_losses_args t, const LossArgs a,
                                                             float* part, unsigned* arrivals) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    // The two waves a SIMD hosts (w and w + 4) run the same stage sequence in lockstep and would want the matrix core, the
+    // LDS and the VALU at the same moments; a fixed priority difference lets one burst its MFMAs while the other is in its
+    // epilogue / staging, so the phases of the pair interleave instead of colliding.
+    if (threadIdx.x >= 256) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(2);
     __shared__ float lg[8][kTLHeads + 8];
     __shared__ float dl[8][kTLHeads + 8];
     __shared__ float red[8][4][128];

@@ -179,6 +179,35 @@ __device__ __forceinline__ bool jac_pair_fixed(float4 (&u)[NCH], float& al, floa
     return false;
 }
 
+// The same rotation with BOTH columns in registers (u: cached squared norm al, v: be).  Returns the pair's "still moving"
+// flag like jac_pair; every lane of the group takes the same branch.
+template <int G, int NCH>
+__device__ __forceinline__ bool jac_rot_rr(float4 (&u)[NCH], float& al, float4 (&v)[NCH], float& be, float tol2, float negl,
+                                           float stop2) {
+    float ga = 0.f;
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) ga += dot4(u[q], v[q]);
+    ga = group_sum<G>(ga);
+    const bool rot = ga * ga > tol2 * al * be && al > negl && be > negl;
+    if (rot) {
+        const float tau = be - al, d = 2.f * ga;
+        float t = d * __builtin_amdgcn_rcpf(fabsf(tau) + __builtin_amdgcn_sqrtf(tau * tau + d * d));
+        t = tau >= 0.f ? t : -t;
+        const float c = __builtin_amdgcn_rsqf(1.f + t * t), sn = c * t;
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) {
+            const float4 a = u[q], b = v[q];
+            u[q] = make_float4(c * a.x - sn * b.x, c * a.y - sn * b.y, c * a.z - sn * b.z, c * a.w - sn * b.w);
+            v[q] = make_float4(sn * a.x + c * b.x, sn * a.y + c * b.y, sn * a.z + c * b.z, sn * a.w + c * b.w);
+        }
+        const bool bigger = ga * ga > stop2 * al * be;
+        be = be + t * ga;
+        al = fmaxf(al - t * ga, 0.f);
+        return bigger;
+    }
+    return false;
+}
+
 struct ErankArgs {
     const float* x; int ld; long long batch_stride;      // [batch][R][ld]
     int R, C;
@@ -224,7 +253,13 @@ __device__ __forceinline__ void erank_stats_block(const float* sig, int C, float
 // Unlike it, a group keeps the SAME first column for a whole level, so that column stays in registers and only the
 // partner travels through LDS: per round 1 column read + 1 written per pair instead of 2 + 2.  The round is bound by the
 // LDS (ds_write_b128 ~83 B/clk/CU, reads ~244) plus the dot -> rcp / sqrt / rsq -> rotate latency chain, not by issue.
-template <int G, int NCH, bool EXACT, bool HALVE = false>
+// MODE 2 (round 3): the level order in 2 x 2 register blocks.  A group owns TWO adjacent first-half columns for a whole level
+// and, per super-round, fetches two adjacent second-half columns, rotates all four cross pairs in registers -- (i1,j1),
+// (i2,j2), then (i1,j2), (i2,j1): two dependent stages of two independent rotations -- and writes the two partners back:
+// per rotation HALF the LDS traffic and HALF the workgroup barriers of MODE 1 (the round is bound by exactly those two:
+// 64 KB of LDS traffic + one barrier + the dot -> reduce -> rcp / sqrt / rsq -> rotate chain per 64 rotations).  The last
+// level (blocks of two columns) runs as one plain round.  Every pair is still visited once per sweep.
+template <int G, int NCH, bool EXACT, int HALVE = 0>
 __global__ __launch_bounds__(kJacThreads) void erank_jacobi_kernel(const ErankArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];   // columns [Cp][Sp] (Sp = Rp [+ Cv]), nrm [Cp]
     __shared__ int rotated;
@@ -278,7 +313,72 @@ __global__ __launch_bounds__(kJacThreads) void erank_jacobi_kernel(const ErankAr
             negl = f * 1e-12f;
         }
         bool my_rot = false;
-        if constexpr (HALVE) {
+        if constexpr (HALVE == 2) {
+            constexpr int N2 = NCH > 0 ? NCH : 1;
+            const int ngrp = npairs / 2;                           // groups: one per two first-half columns
+            const bool act = slot < ngrp;
+            for (int hs = npairs; hs >= 2; hs >>= 1) {
+                const int hg = hs >> 1;                            // super-columns (pairs of columns) per half block
+                const int bp = slot / hg, kk = slot - bp * hg;
+                const int i1 = bp * 2 * hs + 2 * kk, jb = bp * 2 * hs + hs;
+                float4 u1[N2], u2[N2];
+                float al1 = 0.f, al2 = 0.f;
+                if (act) {
+#pragma unroll
+                    for (int q = 0; q < N2; ++q) {
+                        u1[q] = A4[(size_t)i1 * S4 + lg + G * q];
+                        u2[q] = A4[(size_t)(i1 + 1) * S4 + lg + G * q];
+                    }
+                    al1 = nrm[i1]; al2 = nrm[i1 + 1];
+                }
+                for (int r = 0; r < hg; ++r) {
+                    if (act) {
+                        const int j1 = jb + 2 * ((kk + r) & (hg - 1));
+                        float4* c1 = A4 + (size_t)j1 * S4;
+                        float4* c2 = c1 + S4;
+                        float4 v1[N2], v2[N2];
+#pragma unroll
+                        for (int q = 0; q < N2; ++q) { v1[q] = c1[lg + G * q]; v2[q] = c2[lg + G * q]; }
+                        float be1 = nrm[j1], be2 = nrm[j1 + 1];
+                        my_rot |= jac_rot_rr<G, N2>(u1, al1, v1, be1, tol2, negl, kStop2);
+                        my_rot |= jac_rot_rr<G, N2>(u2, al2, v2, be2, tol2, negl, kStop2);
+                        my_rot |= jac_rot_rr<G, N2>(u1, al1, v2, be2, tol2, negl, kStop2);
+                        my_rot |= jac_rot_rr<G, N2>(u2, al2, v1, be1, tol2, negl, kStop2);
+#pragma unroll
+                        for (int q = 0; q < N2; ++q) { c1[lg + G * q] = v1[q]; c2[lg + G * q] = v2[q]; }
+                        if (lg == 0) { nrm[j1] = be1; nrm[j1 + 1] = be2; }
+                    }
+                    __syncthreads();
+                }
+                if (act) {
+#pragma unroll
+                    for (int q = 0; q < N2; ++q) {
+                        A4[(size_t)i1 * S4 + lg + G * q] = u1[q];
+                        A4[(size_t)(i1 + 1) * S4 + lg + G * q] = u2[q];
+                    }
+                    if (lg == 0) { nrm[i1] = al1; nrm[i1 + 1] = al2; }
+                }
+                __syncthreads();
+            }
+            // last level: blocks of two columns (2k, 2k + 1), one round; group g takes pairs 2g and 2g + 1
+            if (act) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int i = 2 * (2 * slot + h);
+                    float4* ci = A4 + (size_t)i * S4;
+                    float4* cj = ci + S4;
+                    float4 u[N2], v[N2];
+#pragma unroll
+                    for (int q = 0; q < N2; ++q) { u[q] = ci[lg + G * q]; v[q] = cj[lg + G * q]; }
+                    float al = nrm[i], be = nrm[i + 1];
+                    my_rot |= jac_rot_rr<G, N2>(u, al, v, be, tol2, negl, kStop2);
+#pragma unroll
+                    for (int q = 0; q < N2; ++q) { ci[lg + G * q] = u[q]; cj[lg + G * q] = v[q]; }
+                    if (lg == 0) { nrm[i] = al; nrm[i + 1] = be; }
+                }
+            }
+            __syncthreads();
+        } else if constexpr (HALVE == 1) {
             const bool act = slot < npairs;                        // (npairs <= 64 <= nslots)
             const int qx = (G == 8) ? (slot & 1) : 0;
             for (int hs = npairs; hs >= 1; hs >>= 1) {
@@ -647,19 +747,32 @@ R3D_EXPORT int r3d_erank_jacobi_warm(const float* x, int ld, int64_t batch_strid
 #ifndef R3D_JAC_LANES
 #define R3D_JAC_LANES 8
 #endif
+#ifndef R3D_JAC_BLOCK2
+#define R3D_JAC_BLOCK2 0        // measured (round 3): 90 us per sweep and 8 sweeps against 81 us and 7 for MODE 1 at [128, 128]:
+#endif                          // half the LDS traffic and barriers, but each super-round is TWO dependent rotation stages and
+                                // the round was a latency chain already (dot -> reduce -> rcp / sqrt / rsq -> rotate), not
+                                // LDS- or barrier-bound; kept under the macro, tests pass in both modes
+        if (R3D_JAC_BLOCK2 && C >= 8) {                // the level order in 2 x 2 register blocks (16 lanes per group)
+            switch (R / 64) {
+                case 1: return go(erank_jacobi_kernel<16, 1, true, 2>);
+                case 2: return go(erank_jacobi_kernel<16, 2, true, 2>);
+                case 4: return go(erank_jacobi_kernel<16, 4, true, 2>);
+                default: break;
+            }
+        }
         if (R3D_JAC_LANES == 8) {
             switch (R / 64) {
-                case 1: return go(erank_jacobi_kernel<8, 2, true, true>);
-                case 2: return go(erank_jacobi_kernel<8, 4, true, true>);
-                case 4: return go(erank_jacobi_kernel<8, 8, true, true>);
+                case 1: return go(erank_jacobi_kernel<8, 2, true, 1>);
+                case 2: return go(erank_jacobi_kernel<8, 4, true, 1>);
+                case 4: return go(erank_jacobi_kernel<8, 8, true, 1>);
                 default: break;
             }
         }
         switch (R / 64) {
-            case 1: return go(erank_jacobi_kernel<16, 1, true, true>);
-            case 2: return go(erank_jacobi_kernel<16, 2, true, true>);
-            case 4: return go(erank_jacobi_kernel<16, 4, true, true>);
-            case 8: return go(erank_jacobi_kernel<16, 8, true, true>);
+            case 1: return go(erank_jacobi_kernel<16, 1, true, 1>);
+            case 2: return go(erank_jacobi_kernel<16, 2, true, 1>);
+            case 4: return go(erank_jacobi_kernel<16, 4, true, 1>);
+            case 8: return go(erank_jacobi_kernel<16, 8, true, 1>);
             default: break;
         }
     }

@@ -134,24 +134,50 @@ __device__ __forceinline__ void fc_fwd_fuser(const FcFwd& A, const int wg, float
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         acc0 = zero; acc1 = zero;
+        if (t < 2) R3D_CHAIN_MARK(A.timeline, wg == 0, 8 + 4 * t);
         fc_chunk(a, wr, acc0, acc1);
         __builtin_amdgcn_sched_barrier(0);
+        if (t < 2) R3D_CHAIN_MARK(A.timeline, wg == 0, 9 + 4 * t);
         // chunk t + 3 of the stream into the wave's region, chunk t + 5 requested
+#if defined(R3D_FC_PROBE) && (R3D_FC_PROBE & 8)
+        if (t == 0) { fc_wstore(s1, wl, lane); }
+        if (t == 1) { fc_wstore(s0, wl, lane); }
+        if (t == 2) { fc_wstore(s1, wl, lane); }
+        if (t == 3) { fc_wstore(s0, wl, lane); }
+#elif defined(R3D_FC_PROBE) && (R3D_FC_PROBE & 16)
+        if (t == 0) { fc_wload(s1, A.w1 + (size_t)((4 * wave + 3) * 16) * H, H, 16, lane); }       // c5
+        if (t == 1) { fc_wload(s0, A.w2 + (size_t)(wave * 16) * (4 * H) + 0, 4 * H, 16, lane); }   // c6
+        if (t == 2) { fc_wload(s1, A.w2 + (size_t)(wave * 16) * (4 * H) + 128, 4 * H, 16, lane); } // c7
+        if (t == 3) { fc_wload(s0, A.w2 + (size_t)(wave * 16) * (4 * H) + 256, 4 * H, 16, lane); } // c8
+#else
         if (t == 0) { fc_wstore(s1, wl, lane); fc_wload(s1, A.w1 + (size_t)((4 * wave + 3) * 16) * H, H, 16, lane); }       // c5
         if (t == 1) { fc_wstore(s0, wl, lane); fc_wload(s0, A.w2 + (size_t)(wave * 16) * (4 * H) + 0, 4 * H, 16, lane); }   // c6
         if (t == 2) { fc_wstore(s1, wl, lane); fc_wload(s1, A.w2 + (size_t)(wave * 16) * (4 * H) + 128, 4 * H, 16, lane); } // c7
         if (t == 3) { fc_wstore(s0, wl, lane); fc_wload(s0, A.w2 + (size_t)(wave * 16) * (4 * H) + 256, 4 * H, 16, lane); } // c8
+#endif
         __builtin_amdgcn_sched_barrier(0);
+        if (t < 2) R3D_CHAIN_MARK(A.timeline, wg == 0, 10 + 4 * t);
         const int cu = (4 * wave + t) * 16 + li;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float u = (acc0[i] + acc1[i]) + b_1[t];
+#if defined(R3D_FC_PROBE) && (R3D_FC_PROBE & 4)
+            const float f = u;
+#else
             const float f = gelu_f(u);
+#endif
             const size_t o = (size_t)(row0 + 4 * q + i) * (4 * H) + cu;
+#if !(defined(R3D_FC_PROBE) && (R3D_FC_PROBE & 1))
             A.u[o] = u;
             A.f1[o] = f;
+#endif
+#if !(defined(R3D_FC_PROBE) && (R3D_FC_PROBE & 2))
             bufF[(4 * q + i) * kFcP4 + cu] = f;
+#else
+            if (u == 123.456f) bufF[(4 * q + i) * kFcP4 + cu] = f;
+#endif
         }
+        if (t < 2) R3D_CHAIN_MARK(A.timeline, wg == 0, 11 + 4 * t);
     }
     __syncthreads();
     R3D_CHAIN_MARK(A.timeline, wg == 0, 4);
@@ -283,11 +309,13 @@ __device__ __forceinline__ void fc_fwd_query(const FcFwd& A, const int wgq, floa
 #pragma unroll
     for (int t = 0; t < 3; ++t) b_in[t] = A.b_in[(wave + 8 * t) * 16 + li];
     const float b_out = A.b_out[c], g1 = A.g1[c], be1 = A.be1[c], b_q = A.bq[c];
-    float keep[4], qp[4];
+    const FcMaskSrc md1(A.drop_d1, A.g1, H);
+    uint8_t kb[4];
+    float qp[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = row0 + 4 * q + i;
-        keep[i] = A.drop_d1 ? A.drop_scale * (float)A.drop_d1[(size_t)r * H + c] : 1.f;
+        kb[i] = md1.raw(r, c);
         qp[i] = A.qpos[(size_t)((4 * q + i) & 7) * H + c];
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -343,7 +371,7 @@ __device__ __forceinline__ void fc_fwd_query(const FcFwd& A, const int wgq, floa
     float t1p[4], mean[4], rstd[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        t1p[i] = ((acc0[i] + acc1[i]) + b_out) * keep[i];
+        t1p[i] = ((acc0[i] + acc1[i]) + b_out) * md1.keep(kb[i], A.drop_scale);
         A.t1_pre[(size_t)(row0 + 4 * q + i) * H + c] = t1p[i];
     }
     fc_layernorm(t1p, red, wave, li, q, mean, rstd);
@@ -368,6 +396,10 @@ __device__ __forceinline__ void fc_fwd_query(const FcFwd& A, const int wgq, floa
 
 __global__ __launch_bounds__(512) void fuser_chain_fwd_kernel(const FcFwd A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    // The two waves a SIMD hosts (w and w + 4) run the same stage sequence in lockstep and would want the matrix core, the
+    // LDS and the VALU at the same moments; a fixed priority difference lets one burst its MFMAs while the other is in its
+    // epilogue / staging, so the phases of the pair interleave instead of colliding.
+    if (threadIdx.x >= 256) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(2);
     const int nf = (2 * A.N) / kFcRows;
     if ((int)blockIdx.x < nf) fc_fwd_fuser(A, (int)blockIdx.x, lds);
     else fc_fwd_query(A, (int)blockIdx.x - nf, lds);
@@ -579,12 +611,14 @@ __device__ __forceinline__ void fc_bwd_fuser(const FcBwd& A, const int wg, float
         }
     }
     // operands of the seam's backward (norm1, embd_drop, exchange, depth LayerNorm + ReLU)
-    float x0v[4], m1v[4], r1v[4], keep[4];
+    const FcMaskSrc mx0(A.drop_x0, A.g1n, H);
+    float x0v[4], m1v[4], r1v[4];
+    uint8_t kb[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = row0 + 4 * q + i;
         x0v[i] = A.x0[(size_t)r * H + c]; m1v[i] = A.m1[r]; r1v[i] = A.r1[r];
-        keep[i] = A.drop_x0 ? A.drop_scale * (float)A.drop_x0[(size_t)r * H + c] : 1.f;
+        kb[i] = mx0.raw(r, c);
     }
     const float g1n = A.g1n[c], mr = A.m_rgb[c], md = A.m_dep[c], gd = A.lnd_g[c], bd = A.lnd_b[c];
     float rgbv[2], dpv[2], mdv[2], rdv[2];
@@ -635,7 +669,8 @@ __device__ __forceinline__ void fc_bwd_fuser(const FcBwd& A, const int wg, float
         fb_rowsum2<4>(g, gx, redA, wave, li, q, s1v, s2v);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            gx0[i] = (r1v[i] * (g[i] - s1v[i] - xh[i] * s2v[i]) + dx1[i] + (A.add_xres ? dx3[i] : 0.f)) * keep[i];
+            gx0[i] = (r1v[i] * (g[i] - s1v[i] - xh[i] * s2v[i]) + dx1[i] + (A.add_xres ? dx3[i] : 0.f)) *
+                     mx0.keep(kb[i], A.drop_scale);
     }
     {
         float g[2], gx[2], xh[2], s1v[2], s2v[2];
@@ -679,14 +714,16 @@ __device__ __forceinline__ void fc_bwd_query(const FcBwd& A, const int wgq, floa
     fb_wload(s0, A.wq + n0, H, 128, lane);                                            // c0
     fb_wload(s1, A.w_out + n0, H, 128, lane);                                         // c1
     const f32x4 a_in = *reinterpret_cast<const f32x4*>(A.d_caq + (size_t)(row0 + (tid >> 5)) * H + 4 * (tid & 31));
-    float t2p[4], tpre[4], m1v[4], r1v[4], keep[4];
+    const FcMaskSrc md1(A.drop_d1, A.g1d, H);
+    float t2p[4], tpre[4], m1v[4], r1v[4];
+    uint8_t kb[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = row0 + 4 * q + i;
         t2p[i] = A.d_t1_res[(size_t)r * H + c];
         tpre[i] = A.t1_pre[(size_t)r * H + c];
         m1v[i] = A.m1d[r]; r1v[i] = A.r1d[r];
-        keep[i] = A.drop_d1 ? A.drop_scale * (float)A.drop_d1[(size_t)r * H + c] : 1.f;
+        kb[i] = md1.raw(r, c);
     }
     const float g1 = A.g1d[c];
     __builtin_amdgcn_sched_barrier(0);
@@ -722,9 +759,10 @@ __device__ __forceinline__ void fc_bwd_query(const FcBwd& A, const int wgq, floa
         for (int i = 0; i < 4; ++i) {
             const float o = r1v[i] * (g[i] - s1v[i] - xh[i] * s2v[i]);
             const size_t e = (size_t)(row0 + 4 * q + i) * H + c;
+            const float ok = o * md1.keep(kb[i], A.drop_scale);
             if (A.t1pre_out) A.t1pre_out[e] = o;
-            A.sap[e] = o * keep[i];
-            bufV[(4 * q + i) * kFcP1 + c] = o * keep[i];
+            A.sap[e] = ok;
+            bufV[(4 * q + i) * kFcP1 + c] = ok;
         }
     }
     __syncthreads();
@@ -780,6 +818,10 @@ __device__ __forceinline__ void fc_bwd_query(const FcBwd& A, const int wgq, floa
 
 __global__ __launch_bounds__(512) void fuser_chain_bwd_kernel(const FcBwd A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    // The two waves a SIMD hosts (w and w + 4) run the same stage sequence in lockstep and would want the matrix core, the
+    // LDS and the VALU at the same moments; a fixed priority difference lets one burst its MFMAs while the other is in its
+    // epilogue / staging, so the phases of the pair interleave instead of colliding.
+    if (threadIdx.x >= 256) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(2);
     const int nf = (2 * A.N) / kFcRows;
     if ((int)blockIdx.x < nf) fc_bwd_fuser(A, (int)blockIdx.x, lds);
     else fc_bwd_query(A, (int)blockIdx.x - nf, lds);

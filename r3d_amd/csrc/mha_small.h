@@ -50,12 +50,16 @@ __device__ __forceinline__ void mha_fwd_small_unit(const MhaArgs& a, const int u
         const int e = lane + 64 * t, ec = e < LQ * DH ? e : LQ * DH - 1;
         qv[t] = qb[(size_t)(ec / DH) * a.ldq + (ec % DH)];
     }
-    float keep[LQ];
+    // optional operands as UNCONDITIONAL loads (a load under a branch is waited for on the spot): an absent one reads a
+    // valid address (the key row) and is discarded; the raw values are converted only after the staging barrier
+    const bool has_drop = a.drop != nullptr, has_kpm = a.kpm != nullptr, has_lab = a.key_label != nullptr;
+    const uint8_t* dp = has_drop ? a.drop + pbase + jc : reinterpret_cast<const uint8_t*>(kr);
+    const size_t dst_ = has_drop ? (size_t)Lk : 0;
+    uint8_t kraw[LQ];
 #pragma unroll
-    for (int i = 0; i < LQ; ++i) keep[i] = a.drop ? a.drop_scale * (float)a.drop[pbase + (size_t)i * Lk + jc] : 1.f;
-    bool masked = lane >= Lk;
-    if (a.kpm) masked = masked || a.kpm[(size_t)b * Lk + jc] != 0;
-    if (a.key_label) masked = masked || a.key_label[(size_t)b * Lk + jc] == (int64_t)a.pad_idx;
+    for (int i = 0; i < LQ; ++i) kraw[i] = dp[(size_t)i * dst_];
+    const uint8_t kpm_raw = *(has_kpm ? a.kpm + (size_t)b * Lk + jc : reinterpret_cast<const uint8_t*>(kr));
+    const int64_t lab_raw = *(has_lab ? a.key_label + (size_t)b * Lk + jc : reinterpret_cast<const int64_t*>(kr));
 #pragma unroll
     for (int t = 0; t < (LQ * DH + 63) / 64; ++t) {
         const int e = lane + 64 * t;
@@ -67,6 +71,10 @@ __device__ __forceinline__ void mha_fwd_small_unit(const MhaArgs& a, const int u
         vc[lane * (DH + 1) + 4 * t + 2] = v4[t].z; vc[lane * (DH + 1) + 4 * t + 3] = v4[t].w;
     }
     mha_unit_sync<WG>();
+    float keep[LQ];
+#pragma unroll
+    for (int i = 0; i < LQ; ++i) keep[i] = has_drop ? a.drop_scale * (float)kraw[i] : 1.f;
+    const bool masked = lane >= Lk || (has_kpm && kpm_raw != 0) || (has_lab && lab_raw == (int64_t)a.pad_idx);
     float p[LQ];
 #pragma unroll
     for (int i = 0; i < LQ; ++i) {
@@ -123,11 +131,15 @@ __device__ __forceinline__ void mha_bwd_small_unit(const MhaArgs& a, const int u
         qv[t] = qb[(size_t)(ec / DH) * a.ldq + (ec % DH)];
         dv_[t] = dob[(size_t)(ec / DH) * a.lddo + (ec % DH)];
     }
-    float P[LQ], keep[LQ];
+    const bool has_drop = a.drop != nullptr;
+    const uint8_t* dp = has_drop ? a.drop + pbase + jc : reinterpret_cast<const uint8_t*>(kr);
+    const size_t dst_ = has_drop ? (size_t)Lk : 0;
+    float P[LQ];
+    uint8_t kraw[LQ];
 #pragma unroll
     for (int i = 0; i < LQ; ++i) {
         P[i] = a.probs[pbase + (size_t)i * Lk + jc];
-        keep[i] = a.drop ? a.drop_scale * (float)a.drop[pbase + (size_t)i * Lk + jc] : 1.f;
+        kraw[i] = dp[(size_t)i * dst_];
     }
 #pragma unroll
     for (int t = 0; t < (LQ * DH + 63) / 64; ++t) {
@@ -140,6 +152,9 @@ __device__ __forceinline__ void mha_bwd_small_unit(const MhaArgs& a, const int u
         kc[lane * (DH + 1) + 4 * t + 2] = k4[t].z; kc[lane * (DH + 1) + 4 * t + 3] = k4[t].w;
     }
     mha_unit_sync<WG>();
+    float keep[LQ];
+#pragma unroll
+    for (int i = 0; i < LQ; ++i) keep[i] = has_drop ? a.drop_scale * (float)kraw[i] : 1.f;
     // dP = (dO . V^T) o keep ; softmax backward with the 1/sqrt(dh) folded in ; Pd = dropped probabilities
     float dS[LQ], Pd[LQ];
     const bool live = lane < Lk;

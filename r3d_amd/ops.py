@@ -932,3 +932,48 @@ def embed_gather_bwd(d_out, idx, d_weight):
     assert idx.dtype == torch.int64 and idx.is_contiguous() and d_weight.is_contiguous() and d_weight.shape[1] == H
     check(_lib.load().r3d_embed_gather_bwd(_p(d_out), _ld(d_out), _p(idx), _p(d_weight), d_weight.shape[0], rows, H, _stream()),
           "r3d_embed_gather_bwd")
+
+
+# ----------------------------------------------------------------------------------------------------------
+# build-defined three-modality fuser pieces (csrc/fuser3.hip)
+# ----------------------------------------------------------------------------------------------------------
+def token_exchange3_fwd(xa, xb, xc, mask, x0, *, drop_mask=None, drop_scale=1.0):
+    N, Cc = xa.shape
+    assert xb.shape == xa.shape == xc.shape and tuple(mask.shape) == (3, Cc) and tuple(x0.shape) == (3 * N, Cc)
+    for t in (xa, xb, xc, mask, x0):
+        assert t.is_contiguous()
+    check(_lib.load().r3d_token_exchange3_fwd(_p(xa), _p(xb), _p(xc), _p(mask), _p(drop_mask), drop_scale, _p(x0), N, Cc, _stream()),
+          "r3d_token_exchange3_fwd")
+
+
+def token_exchange3_bwd(dx0, mask, da, db, dc, *, drop_mask=None, drop_scale=1.0):
+    N, Cc = da.shape
+    assert tuple(dx0.shape) == (3 * N, Cc) and dx0.is_contiguous() and da.is_contiguous() and db.is_contiguous() and dc.is_contiguous()
+    check(_lib.load().r3d_token_exchange3_bwd(_p(dx0), _p(mask), _p(drop_mask), drop_scale, _p(da), _p(db), _p(dc), N, Cc, _stream()),
+          "r3d_token_exchange3_bwd")
+
+
+def attn3_fwd(qkv, probs, out, heads):
+    rows, C3 = qkv.shape
+    N, Cc = rows // 3, C3 // 3
+    assert qkv.is_contiguous() and out.is_contiguous() and tuple(out.shape) == (rows, Cc) and probs.numel() == N * heads * 6
+    check(_lib.load().r3d_attn3_fwd(_p(qkv), _p(probs), _p(out), N, Cc, heads, _stream()), "r3d_attn3_fwd")
+
+
+def attn3_bwd(qkv, d_out, d_qkv, heads):
+    rows, C3 = qkv.shape
+    N, Cc = rows // 3, C3 // 3
+    assert qkv.is_contiguous() and d_out.is_contiguous() and d_qkv.is_contiguous() and d_qkv.shape == qkv.shape
+    check(_lib.load().r3d_attn3_bwd(_p(qkv), _p(d_out), _p(d_qkv), N, Cc, heads, _stream()), "r3d_attn3_bwd")
+
+
+def triple_mean_fwd(y, out):
+    N, Cc = out.shape
+    assert tuple(y.shape) == (3 * N, Cc) and y.is_contiguous() and out.is_contiguous()
+    check(_lib.load().r3d_triple_mean_fwd(_p(y), _p(out), N, Cc, _stream()), "r3d_triple_mean_fwd")
+
+
+def triple_mean_bwd(d_out, dy):
+    N, Cc = d_out.shape
+    assert tuple(dy.shape) == (3 * N, Cc) and dy.is_contiguous() and d_out.is_contiguous()
+    check(_lib.load().r3d_triple_mean_bwd(_p(d_out), _p(dy), N, Cc, _stream()), "r3d_triple_mean_bwd")

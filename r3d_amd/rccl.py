@@ -45,6 +45,8 @@ def _load():
     L.ncclGetUniqueId.argtypes = [ctypes.POINTER(_UniqueId)]
     L.ncclCommInitRank.argtypes = [ctypes.POINTER(vp), i, _UniqueId, i]
     L.ncclCommDestroy.argtypes = [vp]
+    L.ncclCommCount.argtypes = [vp, ctypes.POINTER(i)]
+    L.ncclCommCount.restype = i
     L.ncclAllReduce.argtypes = [vp, vp, sz, i, i, vp, vp]
     L.ncclReduceScatter.argtypes = [vp, vp, sz, i, i, vp, vp]
     L.ncclAllGather.argtypes = [vp, vp, sz, i, vp, vp]
@@ -97,6 +99,12 @@ class RcclComm:
         self._comm = ctypes.c_void_p()
         with torch.cuda.device(self.device):
             _check(L.ncclCommInitRank(ctypes.byref(self._comm), self.world, uid, self.rank), "ncclCommInitRank")
+
+    def nranks(self):
+        """Ranks RCCL itself reports for this communicator (ncclCommCount) -- what bench.py's N > 1 line records."""
+        n = ctypes.c_int(0)
+        _check(_load().ncclCommCount(self._comm, ctypes.byref(n)), "ncclCommCount")
+        return int(n.value)
 
     def close(self):
         if getattr(self, "_comm", None):

@@ -120,3 +120,22 @@ def test_oracle_bn_blend_variant_matches_reference_fixture(tag):
         eo, _ = O.forward(tr.p, (batch[0], batch[2]), batch[1], "train", m["pad_idx"], m["n_head"], m["n_dec"],
                           bn_state=tr.bn_state, bn_training=False)
     assert_close(eo["action"], fx["eval_action"], 1e-4, 1e-5, "eval action")
+
+
+def test_m_modality_fuser_restatement_reduces_to_the_reference_pinned_two_modality_one():
+    """oracle.cm_fuser_m (the build-defined M-modality extension, checker of the HIP three-modality fuser) with M = 2 is
+    cm_fuser bit for bit -- the function the reference fixtures pin -- in both selection modes."""
+    import torch
+    from oracle import futr_oracle as O
+    from tests.helpers import load_fixture, fixture_params
+    fx = load_fixture("step_tiny")
+    m = fx["meta"]
+    p = fixture_params(fx)
+    g = torch.Generator().manual_seed(3)
+    rgb = torch.randn(m["B"], m["S"], m["H"], generator=g).relu()
+    dep = torch.randn(m["B"], m["S"], m["H"], generator=g).relu()
+    for mode in ("train", "val"):
+        a, aux_a = O.cm_fuser(p, rgb, dep, mode, m["n_head"])
+        b, aux_b = O.cm_fuser_m(p, [rgb, dep], mode, m["n_head"])
+        assert torch.equal(a, b), mode
+        assert torch.equal(aux_a["idx_rgb"], aux_b["idx"][0]) and torch.equal(aux_a["idx_dep"], aux_b["idx"][1])

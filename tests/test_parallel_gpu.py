@@ -537,3 +537,102 @@ def test_train_loop_pixel_shard_graphed_one_rank_equals_single_gpu(case):
     rank, status, info = q.get(timeout=600)
     p.join(timeout=60)
     assert status == "ok", info
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# two REAL devices, real RCCL (skipped, loudly, on a one-GPU box): first contact with ncclAllToAll / ReduceScatter / the
+# grouped AllGather + AllReduce between devices, eager and captured into the step's hipGraph
+# ---------------------------------------------------------------------------------------------------------------------
+def _two_device_worker(rank, world, port, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                          HSA_ENABLE_IPC_MODE_LEGACY="0")
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+        from r3d_amd.parallel import DataParallelStep, RcclStep
+        from r3d_amd.rccl import RcclComm
+        fx = load_fixture("step_tiny")
+        m = fx["meta"]
+        steps = 3
+        batches = [[t.cuda() for t in fixture_batch(fx, seed=100 + 10 * s + rank)] for s in range(steps)]
+        x2d = [b[1].reshape(m["B"] * m["S"], -1) for b in batches]
+        # yardstick: the torch.distributed (ProcessGroupNCCL) replicated step, launch by launch
+        engA, _, recA = _run(fx, rank, False, steps, False)
+        info = []
+        for pixel_shard in (False, True):
+            for graphed in (False, True):
+                model = _model(fx)
+                eng = model.engine()
+                dp = DataParallelStep(eng, pixel_shard=pixel_shard)
+                dp.broadcast_parameters()
+                comm, side = RcclComm(), RcclComm()
+                assert comm.nranks() == world and side.nranks() == world
+                rs = RcclStep(dp, comm, side, m["lr"], m["wd"], fuse_adam=False)
+                losses = []
+                rs.stage(x2d[0], batches[0][3], m["pad_idx"], 0)
+                graphs = {}
+                for s, (feats, depth, lab, dur, tgt) in enumerate(batches):
+                    if s + 1 < steps:
+                        rs.stage(x2d[s + 1], batches[s + 1][3], m["pad_idx"], (s + 1) % 2)
+                    if graphed and s >= 1:
+                        # capture this slot's step (the RCCL kernels become graph nodes) and replay it: the static buffers
+                        # are the batch tensors of step s, so the replay IS step s
+                        torch.cuda.synchronize()
+                        g = torch.cuda.CUDAGraph()
+                        eng._drop_ready = None
+                        with torch.cuda.graph(g):
+                            rs.run(feats, depth, lab, dur, tgt, m["pad_idx"], False, slot=s % 2)
+                        graphs[s] = g
+                        # (capture does not execute: the replay runs the step once)
+                        g.replay()
+                    else:
+                        rs.run(feats, depth, lab, dur, tgt, m["pad_idx"], False, slot=s % 2)
+                    torch.cuda.synchronize()
+                    losses.append(eng.last["w"].loss.clone())
+                if dp.tp is not None:
+                    dp.tp.sync_full_weight()
+                torch.cuda.synchronize()
+                for s in range(steps):
+                    tol = 1e-5 if s == 0 else 2e-2
+                    assert torch.allclose(recA[s]["loss"], losses[s], rtol=tol, atol=1e-6), (pixel_shard, graphed, s,
+                                                                                           recA[s]["loss"], losses[s])
+                a, b = engA.arena, eng.arena
+                pa, pb = a.params[:a.n_live], b.params[:b.n_live]
+                d = (pa - pb).abs()
+                assert float(d.max()) <= steps * 2.1 * m["lr"], float(d.max())
+                frac = float((d <= 1e-5 * (1 + pa.abs())).double().mean())
+                assert frac > 0.95, (pixel_shard, graphed, frac)
+                t = pb.clone()
+                dist.broadcast(t, src=0)
+                assert torch.equal(t, pb), "ranks must end with identical parameters"
+                info.append((pixel_shard, graphed, frac))
+                comm.close()
+                side.close()
+        q.put((rank, "ok", info))
+    except Exception as e:          # noqa: BLE001
+        import traceback
+        q.put((rank, "fail", traceback.format_exc() + repr(e)))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_rccl_step_on_two_real_devices():
+    """Replicated AND pixel-sharded RcclStep, eager AND with the step captured into a hipGraph, on two real devices over
+    real RCCL (xGMI), against the torch.distributed replicated step.  A one-GPU box cannot run it: the skip says so --
+    the first multi-GPU node that runs the suite executes the exchanges between devices before any benchmark does
+    (reference counterpart: nn.DataParallel, main_darai.py:133)."""
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip(f"NOT RUN: needs >= 2 MI355X devices, this box has {n} -- RCCL between devices is unexercised here")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_two_device_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=900) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, status, info in res:
+        assert status == "ok", f"rank {rank}: {info}"

@@ -50,14 +50,10 @@ def main():
             if len(used) < 2:
                 continue
             base = seg[:, used[0]]
-            prev = base
-            line = []
-            for i in used[1:]:
-                d = (seg[:, i] - prev).median()
-                line.append(f"[{lo + i}] +{float(d):.2f}")
-                prev = seg[:, i]
-            tot = float((seg[:, used[-1]] - base).median())
-            print(f"   {name}: " + "  ".join(line) + f"   total {tot:.2f} us")
+            rel = {i: float((seg[:, i] - base).median()) for i in used}
+            order = sorted(used, key=lambda i: rel[i])
+            line = [f"[{lo + i}] {rel[i]:.2f}" for i in order]
+            print(f"   {name} (us since the first mark): " + "  ".join(line))
 
 
 if __name__ == "__main__":
