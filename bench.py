@@ -199,7 +199,12 @@ def cpu_baseline(c, budget_s=8.0):
     params = {n: p.detach().clone() for n, p in m.named_parameters()}
     batch = [torch.from_numpy(x) for x in synth.make_batch(c["B"], c["S"], c["K"], c["K"] + 1, 1)]
     runs = []
-    for cores in sorted({max(1, min(16, avail)), max(1, min(64, avail)), avail}):
+    # every core of a 256-thread host is not a meaningful arm for a 4 GFLOP step: measured in the round-3 profile refresh,
+    # 256 threads ran ONE step in 38 s (0.2 clips/s, oversubscribed intra-op pools) -- "all cores" is timed up to 128
+    sizes = {max(1, min(16, avail)), max(1, min(64, avail))}
+    if avail <= 128:
+        sizes.add(avail)
+    for cores in sorted(sizes):
         torch.set_num_threads(cores)
         tr = O.CpuTrainer({k: v.clone() for k, v in params.items()}, c["K"] + 1, c["heads"], c["n_dec"], c["lr"], c["wd"])
         tr.step(batch)                                                    # warm-up
@@ -214,6 +219,8 @@ def cpu_baseline(c, budget_s=8.0):
     best = max(runs, key=lambda r: r["value"])
     return dict(value=best["value"], unit="clips/s", cores=best["cores"], kind="port", host_cores=os.cpu_count(),
                 host_cores_available=avail, by_threads={str(r["cores"]): r["value"] for r in runs},
+                all_cores_note=(None if avail <= 128 else f"{avail} threads not timed: 256 threads ran one step in 38 s "
+                                                          "(0.2 clips/s) in profiles/r03_bench_cfg2.json's refresh"),
                 sample="; ".join(f"{r['steps']} full CPU training steps (fwd+3 losses+autograd bwd+AdamW) of the same "
                                  f"B={c['B']},S={c['S']},H={c['H']} workload in {r['seconds']:.1f}s on {r['cores']} threads"
                                  for r in runs) + f"; torch {torch.__version__} CPU; box: {os.cpu_count()} cores, {avail} "
@@ -306,6 +313,9 @@ def main():
     ap.add_argument("--no-fuser-chain", action="store_true",
                     help="the fuser block's row-local chain as grouped GEMM / gemm_ln launches instead of the one-launch "
                          "chain kernels (A/B)")
+    ap.add_argument("--chain-fp32", action="store_true",
+                    help="the chain kernels' products on the exact-fp32 MFMA instead of the bf16 matrix cores (bf16x3 split, "
+                         "pre-split weight planes) (A/B)")
     ap.add_argument("--no-decoder-chain", action="store_true",
                     help="the decoder layer's query side as separate attention / GEMM / LayerNorm / loss launches instead of "
                          "the one-launch decoder chain kernel (A/B)")
@@ -380,6 +390,7 @@ def main():
     eng.use_gemm_ln = not a.no_gemm_ln
     eng.use_fuser_chain = not a.no_fuser_chain
     eng.use_decoder_chain = not a.no_decoder_chain
+    eng.chain_bf3 = not a.chain_fp32
     eng.erank_side_stream = not a.erank_main_stream
     if a.no_paired:
         eng.use_paired_launches = False

@@ -280,7 +280,21 @@ typedef struct r3d_fuser_chain_fwd_args {
     int32_t N, S, K, H, add_xres, B, Q, heads;
     uint64_t* timeline;      /* profiling aid, normally NULL: wave 0 of the first workgroup of each role stores wall_clock64()
                                 (100 MHz) at its stage boundaries -- fuser role [0..15], query role [16..31] */
+    /* optional (all or none): bf16x3 operand-order planes (r3d_weight_planes) of wv, wproj, w1, w2, wkv, wseg as
+     * B[n = output column][k = input column] -- the fuser role then runs on the bf16 matrix cores (three-way exact operand
+     * split, six products, fp32 accumulate: the precision of r3d_gemm_desc::prec = 1) */
+    const uint16_t* pl_wv; const uint16_t* pl_wproj; const uint16_t* pl_w1; const uint16_t* pl_w2; const uint16_t* pl_wkv;
+    const uint16_t* pl_wseg;
 } r3d_fuser_chain_fwd_args;
+/* bf16x3 operand-order planes: for a matrix B[n][k] (N x K), bf16 element (tile t = n / 16, k-step s = k / 32, plane p of
+ * {high, middle, low}, lane = n %% 16 + 16 ((k %% 32) / 8), e = k %% 8) at index ((((t * ceil(K/32) + s) * 3 + p) * 64 + lane) * 8
+ * + e); zero where n >= N or k >= K.  transposed != 0: B[n][k] = src[k * ld + n] (the planes of the transpose: input-gradient
+ * products), else src[n * ld + k]. */
+typedef struct r3d_plane_job {
+    const float* src; uint16_t* dst; int32_t ld, N, K, transposed, first_block, pad_;
+} r3d_plane_job;
+int64_t r3d_weight_plane_elems(int N, int K);
+int r3d_weight_planes(const r3d_plane_job* jobs_device, int njobs, int total_blocks, void* stream);
 int r3d_fuser_chain_supported(int N, int H, int K, int B, int Q, int heads);
 int r3d_fuser_chain_fwd(const r3d_fuser_chain_fwd_args* a, void* stream);
 /* The adjoint of r3d_fuser_chain_fwd, one launch.  Fuser role: d(memory + pos) = d_cakv Wkv (stored in d_fused: the

@@ -71,8 +71,16 @@ class FuserChainFwdArgs(C.Structure):
     _PTRS = ("x0 h1 wv wproj bproj g2 be2 w1 b1 w2 b2 gf bef pos wkv bkv wseg bseg vsw x1 h2 m2 r2 u f1 x3 y mf rf fused seg "
              "cakv qpos w_in b_in w_out b_out g1 be1 wq bq drop_sa drop_d1").split()
     _PTRS2 = "sa_qkv p_sa sa_o t1_pre t1 m1 r1 caq".split()
+    _PLANES = "pl_wv pl_wproj pl_w1 pl_w2 pl_wkv pl_wseg".split()
     _fields_ = ([(n, C.c_void_p) for n in _PTRS] + [("drop_scale", C.c_float)] + [(n, C.c_void_p) for n in _PTRS2] +
-                [(n, C.c_int32) for n in "N S K H add_xres B Q heads".split()] + [("timeline", C.c_void_p)])
+                [(n, C.c_int32) for n in "N S K H add_xres B Q heads".split()] + [("timeline", C.c_void_p)] +
+                [(n, C.c_void_p) for n in _PLANES])
+
+
+class PlaneJob(C.Structure):
+    """struct r3d_plane_job"""
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("ld", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+                ("transposed", C.c_int32), ("first_block", C.c_int32), ("pad_", C.c_int32)]
 
 
 class FuserChainBwdArgs(C.Structure):
@@ -161,6 +169,8 @@ _SIGNATURES = {
     "r3d_fuser_chain_supported": ([_I, _I, _I, _I, _I, _I], C.c_int),
     "r3d_fuser_chain_fwd": ([_P, _P], C.c_int),
     "r3d_fuser_chain_bwd": ([_P, _P], C.c_int),
+    "r3d_weight_plane_elems": ([_I, _I], C.c_int64),
+    "r3d_weight_planes": ([_P, _I, _I, _P], C.c_int),
     "r3d_token_exchange3_fwd": ([_P, _P, _P, _P, _P, _F, _P, _I, _I, _P], C.c_int),
     "r3d_token_exchange3_bwd": ([_P, _P, _P, _F, _P, _P, _P, _I, _I, _P], C.c_int),
     "r3d_attn3_fwd": ([_P, _P, _P, _I, _I, _I, _P], C.c_int),

@@ -25,7 +25,7 @@
 //
 // Intermediates the weight-gradient launch and the backward need (vsw, x1, h2, u, f1, x3, row statistics, ...) are stored
 // from the accumulator layout as they are produced.
-#include "chain_common.h"
+#include "chain_bf3.h"
 #include "mha_small.h"
 #include "../../include/r3d_hip.h"
 
@@ -392,6 +392,241 @@ __device__ __forceinline__ void fc_fwd_query(const FcFwd& A, const int wgq, floa
 #pragma unroll
     for (int i = 0; i < 4; ++i) A.caq[(size_t)(row0 + 4 * q + i) * H + c] = (acc0[i] + acc1[i]) + b_q;
     R3D_CHAIN_MARK(A.timeline, wgq == 0, 21);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// forward, fuser role on the bf16 matrix cores (chain_bf3.h): the same stages, weights from the operand-order planes
+// (A.pl_*), activations handed from stage to stage as three bf16 planes in LDS
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kF3P1 = kFcH + 8;                              // bf16 pitch of a [16][128] image
+constexpr int kF3P4 = 4 * kFcH + 8;                          // ... of the [16][512] one
+constexpr int kF3ImgH = 0;                                   // (offsets in bf16 elements)
+constexpr int kF3ImgV = kF3ImgH + 3 * 16 * kF3P1;
+constexpr int kF3ImgF = kF3ImgV + 3 * 16 * kF3P1;
+constexpr int kF3RedBytes = (kF3ImgF + 3 * 16 * kF3P4) * 2;
+constexpr int kF3LdsBytes = kF3RedBytes + 2 * 2 * 8 * kFcRows * 4;
+
+__device__ __forceinline__ void fc3_fwd_fuser(const FcFwd& A, const int wg, float* lds) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, q = lane >> 4;
+    unsigned short* img = reinterpret_cast<unsigned short*>(lds);
+    unsigned short* imgH = img + kF3ImgH;
+    unsigned short* imgV = img + kF3ImgV;
+    unsigned short* imgF = img + kF3ImgF;
+    float (*red)[8][kFcRows] = reinterpret_cast<float (*)[8][kFcRows]>(reinterpret_cast<unsigned char*>(lds) + kF3RedBytes);
+    const int row0 = wg * kFcRows;
+    const int c = wave * 16 + li;
+    constexpr int H = kFcH;
+    const int nseg_t = (A.K + 15) >> 4;
+    const bool has12 = wave < nseg_t;
+    R3D_CHAIN_MARK(A.timeline, wg == 0, 0);
+    // ---- weight chunks c0..c2 (chunk c lives in register set c % 3; a set is refilled with chunk c + 3 once c is multiplied)
+    Bf3B b0, b1, b2;
+    bf3_bload<4>(b0, A.pl_wv, 4, wave, 0, lane);                                       // c0: V projection, tile w
+    bf3_bload<4>(b1, A.pl_wproj, 4, wave, 0, lane);                                    // c1: attn.proj
+    bf3_bload<4>(b2, A.pl_w1, 4, 4 * wave + 0, 0, lane);                               // c2: fc1 tile 4w
+    const f32x4 a_in = *reinterpret_cast<const f32x4*>(A.h1 + (size_t)(row0 + (tid >> 5)) * H + 4 * (tid & 31));
+    float x0[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x0[i] = A.x0[(size_t)(row0 + 4 * q + i) * H + c];
+    const float b_proj = A.bproj[c], g2 = A.g2[c], be2 = A.be2[c], b_2 = A.b2[c], gF = A.gf[c], beF = A.bef[c];
+    float b_1[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) b_1[t] = A.b1[(4 * wave + t) * 16 + li];
+    const int f0 = (row0 >> 1) + 2 * q;
+    const float pos0 = A.pos[(size_t)(f0 % A.S) * H + c], pos1 = A.pos[(size_t)((f0 + 1) % A.S) * H + c];
+    const float bkv0 = A.bkv[wave * 16 + li], bkv1 = A.bkv[(wave + 8) * 16 + li];
+    const int cseg = (has12 ? wave : 0) * 16 + li;
+    const float bsg = A.bseg[cseg < A.K ? cseg : A.K - 1];
+    __builtin_amdgcn_sched_barrier(0);
+    bf3_stage_tile(imgH, kF3P1, 0, a_in, tid);
+    __syncthreads();
+    R3D_CHAIN_MARK(A.timeline, wg == 0, 1);
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc0 = zero, acc1 = zero;
+    // ---- stage 1: V = h1 . Wv^T, stored pair-swapped
+    bf3_chunk<4>(imgH, kF3P1, li, q, 0, b0, acc0, acc1);                               // c0
+    __builtin_amdgcn_sched_barrier(0);
+    bf3_bload<4>(b0, A.pl_w1, 4, 4 * wave + 1, 0, lane);                               // c3
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float v = acc0[i] + acc1[i];
+        const int rs = 4 * q + (i ^ 1);
+        A.vsw[(size_t)(row0 + rs) * H + c] = v;
+        bf3_store1(imgV, kF3P1, rs, c, v);
+    }
+    __syncthreads();
+    R3D_CHAIN_MARK(A.timeline, wg == 0, 2);
+    // ---- stage 2: x1 = x0 + vsw . Wproj^T + b ; h2 = norm2(x1)
+    acc0 = zero; acc1 = zero;
+    bf3_chunk<4>(imgV, kF3P1, li, q, 0, b1, acc0, acc1);                               // c1
+    __builtin_amdgcn_sched_barrier(0);
+    bf3_bload<4>(b1, A.pl_w1, 4, 4 * wave + 2, 0, lane);                               // c4
+    __builtin_amdgcn_sched_barrier(0);
+    float x1[4], mean[4], rstd[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        x1[i] = (acc0[i] + acc1[i]) + b_proj + x0[i];
+        A.x1[(size_t)(row0 + 4 * q + i) * H + c] = x1[i];
+    }
+    fc_layernorm(x1, red, wave, li, q, mean, rstd);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float h = (x1[i] - mean[i]) * rstd[i] * g2 + be2;
+        const int r = 4 * q + i;
+        A.h2[(size_t)(row0 + r) * H + c] = h;
+        bf3_store1(imgH, kF3P1, r, c, h);
+        if (wave == 0 && li == 0) { A.m2[row0 + r] = mean[i]; A.r2[row0 + r] = rstd[i]; }
+    }
+    __syncthreads();
+    R3D_CHAIN_MARK(A.timeline, wg == 0, 3);
+    // ---- stage 3: u = h2 . W1^T + b1 ; f1 = GELU(u)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        acc0 = zero; acc1 = zero;
+        if (t == 0) bf3_chunk<4>(imgH, kF3P1, li, q, 0, b2, acc0, acc1);               // c2
+        if (t == 1) bf3_chunk<4>(imgH, kF3P1, li, q, 0, b0, acc0, acc1);               // c3
+        if (t == 2) bf3_chunk<4>(imgH, kF3P1, li, q, 0, b1, acc0, acc1);               // c4
+        if (t == 3) bf3_chunk<4>(imgH, kF3P1, li, q, 0, b2, acc0, acc1);               // c5
+        __builtin_amdgcn_sched_barrier(0);
+        if (t == 0) bf3_bload<4>(b2, A.pl_w1, 4, 4 * wave + 3, 0, lane);               // c5
+        if (t == 1) bf3_bload<4>(b0, A.pl_w2, 16, wave, 0, lane);                      // c6: fc2, k-steps 0..3
+        if (t == 2) bf3_bload<4>(b1, A.pl_w2, 16, wave, 4, lane);                      // c7
+        if (t == 3) bf3_bload<4>(b2, A.pl_w2, 16, wave, 8, lane);                      // c8
+        __builtin_amdgcn_sched_barrier(0);
+        const int cu = (4 * wave + t) * 16 + li;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float u = (acc0[i] + acc1[i]) + b_1[t];
+            const float f = gelu_f(u);
+            const size_t o = (size_t)(row0 + 4 * q + i) * (4 * H) + cu;
+            A.u[o] = u;
+            A.f1[o] = f;
+            bf3_store1(imgF, kF3P4, 4 * q + i, cu, f);
+        }
+    }
+    __syncthreads();
+    R3D_CHAIN_MARK(A.timeline, wg == 0, 4);
+    // ---- stage 4: x3 = x1 (+ x0) + f1 . W2^T + b2 ; y = fuser.norm(x3) ; fused = mean over the token pair
+    acc0 = zero; acc1 = zero;
+    bf3_chunk<4>(imgF, kF3P4, li, q, 0, b0, acc0, acc1);                               // c6
+    __builtin_amdgcn_sched_barrier(0);
+    bf3_bload<4>(b0, A.pl_w2, 16, wave, 12, lane);                                     // c9
+    __builtin_amdgcn_sched_barrier(0);
+    bf3_chunk<4>(imgF, kF3P4, li, q, 4, b1, acc0, acc1);                               // c7
+    __builtin_amdgcn_sched_barrier(0);
+    bf3_bload<4>(b1, A.pl_wkv, 4, wave, 0, lane);                                      // c10
+    __builtin_amdgcn_sched_barrier(0);
+    bf3_chunk<4>(imgF, kF3P4, li, q, 8, b2, acc0, acc1);                               // c8
+    __builtin_amdgcn_sched_barrier(0);
+    bf3_bload<4>(b2, A.pl_wkv, 4, wave + 8, 0, lane);                                  // c11
+    __builtin_amdgcn_sched_barrier(0);
+    bf3_chunk<4>(imgF, kF3P4, li, q, 12, b0, acc0, acc1);                              // c9
+    __builtin_amdgcn_sched_barrier(0);
+    bf3_bload<4>(b0, A.pl_wseg, 4, has12 ? wave : 0, 0, lane);                         // c12
+    __builtin_amdgcn_sched_barrier(0);
+    R3D_CHAIN_MARK(A.timeline, wg == 0, 5);
+    float x3[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        x3[i] = (acc0[i] + acc1[i]) + b_2 + x1[i] + (A.add_xres ? x0[i] : 0.f);
+        A.x3[(size_t)(row0 + 4 * q + i) * H + c] = x3[i];
+    }
+    fc_layernorm(x3, red, wave, li, q, mean, rstd);
+    float y[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        y[i] = (x3[i] - mean[i]) * rstd[i] * gF + beF;
+        if (A.y) A.y[(size_t)(row0 + 4 * q + i) * H + c] = y[i];
+        if (wave == 0 && li == 0) { A.mf[row0 + 4 * q + i] = mean[i]; A.rf[row0 + 4 * q + i] = rstd[i]; }
+    }
+    {
+        const float fu0 = (y[0] + y[1]) * 0.5f, fu1 = (y[2] + y[3]) * 0.5f;
+        A.fused[(size_t)f0 * H + c] = fu0;
+        A.fused[(size_t)(f0 + 1) * H + c] = fu1;
+        bf3_store1(imgV, kF3P1, 2 * q, c, fu0);
+        bf3_store1(imgV, kF3P1, 2 * q + 1, c, fu1);
+        bf3_store1(imgV, kF3P1, 8 + 2 * q, c, fu0 + pos0);
+        bf3_store1(imgV, kF3P1, 8 + 2 * q + 1, c, fu1 + pos1);
+    }
+    __syncthreads();
+    R3D_CHAIN_MARK(A.timeline, wg == 0, 6);
+    // ---- stage 5: cakv (output rows 8-15) ; seg (output rows 0-7)
+    const int fr = (row0 >> 1) + ((4 * q) & 7);
+    acc0 = zero; acc1 = zero;
+    bf3_chunk<4>(imgV, kF3P1, li, q, 0, b1, acc0, acc1);                               // c10
+    if (q >= 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) A.cakv[(size_t)(fr + i) * (2 * H) + wave * 16 + li] = (acc0[i] + acc1[i]) + bkv0;
+    }
+    acc0 = zero; acc1 = zero;
+    bf3_chunk<4>(imgV, kF3P1, li, q, 0, b2, acc0, acc1);                               // c11
+    if (q >= 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) A.cakv[(size_t)(fr + i) * (2 * H) + (wave + 8) * 16 + li] = (acc0[i] + acc1[i]) + bkv1;
+    }
+    if (has12) {
+        acc0 = zero; acc1 = zero;
+        bf3_chunk<4>(imgV, kF3P1, li, q, 0, b0, acc0, acc1);                           // c12
+        if (q < 2 && cseg < A.K) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) A.seg[(size_t)(fr + i) * A.K + cseg] = (acc0[i] + acc1[i]) + bsg;
+        }
+    }
+    R3D_CHAIN_MARK(A.timeline, wg == 0, 7);
+}
+
+__global__ __launch_bounds__(512) void fuser_chain_fwd_bf3_kernel(const FcFwd A) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    if (threadIdx.x >= 256) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(2);
+    const int nf = (2 * A.N) / kFcRows;
+    if ((int)blockIdx.x < nf) fc3_fwd_fuser(A, (int)blockIdx.x, lds);
+    else fc_fwd_query(A, (int)blockIdx.x - nf, lds);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// operand-order bf16x3 planes of the chain weights (chain_bf3.h): one wave per (tile, k-step) block of one job
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void weight_planes_kernel(const r3d_plane_job* __restrict__ jobs, int njobs, int total) {
+    const int lane = threadIdx.x & 63;
+    const int blk = (int)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (blk >= total) return;
+    int j = 0;
+    for (int t = 1; t < njobs; ++t) j += (blk >= jobs[t].first_block) ? 1 : 0;
+    const r3d_plane_job J = jobs[j];
+    const int ksteps = (J.K + 31) / 32;
+    const int local = blk - J.first_block, t = local / ksteps, s = local - t * ksteps;
+    const int n = 16 * t + (lane & 15), k0 = 32 * s + 8 * (lane >> 4);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = k0 + e;
+        const bool in = n < J.N && k < J.K;
+        const size_t idx = J.transposed ? (size_t)(in ? k : 0) * J.ld + (in ? n : 0) : (size_t)(in ? n : 0) * J.ld + (in ? k : 0);
+        const float x = J.src[idx];
+        v[e] = in ? x : 0.f;
+    }
+    uint4 h, m, l;
+    {
+        unsigned hh[4], mm[4], ll[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            unsigned short h0, m0, l0, h1, m1, l1;
+            bf3_split1(v[2 * p], h0, m0, l0);
+            bf3_split1(v[2 * p + 1], h1, m1, l1);
+            hh[p] = (unsigned)h0 | ((unsigned)h1 << 16);
+            mm[p] = (unsigned)m0 | ((unsigned)m1 << 16);
+            ll[p] = (unsigned)l0 | ((unsigned)l1 << 16);
+        }
+        h = make_uint4(hh[0], hh[1], hh[2], hh[3]);
+        m = make_uint4(mm[0], mm[1], mm[2], mm[3]);
+        l = make_uint4(ll[0], ll[1], ll[2], ll[3]);
+    }
+    uint4* dst = reinterpret_cast<uint4*>(J.dst) + (size_t)local * (3 * 64) + lane;
+    dst[0] = h;
+    dst[64] = m;
+    dst[128] = l;
 }
 
 __global__ __launch_bounds__(512) void fuser_chain_fwd_kernel(const FcFwd A) {
@@ -854,7 +1089,29 @@ R3D_EXPORT int r3d_fuser_chain_fwd(const r3d_fuser_chain_fwd_args* a, void* stre
                                        r3d::kFcLdsBytes);
     if (e != hipSuccess) return (int)e;
     const int grid = (2 * a->N) / r3d::kFcRows + (a->B * a->Q) / r3d::kFcRows;
+    if (a->pl_wv) {               // weights pre-split into operand-order bf16 planes: the fuser role on the bf16 matrix cores
+        R3D_REQUIRE(a->pl_wproj && a->pl_w1 && a->pl_w2 && a->pl_wkv && a->pl_wseg);
+        const int ldsb = r3d::kFcLdsBytes > r3d::kF3LdsBytes ? r3d::kFcLdsBytes : r3d::kF3LdsBytes;     // (query role: fp32 layout)
+        e = hipFuncSetAttribute((const void*)r3d::fuser_chain_fwd_bf3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(r3d::fuser_chain_fwd_bf3_kernel, dim3(grid), dim3(512), (size_t)ldsb, (hipStream_t)stream, *a);
+        R3D_LAUNCH_CHECK();
+        return R3D_OK;
+    }
     hipLaunchKernelGGL(r3d::fuser_chain_fwd_kernel, dim3(grid), dim3(512), (size_t)r3d::kFcLdsBytes, (hipStream_t)stream, *a);
+    R3D_LAUNCH_CHECK();
+    return R3D_OK;
+}
+
+/* bf16 elements of the operand-order planes of an N x K matrix (three planes, zero-padded to whole 16 x 32 blocks). */
+R3D_EXPORT int64_t r3d_weight_plane_elems(int N, int K) { return N > 0 && K > 0 ? (int64_t)r3d::bf3_plane_elems(N, K) : 0; }
+
+/* Writes the bf16x3 operand-order planes of njobs matrices (chain_bf3.h) in one launch.  jobs: DEVICE array; first_block of
+ * job j = sum over i < j of ceil(N_i / 16) * ceil(K_i / 32); total_blocks = that sum over all jobs. */
+R3D_EXPORT int r3d_weight_planes(const r3d_plane_job* jobs_device, int njobs, int total_blocks, void* stream) {
+    R3D_REQUIRE(jobs_device && njobs > 0 && total_blocks > 0);
+    hipLaunchKernelGGL(r3d::weight_planes_kernel, dim3(r3d_cdiv(total_blocks, 4)), dim3(256), 0, (hipStream_t)stream, jobs_device,
+                       njobs, total_blocks);
     R3D_LAUNCH_CHECK();
     return R3D_OK;
 }

@@ -184,9 +184,17 @@ using namespace r3d;
 // workgroups per CU stream best -- 0.65 - 0.73 of 8 TB/s against 0.60 - 0.63 with 4096 workgroups, whose 28 concurrent
 // streams per CU scatter over more DRAM pages; inside the cache 4096 stay 0.5 us ahead (more requests in flight).
 static inline int adam_blocks(size_t n4) {
-    int cap = (n4 * 64 > ((size_t)200 << 20)) ? 768 : 4096;
-    if (const char* e = getenv("R3D_ADAMW_BLOCKS")) cap = atoi(e);
-    return (int)((n4 + 255) / 256 < (size_t)cap ? (n4 + 255) / 256 : (size_t)cap);
+    // (the override is read once: an entry point must not call getenv per launch; a value that is not a positive number --
+    //  "0", "abc" -- is ignored instead of turning into a 0-block launch)
+    static const int forced = [] {
+        const char* e = getenv("R3D_ADAMW_BLOCKS");
+        const int v = e ? atoi(e) : 0;
+        return v > 0 ? v : 0;
+    }();
+    const int cap = forced ? forced : ((n4 * 64 > ((size_t)200 << 20)) ? 768 : 4096);
+    const size_t want = (n4 + 255) / 256;
+    const size_t blocks = want < (size_t)cap ? want : (size_t)cap;
+    return (int)(blocks > 0 ? blocks : 1);
 }
 
 R3D_EXPORT int r3d_adamw_flat(float* p, const float* g, float* m, float* v, int64_t n, const float* lr, const int64_t* step,

@@ -215,6 +215,11 @@ class FusionEngine:
         # tail, the losses and the way back to the cross-attention's input gradients) as ONE launch (csrc/decoder_chain.hip)
         # instead of 4 + 1 + 5
         self.use_decoder_chain = True
+        # the chain kernels' products on the bf16 matrix cores: every chain weight (and its transpose) is kept as three bf16
+        # planes in MFMA operand order, rebuilt by one launch per step (ops.WeightPlanes); same exact three-way split and six
+        # products as depth_prec = 1.  False: the exact-fp32 MFMA chain kernels
+        self.chain_bf3 = True
+        self._planes = None
         # fused training flows (forward -> losses(tick=True) -> backward -> adamw(ticked=True)) may set this: the loss
         # kernel then leaves the reduction of its per-unit partials (loss / counter statistics only the host reads) to
         # one extra workgroup of the AdamW launch -- w.loss / w.counts are valid after adamw(), not after losses()
@@ -324,6 +329,7 @@ class FusionEngine:
         assert x_rgb.shape[1] == self.D and x_dep.shape[1] == self.P, (x_rgb.shape, x_dep.shape, self.D, self.P)
         assert x_rgb.is_contiguous() and x_dep.is_contiguous()
         w = self._shape(B, S, need_grad)
+        self._loss_pending = None          # (see losses(): a pending loss reduction never survives into another step)
         self._erank_join()                 # (a forward whose backward never ran: its sweep still reads the workspace)
         drop = training and need_grad and self.dropout_enabled
         if drop:
@@ -597,6 +603,20 @@ class FusionEngine:
         self._erank_join()
         return self.last["w"].er_stats[0, 0]
 
+    def chain_planes(self):
+        """The bf16x3 planes of the chain kernels' weights (built on first use; refresh() re-splits the current parameters)."""
+        if self._planes is None:
+            a, H = self.arena, self.H
+            pre, pl = "fuser.blocks.0.", "transformer.decoder.layers.0."
+            wi = a.p(pl + "multihead_attn.in_proj_weight")
+            W = dict(wv=a.p(pre + "attn.qkv.weight")[2 * H:], wproj=a.p(pre + "attn.proj.weight"), w1=a.p(pre + "mlp.mlp.0.weight"),
+                     w2=a.p(pre + "mlp.mlp.2.weight"), wkv=wi[H:], wseg=a.p("fc_seg.weight"))
+            ent = {}
+            for k, w_ in W.items():
+                ent["pl_" + k] = (w_, False)
+            self._planes = ops.WeightPlanes(ent, self.device)
+        return self._planes
+
     def _chain_shape_ok(self, w):
         return bool(not self.bn and self.dh == 16 and ops.fuser_chain_supported(w.N, self.H, self.K, w.B, self.Q, self.heads))
 
@@ -636,8 +656,12 @@ class FusionEngine:
         a, H, Q, S, B, BQ, heads, dh = self.arena, self.H, self.Q, w.S, w.B, w.BQ, self.heads, self.dh
         c, pl = w.layers[0], "transformer.decoder.layers.0."
         if self._chain_ok(w):
-            key = ("fwd_chain", bool(drop))
+            bf3 = bool(self.chain_bf3)
+            key = ("fwd_chain", bool(drop), bf3)
+            if bf3:
+                self.chain_planes().refresh()            # the parameters may have changed since the last forward: re-split
             if key not in w.tables:
+                pls = self.chain_planes() if bf3 else None
                 wi, bi = a.p(pl + "multihead_attn.in_proj_weight"), a.p(pl + "multihead_attn.in_proj_bias")
                 w.tables[key] = ops.FuserChainFwd(
                     x0=w.x0, h1=w.h1, wv=wv, wproj=a.p(pre + "attn.proj.weight"), bproj=a.p(pre + "attn.proj.bias"),
@@ -651,7 +675,8 @@ class FusionEngine:
                     g1=a.p(pl + "norm1.weight"), be1=a.p(pl + "norm1.bias"), wq=wi[:H], bq=bi[:H],
                     drop_sa=dm("sa_p0"), drop_d1=dm("d1_0"), drop_scale=dsc, sa_qkv=c["sa_qkv"], p_sa=c["p_sa"],
                     sa_o=c["sa_o"], t1_pre=c["t1_pre"], t1=c["t1"], m1=c["m1"], r1=c["r1"], caq=c["caq"],
-                    N=w.N, S=S, K=self.K, H=H, add_xres=0 if self.bn else 1, B=B, Q=Q, heads=heads)
+                    N=w.N, S=S, K=self.K, H=H, add_xres=0 if self.bn else 1, B=B, Q=Q, heads=heads,
+                    planes={k: pls.ptr(k) for k in pls.keys} if pls is not None else None)
             w.tables[key].launch()
             self._erank_fork(w)
             return
@@ -830,6 +855,10 @@ class FusionEngine:
         the following adamw(..., ticked=True) needs no launch of its own for that."""
         w = self.last["w"]
         K = self.K
+        # a reduction job left pending by an earlier deferred losses() belongs to THAT step: it may only be consumed by the
+        # adamw() that follows it directly -- never by the optimiser step of another forward (a backward that raised, a flow
+        # that switched to the undeferred reduction)
+        self._loss_pending = None
         ta = self.step_t if tick else None
         tb = self.drop_offset if (tick and self.last["drop"]) else None
         if getattr(w, "_tail_deferred", False):

@@ -338,6 +338,47 @@ def fuser_chain_supported(N, H, K, B, Q, heads):
     return bool(_lib.load().r3d_fuser_chain_supported(N, H, K, B, Q, heads))
 
 
+class WeightPlanes:
+    """bf16x3 operand-order planes (csrc/chain_bf3.h) of a set of weight matrices, rebuilt by ONE launch (refresh()).
+    entries: {key: (tensor [rows, cols] float32 view of the parameter arena, transposed)} -- transposed = False gives the planes
+    of B[n][k] = W[n][k] (y = x W^T products), True those of B[n][k] = W[k][n] (dx = dy W products)."""
+
+    def __init__(self, entries, device):
+        from ._lib import PlaneJob
+        lib = _lib.load()
+        self.keys = list(entries)
+        sizes, offs, total_el, blocks = [], [], 0, 0
+        jobs = (PlaneJob * len(self.keys))()
+        for i, k in enumerate(self.keys):
+            w, tr = entries[k]
+            assert w.dim() == 2 and w.stride(1) == 1 and w.dtype == torch.float32 and w.is_cuda
+            N, K = (w.shape[1], w.shape[0]) if tr else (w.shape[0], w.shape[1])
+            el = int(lib.r3d_weight_plane_elems(N, K))
+            offs.append(total_el)
+            sizes.append((N, K))
+            j = jobs[i]
+            j.src, j.ld, j.N, j.K, j.transposed, j.first_block = w.data_ptr(), w.stride(0), N, K, 1 if tr else 0, blocks
+            total_el += el
+            blocks += ((N + 15) // 16) * ((K + 31) // 32)
+        self.buf = torch.zeros(total_el, dtype=torch.int16, device=device)
+        for i in range(len(self.keys)):
+            jobs[i].dst = self.buf.data_ptr() + 2 * offs[i]
+        raw = bytes(jobs)
+        self.jobs_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+        self.njobs, self.blocks = len(self.keys), blocks
+        self._ptr = {k: self.buf.data_ptr() + 2 * offs[i] for i, k in enumerate(self.keys)}
+        self._view = {k: self.buf[offs[i]:offs[i] + int(lib.r3d_weight_plane_elems(*sizes[i]))] for i, k in enumerate(self.keys)}
+
+    def refresh(self):
+        check(_lib.load().r3d_weight_planes(_p(self.jobs_dev), self.njobs, self.blocks, _stream()), "r3d_weight_planes")
+
+    def ptr(self, key):
+        return self._ptr[key]
+
+    def view(self, key):
+        return self._view[key]
+
+
 class FuserChainFwd:
     """The argument block of r3d_fuser_chain_fwd (csrc/fuser_chain.hip), built once per workspace: every operand is a
     dense row-major tensor whose address is fixed for the life of the workspace (the dropout masks are optional)."""
@@ -348,6 +389,10 @@ class FuserChainFwd:
         dims = {k: t.pop(k) for k in ("N", "S", "K", "H", "add_xres", "B", "Q", "heads")}
         a.drop_scale = float(t.pop("drop_scale", 1.0))
         opt = {"y", "drop_sa", "drop_d1"}
+        planes = t.pop("planes", None)                 # dict name -> device address of the weight's bf16x3 planes, or None
+        if planes is not None:
+            for name in FuserChainFwdArgs._PLANES:
+                setattr(a, name, planes[name])
         for name in FuserChainFwdArgs._PTRS + FuserChainFwdArgs._PTRS2:
             v = t.pop(name, None)
             if v is None:
@@ -797,8 +842,14 @@ def erank_jacobi(x, sigma, stats, *, af_t=None, gram=False, max_sweeps=30):
                                max_sweeps, _stream()), "r3d_erank_jacobi")
 
 
-def erank_blocked(x, max_sweeps=16):
-    """x: [R, C] (row stride >= C).  Returns (sigma [C], stats [4], af_t [Cpad, R] -- a view of the [Cpad, Rp] buffer the
+def erank_blocked(x, max_sweeps=30):
+    """(max_sweeps: the sweeps ENQUEUED -- the launches past convergence are no-ops of ~3 us each.  Fused tokens converge in
+    9-13; a spectrum with clusters of singular values 0.1 % apart at sigma_max / sigma_min = 1e4 needed 19 at [512, 512]
+    (tests/test_kernels_gpu.py::test_erank_clustered_and_ill_conditioned_spectra), and an unconverged sweep leaves an
+    effective rank that is still right to 1e-3 but a gradient that is not -- so the differentiable op enqueues 30; the
+    training step, where every no-op launch sits in the replayed graph, enqueues engine.erank_max_sweeps = 16 and the
+    test of the step asserts that convergence came earlier.)
+    x: [R, C] (row stride >= C).  Returns (sigma [C], stats [4], af_t [Cpad, R] -- a view of the [Cpad, Rp] buffer the
     kernel sweeps, Rp = R rounded up to 4) -- any size, columns in HBM."""
     import ctypes
     lib = _lib.load()

@@ -736,6 +736,71 @@ def test_erank_blocked_vs_svdvals(ops, R, Cc):
     assert float((xg.grad.cpu().double() - xr.grad).abs().max()) < 2e-3 * sc
 
 
+@pytest.mark.parametrize("R,Cc,route", [(128, 128, "lds"), (256, 128, "lds"), (512, 512, "blocked"), (256, 1024, "blocked")])
+def test_erank_clustered_and_ill_conditioned_spectra(ops, R, Cc, route):
+    """the sweeps stop after the first sweep that starts with every coupling below 1e-2 -- quadratic convergence
+    leaves ~1e-4, but only for SEPARATED singular values.  A spectrum with CLUSTERS (groups of singular values 0.1 % apart:
+    neither duplicate nor rank-deficient, so tan 2 theta = 2 gamma / (alpha - beta) is not small although gamma is) and a
+    conditioning of 1e4 -- the regime of the fused tokens -- pins sigma, the effective rank and the gradient at 3e-3 (the
+    tolerance before the early stop; the Neumann-corrected backward of round 3 is what makes the ill-conditioned half pass)."""
+    from r3d_amd.erank import effective_rank
+    k = min(R, Cc)
+    q1 = torch.linalg.qr(rnd(R, k, seed=R + 3 * Cc).double())[0]
+    q2 = torch.linalg.qr(rnd(Cc, k, seed=R + 3 * Cc + 1).double())[0]
+    base = torch.logspace(0, -4, k // 4, dtype=torch.float64)                   # sigma_max / sigma_min = 1e4
+    sv_true = (base[:, None] * (1.0 + 1e-3 * torch.arange(4, dtype=torch.float64))[None, :]).reshape(-1)[:k]
+    sv_true = torch.sort(sv_true, descending=True)[0] * 50.0
+    if sv_true.numel() < k:
+        sv_true = torch.cat([sv_true, sv_true[-1:].repeat(k - sv_true.numel()) * 0.5])
+    x = (q1 @ torch.diag(sv_true) @ q2.t()).float()
+    xg = dev(x).clone().requires_grad_(True)
+    er = effective_rank(xg, route=route)
+    er.backward()
+    torch.cuda.synchronize()
+    if route == "blocked":
+        xx = dev(x.t().contiguous() if R < Cc else x)
+        _, st_, _ = ops.erank_blocked(xx, max_sweeps=30)
+        torch.cuda.synchronize()
+        print(f"[erank clustered {R}x{Cc}] two-level sweeps to convergence: {float(st_[3]):.0f}")
+    xr = x.double().clone().requires_grad_(True)
+    s = torch.linalg.svdvals(xr)
+    p = s / s.sum()
+    ref = torch.exp(-(p * torch.log(p)).sum())
+    ref.backward()
+    assert abs(float(er.detach()) - float(ref.detach())) < 3e-3 * max(1.0, float(ref.detach()) / 50), (float(er), float(ref))
+    sc = float(xr.grad.abs().max())
+    err = float((xg.grad.cpu().double() - xr.grad).abs().max()) / sc
+    print(f"[erank clustered {R}x{Cc} {route}] erank {float(er):.4f} vs {float(ref):.4f}, gradient error / scale {err:.2e}")
+    assert err < 3e-3, err
+
+
+@pytest.mark.parametrize("N,K,tr", [(128, 128, False), (17, 128, False), (128, 17, True), (512, 128, True), (128, 512, False)])
+def test_weight_planes_are_an_exact_three_way_split_in_operand_order(ops, N, K, tr):
+    """r3d_weight_planes (csrc/chain_bf3.h): for every element h + m + l == w EXACTLY (truncation split), the element sits where
+    the MFMA's lane reads it, and the padding of partial tiles / k-steps is zero."""
+    rows, cols = (K, N) if tr else (N, K)
+    wt = rnd(rows, cols, seed=N + 3 * K)
+    wp = ops.WeightPlanes({"w": (dev(wt), tr)}, torch.device("cuda"))
+    wp.refresh()
+    torch.cuda.synchronize()
+    raw = wp.view("w").cpu().view(torch.int16)
+    tiles, ksteps = (N + 15) // 16, (K + 31) // 32
+    pl = raw.view(tiles, ksteps, 3, 64, 8).to(torch.int32)
+    vals = ((pl & 0xFFFF) << 16).contiguous().view(torch.float32).double()      # bf16 bits -> fp32 values [t, s, plane, lane, e]
+    B = wt.t().contiguous() if tr else wt                                       # B[n][k]
+    want = torch.zeros(tiles * 16, ksteps * 32, dtype=torch.float64)
+    want[:N, :K] = B.double()
+    lane = torch.arange(64)
+    n_idx = (torch.arange(tiles)[:, None, None, None] * 16 + (lane % 16)[None, None, :, None]).expand(tiles, ksteps, 64, 8)
+    k_idx = (torch.arange(ksteps)[None, :, None, None] * 32 + (8 * (lane // 16))[None, None, :, None] +
+             torch.arange(8)[None, None, None, :]).expand(tiles, ksteps, 64, 8)
+    got = vals.sum(dim=2)                                                       # h + m + l in fp64: exact
+    assert torch.equal(got, want[n_idx, k_idx]), float((got - want[n_idx, k_idx]).abs().max())
+    # the planes are ordered by magnitude: |m| <= 2^-8 |h|, |l| <= 2^-16 |h| (where h != 0)
+    h, m, l = vals[:, :, 0].abs(), vals[:, :, 1].abs(), vals[:, :, 2].abs()
+    assert bool((m <= h * 2.0 ** -7).all()) and bool((l <= h * 2.0 ** -15).all())
+
+
 def test_attention_cores_as_riders_equal_their_own_launches(ops):
     """The small attention core carried as extra workgroups of r3d_gemm_ln_mha_fwd / r3d_layernorm_bwd_multi_mha
     (mha_small.h: one (clip, head) unit per wave) writes bit for bit what r3d_mha_core_fwd / _bwd write on their own, and

@@ -24,6 +24,8 @@ def main():
     tl = {}
     for key, obj in w.tables.items():
         if key[0] in ("fwd_chain", "bwd_chain", "dec_chain") and hasattr(obj, "args"):
+            if key[0] in tl:
+                continue
             t = torch.zeros(32, dtype=torch.int64, device=dev)
             obj.args.timeline = t.data_ptr()
             tl[key[0]] = t

@@ -31,5 +31,13 @@ for W in erank adamw; do
   cp $(find $O/${W}_stats -name "*kernel_stats.csv" | head -1) $O/${W}_kernel_stats.csv
 done
 for c in cfg3 cfg4 cfg5; do timeout -k 10 200 python3 $R/bench.py --config $c --steps 50 --no-cpu-baseline > $O/bench_$c.json 2>/dev/null; cut -c1-200 $O/bench_$c.json; done
+timeout -k 10 200 python3 $R/bench.py --steps 200 --no-cpu-baseline --erank-weight 0.05 > $O/bench_erank_in_step.json 2>/dev/null; cut -c1-200 $O/bench_erank_in_step.json
+timeout -k 10 300 python3 $R/bench.py --config cfg4 --steps 50 --no-cpu-baseline --erank-weight 0.05 > $O/bench_cfg4_erank_in_step.json 2>/dev/null; cut -c1-200 $O/bench_cfg4_erank_in_step.json
+timeout -k 10 200 python3 $R/tools/chain_timeline.py --graph > $O/chain_timeline.txt 2>&1
+# matrix-core utilisation of every MFMA kernel of the step: one PMC pass (no trace domains besides kernel-trace)
+timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA --kernel-trace --output-format csv -d $O/pmc_mfma -o m -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/pmc_mfma.log 2>&1; echo "mfma rc=$?"
+MC=$(find $O/pmc_mfma -name "*counter_collection.csv" | head -1); MT=$(find $O/pmc_mfma -name "*kernel_trace.csv" | head -1)
+python3 $R/tools/mfma_util.py "$MC" "$MT" $O/mfma_util.csv > $O/mfma_util.log 2>&1; tail -12 $O/mfma_util.log
+bash $R/tools/step_trace.sh final/trace > $O/trace.log 2>&1; cp $O/trace/one_step.txt $O/step_trace.txt
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete; find $O -name "*agent_info.csv" -delete
 ls $O | head -50

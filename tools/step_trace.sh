@@ -13,7 +13,9 @@ import csv, glob
 f = glob.glob("stats/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "adamw_dropout" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "adamw_dropout_fin" in r["Kernel_Name"]]      # (the step's variant; bench.py's
+if len(idx) < 3:                                                                        #  roofline timing loop runs the plain one)
+    idx = [i for i, r in enumerate(rows) if "adamw" in r["Kernel_Name"]]
 a, b = idx[-3], idx[-2]
 prev = None
 with open("one_step.txt", "w") as out:
