@@ -323,6 +323,10 @@ typedef struct r3d_fuser_chain_bwd_args {
     float drop_scale;
     int32_t N, S, K, H, add_xres, B, Q, heads;
     uint64_t* timeline;      /* as in r3d_fuser_chain_fwd_args */
+    /* optional (all or none; K <= 32): bf16x3 operand-order planes of the TRANSPOSED weights (r3d_plane_job::transposed = 1) of
+     * wkv, wseg, w2, w1, wproj, wv -- the fuser role's input-gradient products then run on the bf16 matrix cores */
+    const uint16_t* pl_wkv_t; const uint16_t* pl_wseg_t; const uint16_t* pl_w2_t; const uint16_t* pl_w1_t;
+    const uint16_t* pl_wproj_t; const uint16_t* pl_wv_t;
 } r3d_fuser_chain_bwd_args;
 int r3d_fuser_chain_bwd(const r3d_fuser_chain_bwd_args* a, void* stream);
 
@@ -516,6 +520,10 @@ typedef struct r3d_decoder_chain_args {
     int32_t pad_idx, B, S, H, Q, heads, phases;
     uint64_t* timeline;      /* profiling aid, normally NULL: wave 0 of clip 0 stores wall_clock64() (100 MHz) at its stage
                                 boundaries [0..31] */
+    /* optional (all or none): bf16x3 operand-order planes (r3d_weight_planes) of wo, w1, w2 and of their transposes -- the
+     * products then run on the bf16 matrix cores */
+    const uint16_t* pl_wo; const uint16_t* pl_w1; const uint16_t* pl_w2; const uint16_t* pl_w2_t; const uint16_t* pl_w1_t;
+    const uint16_t* pl_wo_t;
 } r3d_decoder_chain_args;
 int r3d_decoder_chain_supported(int H, int Q, int heads, int S);
 int r3d_decoder_chain(const r3d_decoder_chain_args* d, const r3d_tail_losses_args* tail, float* ws, void* stream);

@@ -89,8 +89,10 @@ class FuserChainBwdArgs(C.Structure):
              "dep_pre mean_d rstd_d lnd_g lnd_b d_fused d_x3 d_u d_h2 d_x1 d_v d_h1 d_rgb_pre d_dep_pre part_nf part_n2 "
              "part_n1 part_dep d_caq d_t1_res wq t1_pre m1d r1d g1d drop_d1 w_out sa_qkv p_sa drop_sa w_in caqin t1pre_out "
              "sap sao saqkv sain part_d1").split()
+    _PLANES = "pl_wkv_t pl_wseg_t pl_w2_t pl_w1_t pl_wproj_t pl_wv_t".split()
     _fields_ = ([(n, C.c_void_p) for n in _PTRS] + [("drop_scale", C.c_float)] +
-                [(n, C.c_int32) for n in "N S K H add_xres B Q heads".split()] + [("timeline", C.c_void_p)])
+                [(n, C.c_int32) for n in "N S K H add_xres B Q heads".split()] + [("timeline", C.c_void_p)] +
+                [(n, C.c_void_p) for n in _PLANES])
 
 
 class DecoderChainArgs(C.Structure):
@@ -98,7 +100,8 @@ class DecoderChainArgs(C.Structure):
     _PTRS = ("caq cakv key_label p_ca drop_ca ca_o wo bo drop_d2 t1 t2_pre g2 be2 t2 m2 r2 w1 b1 drop_ff ff1 w2 b2 drop_d3 "
              "t3_pre d_t3pre d_ff2 d_ff1 d_t2pre d_cap d_cao d_caq d_cakv part_d2").split()
     _fields_ = ([(n, C.c_void_p) for n in _PTRS] + [("drop_scale", C.c_float)] +
-                [(n, C.c_int32) for n in "pad_idx B S H Q heads phases".split()] + [("timeline", C.c_void_p)])
+                [(n, C.c_int32) for n in "pad_idx B S H Q heads phases".split()] + [("timeline", C.c_void_p)] +
+                [(n, C.c_void_p) for n in "pl_wo pl_w1 pl_w2 pl_w2_t pl_w1_t pl_wo_t".split()])
 
 
 class MhaJob(C.Structure):

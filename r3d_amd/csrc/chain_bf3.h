@@ -65,30 +65,16 @@ __device__ __forceinline__ void bf3_store1(unsigned short* img, int pitch, int r
     p[32 * pitch] = l;
 }
 // four consecutive-k values of one row (a staged global load) -> 8-byte stores into the three planes
+// (each value through bf3_split1: a pair-wise v_perm_b32 form of this split measured 4.6e-5 instead of 1.6e-7 against fp64 in
+//  tools/bf3_probe2.hip although it reconstructs exactly when emulated -- not pursued: staging runs once per kernel)
 __device__ __forceinline__ void bf3_store4(unsigned short* img, int pitch, int row, int col, const f32x4 x) {
-    unsigned h0, m0, l0, h1, m1, l1;
-    {   // pairs (x0, x1), (x2, x3): element k in the low half of the dword
-        const unsigned u0 = __builtin_bit_cast(unsigned, x[0]), u1 = __builtin_bit_cast(unsigned, x[1]);
-        h0 = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
-        const float r0 = x[0] - __builtin_bit_cast(float, u0 & 0xffff0000u), r1 = x[1] - __builtin_bit_cast(float, u1 & 0xffff0000u);
-        const unsigned v0 = __builtin_bit_cast(unsigned, r0), v1 = __builtin_bit_cast(unsigned, r1);
-        m0 = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
-        const float q0 = r0 - __builtin_bit_cast(float, v0 & 0xffff0000u), q1 = r1 - __builtin_bit_cast(float, v1 & 0xffff0000u);
-        l0 = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, q1), __builtin_bit_cast(unsigned, q0), 0x07060302u);
-    }
-    {
-        const unsigned u0 = __builtin_bit_cast(unsigned, x[2]), u1 = __builtin_bit_cast(unsigned, x[3]);
-        h1 = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
-        const float r0 = x[2] - __builtin_bit_cast(float, u0 & 0xffff0000u), r1 = x[3] - __builtin_bit_cast(float, u1 & 0xffff0000u);
-        const unsigned v0 = __builtin_bit_cast(unsigned, r0), v1 = __builtin_bit_cast(unsigned, r1);
-        m1 = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
-        const float q0 = r0 - __builtin_bit_cast(float, v0 & 0xffff0000u), q1 = r1 - __builtin_bit_cast(float, v1 & 0xffff0000u);
-        l1 = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, q1), __builtin_bit_cast(unsigned, q0), 0x07060302u);
-    }
+    unsigned short h[4], m[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bf3_split1(x[e], h[e], m[e], l[e]);
     unsigned short* p = img + row * pitch + col;
-    *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
-    *reinterpret_cast<uint2*>(p + 16 * pitch) = make_uint2(m0, m1);
-    *reinterpret_cast<uint2*>(p + 32 * pitch) = make_uint2(l0, l1);
+    *reinterpret_cast<uint2*>(p) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+    *reinterpret_cast<uint2*>(p + 16 * pitch) = make_uint2((unsigned)m[0] | ((unsigned)m[1] << 16), (unsigned)m[2] | ((unsigned)m[3] << 16));
+    *reinterpret_cast<uint2*>(p + 32 * pitch) = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
 }
 
 // A operands of one k-step: lane (row li, k group q) reads 16 bytes of each plane at k = 32 s + 8 q

@@ -1051,6 +1051,264 @@ __device__ __forceinline__ void fc_bwd_query(const FcBwd& A, const int wgq, floa
     for (int i = 0; i < 4; ++i) A.sain[(size_t)(row0 + 4 * q + i) * H + c] = acc0[i] + acc1[i];
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// backward, fuser role on the bf16 matrix cores: with the planes of the TRANSPOSED weights every input-gradient product is a
+// y = x B^T product like the forward ones (no k-major staging); stages as fc_bwd_fuser
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void fc3_bwd_fuser(const FcBwd& A, const int wg, float* lds) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, q = lane >> 4;
+    unsigned short* img = reinterpret_cast<unsigned short*>(lds);
+    unsigned short* imgH = img + kF3ImgH;
+    unsigned short* imgV = img + kF3ImgV;
+    unsigned short* imgF = img + kF3ImgF;
+    float* redA = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(lds) + kF3RedBytes);
+    float* redB = redA + 2 * 8 * kFcRows;
+    constexpr int H = kFcH;
+    const int row0 = wg * kFcRows;
+    const int c = wave * 16 + li;
+    const int f0 = (row0 >> 1) + 2 * q;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    R3D_CHAIN_MARK(A.timeline, wg == 0, 0);
+    Bf3B b0, b1, b2;
+    bf3_bload<4>(b0, A.pl_wkv_t, 8, wave, 0, lane);                                    // c0: (Wkv)^T, k-steps 0..3
+    bf3_bload<4>(b1, A.pl_wkv_t, 8, wave, 4, lane);                                    // c1: k-steps 4..7
+    bf3_bload<1>(b2, A.pl_wseg_t, 1, wave, 0, lane);                                   // c2: (Wseg)^T, K <= 32
+    {
+        // A operand of stage 0: row r <- [d_cakv[frame r >> 1] (256) | d_seg[frame] zero-padded to 32]
+        const int r = tid >> 5, c4 = tid & 31, fr = (row0 >> 1) + (r >> 1);
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(A.d_cakv + (size_t)fr * (2 * H) + 4 * c4);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(A.d_cakv + (size_t)fr * (2 * H) + 128 + 4 * c4);
+        f32x4 v2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = 4 * (c4 & 7) + e;
+            const float t = A.d_seg[(size_t)fr * A.K + (k < A.K ? k : A.K - 1)];
+            v2[e] = k < A.K ? t : 0.f;
+        }
+        bf3_store4(imgF, kF3P4, r, 4 * c4, v0);
+        bf3_store4(imgF, kF3P4, r, 128 + 4 * c4, v1);
+        if (c4 < 8) bf3_store4(imgF, kF3P4, r, 256 + 4 * c4, v2);
+    }
+    float x3v[4], mfv[4], rfv[4], dex[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = row0 + 4 * q + i;
+        x3v[i] = A.x3[(size_t)r * H + c]; mfv[i] = A.mf[r]; rfv[i] = A.rf[r];
+    }
+    const float gF = A.gf[c];
+    {
+        const float* ex = A.d_extra ? A.d_extra : A.gf;
+        const int ld = A.d_extra ? H : 0;
+        dex[0] = ex[(size_t)f0 * ld + c]; dex[1] = ex[(size_t)(f0 + 1) * ld + c];
+        if (!A.d_extra) { dex[0] = 0.f; dex[1] = 0.f; }
+    }
+    __syncthreads();
+    R3D_CHAIN_MARK(A.timeline, wg == 0, 1);
+    f32x4 acc0 = zero, acc1 = zero;
+    // ---- stage 0: d(memory + pos) = d_cakv . Wkv (kept: pos_embedding's gradient), then + d_seg . Wseg
+    bf3_chunk<4>(imgF, kF3P4, li, q, 0, b0, acc0, acc1);                               // c0
+    __builtin_amdgcn_sched_barrier(0);
+    bf3_bload<4>(b0, A.pl_w2_t, 4, 4 * wave + 0, 0, lane);                             // c3: (W2)^T tile 4w
+    __builtin_amdgcn_sched_barrier(0);
+    bf3_chunk<4>(imgF, kF3P4, li, q, 4, b1, acc0, acc1);                               // c1
+    __builtin_amdgcn_sched_barrier(0);
+    bf3_bload<4>(b1, A.pl_w2_t, 4, 4 * wave + 1, 0, lane);                             // c4
+    __builtin_amdgcn_sched_barrier(0);
+    A.d_fused[(size_t)f0 * H + c] = acc0[0] + acc1[0];
+    A.d_fused[(size_t)(f0 + 1) * H + c] = acc0[2] + acc1[2];
+    bf3_chunk<1>(imgF, kF3P4, li, q, 8, b2, acc0, acc1);                               // c2
+    __builtin_amdgcn_sched_barrier(0);
+    bf3_bload<4>(b2, A.pl_w2_t, 4, 4 * wave + 2, 0, lane);                             // c5
+    __builtin_amdgcn_sched_barrier(0);
+    R3D_CHAIN_MARK(A.timeline, wg == 0, 2);
+    // ---- stage 1: fuser.norm backward
+    float dx3[4];
+    {
+        float d[4], xh[4], g[4], gx[4], s1v[4], s2v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            d[i] = 0.5f * ((acc0[i] + acc1[i]) + dex[i >> 1]);
+            xh[i] = (x3v[i] - mfv[i]) * rfv[i];
+            g[i] = d[i] * gF;
+            gx[i] = g[i] * xh[i];
+        }
+        float* pp = A.part_nf + (size_t)(wg * 4 + q) * (2 * H);
+        pp[c] = (d[0] * xh[0] + d[1] * xh[1]) + (d[2] * xh[2] + d[3] * xh[3]);
+        pp[H + c] = (d[0] + d[1]) + (d[2] + d[3]);
+        fb_rowsum2<4>(g, gx, redA, wave, li, q, s1v, s2v);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            dx3[i] = rfv[i] * (g[i] - s1v[i] - xh[i] * s2v[i]);
+            A.d_x3[(size_t)(row0 + 4 * q + i) * H + c] = dx3[i];
+            bf3_store1(imgH, kF3P1, 4 * q + i, c, dx3[i]);
+        }
+    }
+    float uv[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) uv[t][i] = A.u[(size_t)(row0 + 4 * q + i) * (4 * H) + (4 * wave + t) * 16 + li];
+    }
+    __syncthreads();
+    R3D_CHAIN_MARK(A.timeline, wg == 0, 3);
+    // ---- stage 2: d_u = (d_x3 . W2) * GELU'(u)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        acc0 = zero; acc1 = zero;
+        if (t == 0) bf3_chunk<4>(imgH, kF3P1, li, q, 0, b0, acc0, acc1);               // c3
+        if (t == 1) bf3_chunk<4>(imgH, kF3P1, li, q, 0, b1, acc0, acc1);               // c4
+        if (t == 2) bf3_chunk<4>(imgH, kF3P1, li, q, 0, b2, acc0, acc1);               // c5
+        if (t == 3) bf3_chunk<4>(imgH, kF3P1, li, q, 0, b0, acc0, acc1);               // c6
+        __builtin_amdgcn_sched_barrier(0);
+        if (t == 0) bf3_bload<4>(b0, A.pl_w2_t, 4, 4 * wave + 3, 0, lane);             // c6
+        if (t == 1) bf3_bload<4>(b1, A.pl_w1_t, 16, wave, 0, lane);                    // c7: (W1)^T, k-steps 0..3
+        if (t == 2) bf3_bload<4>(b2, A.pl_w1_t, 16, wave, 4, lane);                    // c8
+        if (t == 3) bf3_bload<4>(b0, A.pl_w1_t, 16, wave, 8, lane);                    // c9
+        __builtin_amdgcn_sched_barrier(0);
+        const int cu = (4 * wave + t) * 16 + li;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float du = (acc0[i] + acc1[i]) * gelu_grad_f(uv[t][i]);
+            A.d_u[(size_t)(row0 + 4 * q + i) * (4 * H) + cu] = du;
+            bf3_store1(imgF, kF3P4, 4 * q + i, cu, du);
+        }
+    }
+    float x1v[4], m2v[4], r2v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = row0 + 4 * q + i;
+        x1v[i] = A.x1[(size_t)r * H + c]; m2v[i] = A.m2[r]; r2v[i] = A.r2[r];
+    }
+    const float g2 = A.g2[c];
+    __syncthreads();
+    R3D_CHAIN_MARK(A.timeline, wg == 0, 4);
+    // ---- stage 3: d_h2 = d_u . W1 ; norm2 backward ; d_x1 = that + d_x3
+    acc0 = zero; acc1 = zero;
+    bf3_chunk<4>(imgF, kF3P4, li, q, 0, b1, acc0, acc1);                               // c7
+    __builtin_amdgcn_sched_barrier(0);
+    bf3_bload<4>(b1, A.pl_w1_t, 16, wave, 12, lane);                                   // c10
+    __builtin_amdgcn_sched_barrier(0);
+    bf3_chunk<4>(imgF, kF3P4, li, q, 4, b2, acc0, acc1);                               // c8
+    __builtin_amdgcn_sched_barrier(0);
+    bf3_bload<4>(b2, A.pl_wproj_t, 4, wave, 0, lane);                                  // c11
+    __builtin_amdgcn_sched_barrier(0);
+    bf3_chunk<4>(imgF, kF3P4, li, q, 8, b0, acc0, acc1);                               // c9
+    __builtin_amdgcn_sched_barrier(0);
+    bf3_bload<4>(b0, A.pl_wv_t, 4, wave, 0, lane);                                     // c12
+    __builtin_amdgcn_sched_barrier(0);
+    bf3_chunk<4>(imgF, kF3P4, li, q, 12, b1, acc0, acc1);                              // c10
+    __builtin_amdgcn_sched_barrier(0);
+    float dx1[4];
+    {
+        float d[4], xh[4], g[4], gx[4], s1v[4], s2v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            d[i] = acc0[i] + acc1[i];
+            if (A.d_h2) A.d_h2[(size_t)(row0 + 4 * q + i) * H + c] = d[i];
+            xh[i] = (x1v[i] - m2v[i]) * r2v[i];
+            g[i] = d[i] * g2;
+            gx[i] = g[i] * xh[i];
+        }
+        float* pp = A.part_n2 + (size_t)(wg * 4 + q) * (2 * H);
+        pp[c] = (d[0] * xh[0] + d[1] * xh[1]) + (d[2] * xh[2] + d[3] * xh[3]);
+        pp[H + c] = (d[0] + d[1]) + (d[2] + d[3]);
+        fb_rowsum2<4>(g, gx, redB, wave, li, q, s1v, s2v);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            dx1[i] = r2v[i] * (g[i] - s1v[i] - xh[i] * s2v[i]) + dx3[i];
+            A.d_x1[(size_t)(row0 + 4 * q + i) * H + c] = dx1[i];
+            bf3_store1(imgV, kF3P1, 4 * q + i, c, dx1[i]);
+        }
+    }
+    const FcMaskSrc mx0(A.drop_x0, A.g1n, H);
+    float x0v[4], m1v[4], r1v[4];
+    uint8_t kb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = row0 + 4 * q + i;
+        x0v[i] = A.x0[(size_t)r * H + c]; m1v[i] = A.m1[r]; r1v[i] = A.r1[r];
+        kb[i] = mx0.raw(r, c);
+    }
+    const float g1n = A.g1n[c], mr = A.m_rgb[c], md = A.m_dep[c], gd = A.lnd_g[c], bd = A.lnd_b[c];
+    float rgbv[2], dpv[2], mdv[2], rdv[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        rgbv[j] = A.rgb[(size_t)(f0 + j) * H + c]; dpv[j] = A.dep_pre[(size_t)(f0 + j) * H + c];
+        mdv[j] = A.mean_d[f0 + j]; rdv[j] = A.rstd_d[f0 + j];
+    }
+    __syncthreads();
+    R3D_CHAIN_MARK(A.timeline, wg == 0, 5);
+    // ---- stage 4: d_vsw = d_x1 . Wproj, un-swapped into d_v
+    acc0 = zero; acc1 = zero;
+    bf3_chunk<4>(imgV, kF3P1, li, q, 0, b2, acc0, acc1);                               // c11
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float v = acc0[i] + acc1[i];
+        const int rs = 4 * q + (i ^ 1);
+        A.d_v[(size_t)(row0 + rs) * H + c] = v;
+        bf3_store1(imgH, kF3P1, rs, c, v);
+    }
+    __syncthreads();
+    R3D_CHAIN_MARK(A.timeline, wg == 0, 6);
+    // ---- stage 5: d_h1 = d_v . Wv ; norm1 backward + both residual gradients ; embd_drop ; exchange ; depth LN + ReLU
+    acc0 = zero; acc1 = zero;
+    bf3_chunk<4>(imgH, kF3P1, li, q, 0, b0, acc0, acc1);                               // c12
+    float gx0[4];
+    {
+        float d[4], xh[4], g[4], gx[4], s1v[4], s2v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            d[i] = acc0[i] + acc1[i];
+            if (A.d_h1) A.d_h1[(size_t)(row0 + 4 * q + i) * H + c] = d[i];
+            xh[i] = (x0v[i] - m1v[i]) * r1v[i];
+            g[i] = d[i] * g1n;
+            gx[i] = g[i] * xh[i];
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float* pp = A.part_n1 + (size_t)(f0 + j) * (2 * H);
+            pp[c] = d[2 * j] * xh[2 * j] + d[2 * j + 1] * xh[2 * j + 1];
+            pp[H + c] = d[2 * j] + d[2 * j + 1];
+        }
+        fb_rowsum2<4>(g, gx, redA, wave, li, q, s1v, s2v);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            gx0[i] = (r1v[i] * (g[i] - s1v[i] - xh[i] * s2v[i]) + dx1[i] + (A.add_xres ? dx3[i] : 0.f)) *
+                     mx0.keep(kb[i], A.drop_scale);
+    }
+    {
+        float g[2], gx[2], xh[2], s1v[2], s2v[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float g0 = gx0[2 * j], g1 = gx0[2 * j + 1];
+            const float drgb = ((mr != 0.f ? 0.f : g0) + (md != 0.f ? g1 : 0.f)) * (rgbv[j] > 0.f ? 1.f : 0.f);
+            A.d_rgb_pre[(size_t)(f0 + j) * H + c] = drgb;
+            float dd = (mr != 0.f ? g0 : 0.f) + (md != 0.f ? 0.f : g1);
+            xh[j] = (dpv[j] - mdv[j]) * rdv[j];
+            if (!(xh[j] * gd + bd > 0.f)) dd = 0.f;
+            float* pp = A.part_dep + (size_t)(f0 + j) * (2 * H);
+            pp[c] = dd * xh[j];
+            pp[H + c] = dd;
+            g[j] = dd * gd;
+            gx[j] = g[j] * xh[j];
+        }
+        fb_rowsum2<2>(g, gx, redB, wave, li, q, s1v, s2v);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            A.d_dep_pre[(size_t)(f0 + j) * H + c] = rdv[j] * (g[j] - s1v[j] - xh[j] * s2v[j]);
+    }
+    R3D_CHAIN_MARK(A.timeline, wg == 0, 7);
+}
+
+__global__ __launch_bounds__(512) void fuser_chain_bwd_bf3_kernel(const FcBwd A) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    if (threadIdx.x >= 256) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(2);
+    const int nf = (2 * A.N) / kFcRows;
+    if ((int)blockIdx.x < nf) fc3_bwd_fuser(A, (int)blockIdx.x, lds);
+    else fc_bwd_query(A, (int)blockIdx.x - nf, lds);
+}
+
 __global__ __launch_bounds__(512) void fuser_chain_bwd_kernel(const FcBwd A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // The two waves a SIMD hosts (w and w + 4) run the same stage sequence in lockstep and would want the matrix core, the
@@ -1134,6 +1392,15 @@ R3D_EXPORT int r3d_fuser_chain_bwd(const r3d_fuser_chain_bwd_args* a, void* stre
                                        r3d::kFbLdsBytes);
     if (e != hipSuccess) return (int)e;
     const int grid = (2 * a->N) / r3d::kFcRows + (a->B * a->Q) / r3d::kFcRows;
+    if (a->pl_wkv_t) {            // planes of the transposed weights: the fuser role on the bf16 matrix cores
+        R3D_REQUIRE(a->pl_wseg_t && a->pl_w2_t && a->pl_w1_t && a->pl_wproj_t && a->pl_wv_t && a->K <= 32);
+        const int ldsb = r3d::kFbLdsBytes > r3d::kF3LdsBytes ? r3d::kFbLdsBytes : r3d::kF3LdsBytes;     // (query role: fp32 layout)
+        e = hipFuncSetAttribute((const void*)r3d::fuser_chain_bwd_bf3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(r3d::fuser_chain_bwd_bf3_kernel, dim3(grid), dim3(512), (size_t)ldsb, (hipStream_t)stream, *a);
+        R3D_LAUNCH_CHECK();
+        return R3D_OK;
+    }
     hipLaunchKernelGGL(r3d::fuser_chain_bwd_kernel, dim3(grid), dim3(512), (size_t)r3d::kFbLdsBytes, (hipStream_t)stream, *a);
     R3D_LAUNCH_CHECK();
     return R3D_OK;

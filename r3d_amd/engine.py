@@ -610,10 +610,13 @@ class FusionEngine:
             pre, pl = "fuser.blocks.0.", "transformer.decoder.layers.0."
             wi = a.p(pl + "multihead_attn.in_proj_weight")
             W = dict(wv=a.p(pre + "attn.qkv.weight")[2 * H:], wproj=a.p(pre + "attn.proj.weight"), w1=a.p(pre + "mlp.mlp.0.weight"),
-                     w2=a.p(pre + "mlp.mlp.2.weight"), wkv=wi[H:], wseg=a.p("fc_seg.weight"))
+                     w2=a.p(pre + "mlp.mlp.2.weight"), wkv=wi[H:], wseg=a.p("fc_seg.weight"),
+                     dec_wo=a.p(pl + "multihead_attn.out_proj.weight"), dec_w1=a.p(pl + "linear1.weight"),
+                     dec_w2=a.p(pl + "linear2.weight"))
             ent = {}
             for k, w_ in W.items():
-                ent["pl_" + k] = (w_, False)
+                ent["pl_" + k] = (w_, False)             # B[n][k] = W[n][k]: the forward products y = x W^T
+                ent["pl_" + k + "_t"] = (w_, True)       # B[n][k] = W[k][n]: the input-gradient products dx = dy W
             self._planes = ops.WeightPlanes(ent, self.device)
         return self._planes
 
@@ -629,8 +632,16 @@ class FusionEngine:
 
     def _dec_chain(self, w, drop):
         """The argument block of the decoder chain kernel for this workspace (one per dropout state)."""
-        key = ("dec_chain", bool(drop))
+        bf3 = bool(self.chain_bf3)
+        key = ("dec_chain", bool(drop), bf3)
+        if bf3 and not (self.use_fuser_chain and self._chain_shape_ok(w)):
+            self.chain_planes().refresh()                # (otherwise the fuser chain's forward launch refreshed them already)
         if key not in w.tables:
+            pls = self.chain_planes() if bf3 else None
+            dpl = None
+            if pls is not None:
+                dpl = dict(pl_wo=pls.ptr("pl_dec_wo"), pl_w1=pls.ptr("pl_dec_w1"), pl_w2=pls.ptr("pl_dec_w2"),
+                           pl_w2_t=pls.ptr("pl_dec_w2_t"), pl_w1_t=pls.ptr("pl_dec_w1_t"), pl_wo_t=pls.ptr("pl_dec_wo_t"))
             a, H = self.arena, self.H
             c, pl = w.layers[0], "transformer.decoder.layers.0."
             dk = (lambda k: w.drop[k]) if drop else (lambda k: None)
@@ -644,7 +655,7 @@ class FusionEngine:
                 w2=a.p(pl + "linear2.weight"), b2=a.p(pl + "linear2.bias"), drop_d3=dk("d3_0"), t3_pre=c["t3_pre"],
                 d_t3pre=g("t3pre"), d_ff2=g("ff2"), d_ff1=g("ff1"), d_t2pre=g("t2pre"), d_cap=g("cap"), d_cao=g("cao"),
                 d_caq=g("caq"), d_cakv=g("cakv"), part_d2=w.lnp["d2_0"] if gl is not None else None,
-                drop_scale=1.0 / (1.0 - DROP_P), pad_idx=self.pad_idx, B=w.B, S=w.S, H=H, Q=self.Q, heads=self.heads)
+                drop_scale=1.0 / (1.0 - DROP_P), pad_idx=self.pad_idx, B=w.B, S=w.S, H=H, Q=self.Q, heads=self.heads, planes=dpl)
         return w.tables[key]
 
     def _gln(self, rows, K):
@@ -676,7 +687,7 @@ class FusionEngine:
                     drop_sa=dm("sa_p0"), drop_d1=dm("d1_0"), drop_scale=dsc, sa_qkv=c["sa_qkv"], p_sa=c["p_sa"],
                     sa_o=c["sa_o"], t1_pre=c["t1_pre"], t1=c["t1"], m1=c["m1"], r1=c["r1"], caq=c["caq"],
                     N=w.N, S=S, K=self.K, H=H, add_xres=0 if self.bn else 1, B=B, Q=Q, heads=heads,
-                    planes={k: pls.ptr(k) for k in pls.keys} if pls is not None else None)
+                    planes={k: pls.ptr(k) for k in pls.keys if not k.endswith("_t") and "dec_" not in k} if pls is not None else None)
             w.tables[key].launch()
             self._erank_fork(w)
             return
@@ -1202,8 +1213,10 @@ class FusionEngine:
             # and the query-side branch, in ONE launch (csrc/fuser_chain.hip)
             c, gl, pl = w.layers[0], w.glayers[0], "transformer.decoder.layers.0."
             er = bool(st.get("erank"))
-            key = ("bwd_chain", bool(drop), er)
+            bf3 = bool(self.chain_bf3 and K <= 32)
+            key = ("bwd_chain", bool(drop), er, bf3)
             if key not in w.tables:
+                pls = self.chain_planes() if bf3 else None
                 wi0 = a.p(pl + "multihead_attn.in_proj_weight")
                 w.tables[key] = ops.FuserChainBwd(
                     d_cakv=gl["cakv"], d_seg=w.d_seg, d_extra=w.d_extra if er else None, wkv=wi0[H:], wseg=a.p("fc_seg.weight"),
@@ -1219,7 +1232,8 @@ class FusionEngine:
                     g1d=a.p(pl + "norm1.weight"), drop_d1=dmf("d1_0"), w_out=a.p(pl + "self_attn.out_proj.weight"),
                     sa_qkv=c["sa_qkv"], p_sa=c["p_sa"], drop_sa=dmf("sa_p0"), w_in=a.p(pl + "self_attn.in_proj_weight"),
                     caqin=gl["caqin"], t1pre_out=gl["t1pre"], sap=gl["sap"], sao=gl["sao"], saqkv=gl["saqkv"], sain=gl["sain"],
-                    part_d1=w.chain_parts["d1"], drop_scale=dsc, N=N, S=S, K=K, H=H, add_xres=1, B=B, Q=Q, heads=heads)
+                    part_d1=w.chain_parts["d1"], drop_scale=dsc, N=N, S=S, K=K, H=H, add_xres=1, B=B, Q=Q, heads=heads,
+                    planes={k: pls.ptr(k) for k in pls.keys if k.endswith("_t") and "dec_" not in k} if pls is not None else None)
             if er:
                 self._erank_join()
                 self._erank_backward(w, ws, dst=w.d_extra)

@@ -419,6 +419,10 @@ class FuserChainBwd:
         dims = {k: t.pop(k) for k in ("N", "S", "K", "H", "add_xres", "B", "Q", "heads")}
         a.drop_scale = float(t.pop("drop_scale", 1.0))
         opt = {"d_extra", "drop_x0", "drop_d1", "drop_sa", "d_h2", "d_h1", "t1pre_out"}
+        planes = t.pop("planes", None)
+        if planes is not None:
+            for name in FuserChainBwdArgs._PLANES:
+                setattr(a, name, planes[name])
         for name in FuserChainBwdArgs._PTRS:
             v = t.pop(name, None)
             if v is None:
@@ -451,6 +455,10 @@ class DecoderChain:
         a.drop_scale = float(t.pop("drop_scale", 1.0))
         opt = {"key_label", "drop_ca", "drop_d2", "drop_ff", "drop_d3", "d_t3pre", "d_ff2", "d_ff1", "d_t2pre", "d_cap", "d_cao",
                "d_caq", "d_cakv", "part_d2"}
+        planes = t.pop("planes", None)
+        if planes is not None:
+            for name in ("pl_wo", "pl_w1", "pl_w2", "pl_w2_t", "pl_w1_t", "pl_wo_t"):
+                setattr(a, name, planes[name])
         for name in DecoderChainArgs._PTRS:
             v = t.pop(name, None)
             if v is None:
