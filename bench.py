@@ -319,6 +319,12 @@ def main():
     ap.add_argument("--no-decoder-chain", action="store_true",
                     help="the decoder layer's query side as separate attention / GEMM / LayerNorm / loss launches instead of "
                          "the one-launch decoder chain kernel (A/B)")
+    ap.add_argument("--overlap-planes", action="store_true",
+                    help="re-split the chain weights on a parallel branch of the graph beside the input projections instead "
+                         "of in stream order in front of the fuser chain (measured slower: the join costs more; A/B)")
+    ap.add_argument("--overlap-param-tail", action="store_true",
+                    help="the grouped weight-gradient launch and the small bucket's AdamW on a parallel branch beside the "
+                         "depth weight gradient and its AdamW instead of in stream order (measured slower; A/B)")
     ap.add_argument("--erank-main-stream", action="store_true",
                     help="with --erank-weight: the Jacobi forward in stream order instead of on the side stream (A/B)")
     ap.add_argument("--no-paired", action="store_true",
@@ -391,6 +397,8 @@ def main():
     eng.use_fuser_chain = not a.no_fuser_chain
     eng.use_decoder_chain = not a.no_decoder_chain
     eng.chain_bf3 = not a.chain_fp32
+    eng.overlap_planes = a.overlap_planes
+    eng.overlap_param_tail = a.overlap_param_tail
     eng.erank_side_stream = not a.erank_main_stream
     if a.no_paired:
         eng.use_paired_launches = False
@@ -422,7 +430,8 @@ def main():
         eng.forward_finish()
         eng.losses(lab, tgt, dur, tick=True)
         fuse = fuse_adam and (dp is None or tp is not None)      # that gradient needs no exchange
-        eng.backward(fused_adamw=dict(lr=c["lr"], weight_decay=c["wd"], grad_scale=gscale) if fuse else None)
+        eng.backward(fused_adamw=dict(lr=c["lr"], weight_decay=c["wd"], grad_scale=gscale) if fuse else None,
+                     adamw_next=dp is None)
         if dp is not None:
             dp.wait_grads()
         eng.adamw(c["lr"], c["wd"], grad_scale=gscale, ticked=True, skip_depth=fuse, prefill_dropout=True)

@@ -220,6 +220,23 @@ class FusionEngine:
         # products as depth_prec = 1.  False: the exact-fp32 MFMA chain kernels
         self.chain_bf3 = True
         self._planes = None
+        # Parallel branches of the step's hipGraph on the weight-gradient stream (self.side), both bit-neutral:
+        #   overlap_planes: the re-split of the chain weights (they changed in the previous step's AdamW) runs beside the two
+        #     input projections and the embedding seam instead of in front of the fuser chain;
+        #   overlap_param_tail: everything of the backward that only feeds parameter gradients (the grouped weight-gradient
+        #     launch with its folded sums) and the AdamW of every parameter but depth_projection.weight run beside the depth
+        #     weight gradient (196 workgroups: a quarter of the chip idles under it) and the AdamW of that one weight (86 %
+        #     of the model).  Needs gradients that are final when they are written (one rank, no exchange), and is joined at
+        #     the end of backward() unless the caller promises the AdamW next (train_step).
+        # MEASURED SLOWER, so both are off (kept under test and behind bench.py's --overlap-* flags): 0.1919 ms/step without,
+        # 0.2063 with the planes branch, 0.2036 with the parameter branch, 0.2039 with both -- a fork/join pair between two
+        # queues of a hipGraph costs 12-14 us here, more than the 7 / 14 us the branches hide (the same finding as round 1's
+        # side-stream query branch; only the 0.5 ms Jacobi sweep is long enough to pay for its join).
+        self.overlap_planes = False
+        self.overlap_param_tail = False
+        self._planes_forked = False
+        self._tail_pending = False
+        self._overlap_tail_now = False
         # fused training flows (forward -> losses(tick=True) -> backward -> adamw(ticked=True)) may set this: the loss
         # kernel then leaves the reduction of its per-unit partials (loss / counter statistics only the host reads) to
         # one extra workgroup of the AdamW launch -- w.loss / w.counts are valid after adamw(), not after losses()
@@ -339,6 +356,13 @@ class FusionEngine:
                 ops.dropout_mask(w.drop_pool, DROP_P, self.drop_seed, self.drop_offset)
         tp = self.tp if (self.tp is not None and need_grad) else None
         seam = self.use_fused_embed and mode == "train" and H <= 1024
+        self._join_tail()
+        if (self.overlap_planes and self.chain_bf3 and self.L == 1 and (self.use_fuser_chain or self.use_decoder_chain) and
+                self._chain_shape_ok(w)):
+            self.side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.side):
+                self.chain_planes().refresh()
+            self._planes_forked = True
         # (running this GEMM on the side stream beside the 5x longer depth projection was measured: the cross-queue
         #  join costs more than the 5 us it hides)
         dr = ops.gemm(GEMM_NT, x_rgb, a.p("input_embed.weight"), w.rgb, bias=a.p("input_embed.bias"), act=1,
@@ -525,6 +549,9 @@ class FusionEngine:
             self._decoder_fused(w, key_labels, drop, dsc)
         else:
             self._decoder_unfused(w, key_labels, dm, dsc, multi, main, s2, sa_block, paired)
+        if self._planes_forked:                # (no chain launch consumed the branch: eval shapes the decoder chain skips)
+            main.wait_stream(self.side)
+            self._planes_forked = False
         er = self.erank_weight != 0.0 and hasattr(w, "glayers")
         if er and not w.__dict__.get("_er_forked", False):
             self._erank_forward(w)
@@ -620,6 +647,21 @@ class FusionEngine:
             self._planes = ops.WeightPlanes(ent, self.device)
         return self._planes
 
+    def _planes_refresh(self):
+        """The planes of the current parameters, before the first chain launch of a forward: joins the branch forward_begin
+        forked, or re-splits here."""
+        if self._planes_forked:
+            torch.cuda.current_stream().wait_stream(self.side)
+            self._planes_forked = False
+        else:
+            self.chain_planes().refresh()
+
+    def _join_tail(self):
+        """Joins the parameter-gradient branch of backward() (overlap_param_tail) into the current stream."""
+        if self._tail_pending:
+            torch.cuda.current_stream().wait_stream(self.side)
+            self._tail_pending = False
+
     def _chain_shape_ok(self, w):
         return bool(not self.bn and self.dh == 16 and ops.fuser_chain_supported(w.N, self.H, self.K, w.B, self.Q, self.heads))
 
@@ -635,7 +677,7 @@ class FusionEngine:
         bf3 = bool(self.chain_bf3)
         key = ("dec_chain", bool(drop), bf3)
         if bf3 and not (self.use_fuser_chain and self._chain_shape_ok(w)):
-            self.chain_planes().refresh()                # (otherwise the fuser chain's forward launch refreshed them already)
+            self._planes_refresh()                       # (otherwise the fuser chain's forward launch refreshed them already)
         if key not in w.tables:
             pls = self.chain_planes() if bf3 else None
             dpl = None
@@ -670,7 +712,7 @@ class FusionEngine:
             bf3 = bool(self.chain_bf3)
             key = ("fwd_chain", bool(drop), bf3)
             if bf3:
-                self.chain_planes().refresh()            # the parameters may have changed since the last forward: re-split
+                self._planes_refresh()                   # the parameters may have changed since the last forward: re-split
             if key not in w.tables:
                 pls = self.chain_planes() if bf3 else None
                 wi, bi = a.p(pl + "multihead_attn.in_proj_weight"), a.p(pl + "multihead_attn.in_proj_bias")
@@ -917,18 +959,28 @@ class FusionEngine:
         return w.loss, w.counts
 
     # ------------------------------------------------------------------------------------------------------
-    def backward(self, d_seg=None, d_actdur=None, fused_adamw=None):
+    def backward(self, d_seg=None, d_actdur=None, fused_adamw=None, adamw_next=False):
         """Adjoint of forward(); gradients land in the grad arena (written, not accumulated).
+        adamw_next: the caller enqueues adamw() right after (train_step): the parameter-gradient branch (overlap_param_tail)
+        is then left open for the AdamW of its parameters to continue on; otherwise it is joined before returning.
         fused_adamw: dict(lr, weight_decay[, betas, eps, grad_scale]) -> depth_projection.weight (86 % of the model) is
         updated INSIDE its weight-gradient GEMM (the gradient is never written); follow with adamw(..., skip_depth=True).
         Only valid when that gradient needs no exchange (one GPU, or the pixel-sharded projection)."""
         self.prepare_fused_adamw(fused_adamw)
-        self.backward_main(d_seg, d_actdur)
+        self._overlap_tail_now = bool(self.overlap_param_tail and self.last["tp"] is None and self.tp is None and
+                                      self.grad_hook is None and self._adam is None and
+                                      "depth_projection.weight" in self.arena.offsets)
+        try:
+            self.backward_main(d_seg, d_actdur)
+        finally:
+            self._overlap_tail_now = False
         if self.last["tp"] is not None:         # before the small bucket: the weight gradient waits for this one
             self.last["tp"].exchange_backward(self.last["w"])
         if self.grad_hook is not None:
             self.grad_hook("small_ready")
         self.backward_depth_wgrad()
+        if not adamw_next:
+            self._join_tail()
         if self.grad_hook is not None:
             self.grad_hook("big_ready")
 
@@ -1363,7 +1415,17 @@ class FusionEngine:
                    w.d_dep_pre, relu=True)
         if not joined:
             main.wait_stream(s2)
-        # ---- everything that only feeds parameter gradients: 2 launches + the broadcast-parameter sums
+        if self._overlap_tail_now:
+            self.side.wait_stream(main)
+            with torch.cuda.stream(self.side):
+                self._param_tail(w, st, chain)
+            self._tail_pending = True
+        else:
+            self._param_tail(w, st, chain)
+
+    def _param_tail(self, w, st, chain):
+        """Everything of the backward that only feeds parameter gradients: 2 launches + the broadcast-parameter sums."""
+        a, Q = self.arena, self.Q
         tname = "chain" if chain else ("bn" if self.bn else ("seam" if st["seam"] else "plain"))
         both = self._wgrad_with_sums(w, tname) if (self.fold_rowsums and self.L == 1) else None
         wg = both if both is not None else w.wgrad_group
@@ -1402,6 +1464,16 @@ class FusionEngine:
         (valid while the next forward uses the same shape and the dropout offset is not advanced again)."""
         a = self.arena
         self.set_lr(lr)
+        kw = dict(beta1=betas[0], beta2=betas[1], eps=eps, weight_decay=weight_decay, grad_scale=grad_scale)
+        n0 = 0
+        if self._tail_pending and ticked and self.tp is None and not skip_depth and before_flat is None:
+            # the branch that produced the small bucket's gradients goes on to update it; this stream keeps the one weight
+            # whose gradient it has just written (AdamW is element-wise: the cut changes no bit)
+            n0 = a.bucket_small[1]
+            with torch.cuda.stream(self.side):
+                ops.adamw_flat(a.params[:n0], a.grads[:n0], a.exp_avg[:n0], a.exp_avg_sq[:n0], self.lr_t, self.step_t, **kw)
+        else:
+            self._join_tail()
         if not ticked:
             ops.tick(self.step_t, self.drop_offset if tick_dropout else None)
         n = a.n_live if (self.tp is None and not skip_depth) else a.bucket_small[1]
@@ -1415,15 +1487,14 @@ class FusionEngine:
             before_flat()
         pending, self._loss_pending = getattr(self, "_loss_pending", None), None
         if prefill_dropout and st is not None and st["drop"] and (ticked or tick_dropout):
-            ops.adamw_flat_dropout(a.params[:n], a.grads[:n], a.exp_avg[:n], a.exp_avg_sq[:n], self.lr_t, self.step_t,
-                                   st["w"].drop_pool, DROP_P, self.drop_seed, self.drop_offset, beta1=betas[0], beta2=betas[1],
-                                   eps=eps, weight_decay=weight_decay, grad_scale=grad_scale, loss_fin=pending)
+            ops.adamw_flat_dropout(a.params[n0:n], a.grads[n0:n], a.exp_avg[n0:n], a.exp_avg_sq[n0:n], self.lr_t, self.step_t,
+                                   st["w"].drop_pool, DROP_P, self.drop_seed, self.drop_offset, loss_fin=pending, **kw)
             self._drop_ready = st["w"]
             pending = None
         else:
-            ops.adamw_flat(a.params[:n], a.grads[:n], a.exp_avg[:n], a.exp_avg_sq[:n], self.lr_t, self.step_t,
-                           beta1=betas[0], beta2=betas[1], eps=eps, weight_decay=weight_decay, grad_scale=grad_scale,
-                           loss_fin=pending)
+            ops.adamw_flat(a.params[n0:n], a.grads[n0:n], a.exp_avg[n0:n], a.exp_avg_sq[n0:n], self.lr_t, self.step_t,
+                           loss_fin=pending, **kw)
+        self._join_tail()
         if self.tp is not None and not skip_depth and not depth_cols_first:
             t = self.tp                             # depth_projection.weight: only this rank's pixel columns are live
             ops.adamw_2d(t.w, t.g, t.m, t.v, self.lr_t, self.step_t, beta1=betas[0], beta2=betas[1], eps=eps,
@@ -1440,6 +1511,6 @@ class FusionEngine:
             self.defer_tail, self.defer_loss_reduce = keep, keep_r
         # (backward(fused_adamw=...) + adamw(skip_depth=True) would update depth_projection.weight inside its
         #  weight-gradient GEMM; measured neutral at the bench shape, so the plain sequence stays the default)
-        self.backward()
+        self.backward(adamw_next=True)
         self.adamw(lr, weight_decay, ticked=True, prefill_dropout=True)
         return loss, counts

@@ -230,8 +230,9 @@ class UnsupDepthEngine:
         return w.loss, w.counts
 
     # ------------------------------------------------------------------------------------------------------
-    def backward(self, d_seg=None, d_actdur=None, fused_adamw=None):
-        """Adjoint of forward(); gradients land in the grad arena (written, not accumulated)."""
+    def backward(self, d_seg=None, d_actdur=None, fused_adamw=None, adamw_next=False):
+        """Adjoint of forward(); gradients land in the grad arena (written, not accumulated).  (adamw_next: accepted for
+        FusionEngine's signature; this engine has no parallel parameter-gradient branch.)"""
         assert fused_adamw is None
         st = self.last
         w, a, H, Q, K, heads, dh, ws = st["w"], self.arena, self.H, self.Q, self.K, self.heads, self.dh, self.ws

@@ -168,7 +168,7 @@ class _GraphedSteps:
         finally:
             if fused:
                 eng.defer_tail, eng.defer_loss_reduce, eng.loss_acc = keep
-        eng.backward()
+        eng.backward(adamw_next=True)
         eng.adamw(lr, wd, betas=betas, eps=eps, ticked=True)     # (no dropout prefill: every captured step generates its
         if not folded:                                            #  own masks, so graphs of different shapes can interleave)
             self.acc_loss += loss
@@ -433,7 +433,7 @@ def train(args, model, train_loader, optimizer, scheduler, criterion, model_save
             eng.forward(features, depth_features, past_label, "train", training=model.training)
             fused_opt = isinstance(optimizer, FlatAdamW)
             loss, counts = eng.losses(past_label, trans_future_target, trans_dur_future, tick=fused_opt)
-            eng.backward()
+            eng.backward(adamw_next=fused_opt and dp is None)
             if dp is not None:
                 dp.wait_grads()
             if fused_opt:

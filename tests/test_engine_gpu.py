@@ -394,7 +394,8 @@ def test_adamw_in_weight_gradient_epilogue_equals_flat_adamw():
                                    dict(use_gemm_ln=False, use_paired_launches=False), dict(fold_rowsums=False), dict(ride_attention=False),
                                    dict(ride_attention_bwd=True), dict(split_k4h=True), dict(use_fuser_chain=False),
                                    dict(use_decoder_chain=False), dict(use_decoder_chain=False, use_fuser_chain=False),
-                                   dict(use_decoder_chain=True, use_fused_tail=False), dict(chain_bf3=False)])
+                                   dict(use_decoder_chain=True, use_fused_tail=False), dict(chain_bf3=False),
+                                   dict(overlap_planes=True), dict(overlap_param_tail=True)])
 @pytest.mark.parametrize("tag,training", [("step_cfg2", True), ("step_k122_dec2", False)])
 def test_launch_fusion_paths_agree(tag, training, flags):
     """Every launch-fusion switch of the engine (decoder tail kernel, paired GEMM launches, embedding seam, side stream,
@@ -444,6 +445,26 @@ def test_dropout_prefill_in_adamw_launch_gives_the_same_masks():
         torch.cuda.synchronize()
         outs.append((eng.arena.params.clone(), eng.last["w"].drop_pool.clone(), eng.last["w"].loss.clone()))
     assert torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][0], outs[1][0])
+
+
+def test_parallel_graph_branches_change_no_bit():
+    """overlap_planes / overlap_param_tail move the weight re-split, the grouped weight-gradient launch and the small
+    bucket's AdamW to a second stream (fork / join by events, as under graph capture): three training steps through
+    train_step() must leave bit-identical parameters and losses."""
+    fx = load_fixture("step_cfg2")
+    m = fx["meta"]
+    d = [t.cuda() for t in fixture_batch(fx)]
+    outs = []
+    for ov in (False, True):
+        model = build_model(fx).train()
+        eng = model.engine()
+        eng.overlap_planes = eng.overlap_param_tail = ov
+        for _ in range(3):
+            loss, _ = eng.train_step(d[0], d[1], d[2], d[3], d[4], m["lr"], m["wd"], training=True)
+        torch.cuda.synchronize()
+        assert not eng._tail_pending and not eng._planes_forked
+        outs.append((eng.arena.params.clone(), eng.arena.exp_avg.clone(), eng.last["w"].loss.clone()))
+    assert torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
 @pytest.mark.parametrize("tag,paired", [("step_cfg2", True), ("step_cfg2", False), ("step_tiny", True)])
