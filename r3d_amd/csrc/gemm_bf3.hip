@@ -8,6 +8,7 @@
 // same as the fp32 MFMA path -- tests/test_kernels_gpu.py::test_gemm_bf16x3_*).  6 MFMAs of K = 16 replace 8 of K = 2:
 // 2.7x less matrix-core time, which turns both GEMMs from MFMA-bound into HBM-bound kernels.
 // Selected per problem by r3d_gemm_desc::prec = 1 (the engine sets it for the depth projection only).
+#include <type_traits>
 #include "common.h"
 #include "../../include/r3d_hip.h"
 
@@ -22,6 +23,21 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // x = h + m + l EXACTLY.  4 full-rate VALU instructions per pair and level (perm, 2 x and, packed subtract).
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+#ifdef R3D_SPLIT_PACKED
+    // (the two subtractions of a level as ONE v_pk_add_f32: written on a 2-vector, scalar floats compile to two v_sub_f32)
+    const f32x2_t x = {x0, x1};
+    const unsigned u0 = __builtin_bit_cast(unsigned, x0), u1 = __builtin_bit_cast(unsigned, x1);
+    h = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+    const f32x2_t hf = {__builtin_bit_cast(float, u0 & 0xffff0000u), __builtin_bit_cast(float, u1 & 0xffff0000u)};
+    const f32x2_t r = x - hf;
+    const float r0 = r[0], r1 = r[1];      // (__builtin_bit_cast straight on a vector ELEMENT reads element 0 for both)
+    const unsigned v0 = __builtin_bit_cast(unsigned, r0), v1 = __builtin_bit_cast(unsigned, r1);
+    m = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+    const f32x2_t mf = {__builtin_bit_cast(float, v0 & 0xffff0000u), __builtin_bit_cast(float, v1 & 0xffff0000u)};
+    const f32x2_t q = r - mf;
+    const float q0 = q[0], q1 = q[1];
+    l = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, q1), __builtin_bit_cast(unsigned, q0), 0x07060302u);
+#else
     const unsigned u0 = __builtin_bit_cast(unsigned, x0), u1 = __builtin_bit_cast(unsigned, x1);
     h = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
     const float r0 = x0 - __builtin_bit_cast(float, u0 & 0xffff0000u);
@@ -31,6 +47,7 @@ __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& h, uns
     const float q0 = r0 - __builtin_bit_cast(float, v0 & 0xffff0000u);
     const float q1 = r1 - __builtin_bit_cast(float, v1 & 0xffff0000u);
     l = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, q1), __builtin_bit_cast(unsigned, q0), 0x07060302u);
+#endif
 }
 // eight consecutive-k values -> one 16-byte MFMA operand per plane
 __device__ __forceinline__ void split3_oct(const float* v, uint4& h, uint4& m, uint4& l) {
@@ -259,6 +276,36 @@ __global__ __launch_bounds__(512, 1) void wgrad_panel_bf3_kernel(const r3d_gemm_
 // Output: raw fp32 slabs exactly as gemm_f32_kernel leaves them for split-K (the caller's reducer applies bias / LayerNorm /
 // the epilogue), placed XCD-aware (the tiles of one K-split share linear id mod 8).
 // ---------------------------------------------------------------------------------------------------------
+// Profiling builds only (tools/nt_stub_probe.sh; results wrong by construction): R3D_NT_PROBE bits -- 1 consumers do nothing but
+// the barriers, 8 consumers read their operands but issue no MFMA, 2 producers store the raw bits (no split), 4 producers
+// store nothing (the loads are still waited for); 16 timeline: threads 0 (consumer wave 0) and 256 (producer wave 4) of workgroup 16
+// store wall_clock64() (100 MHz) marks behind the slabs (the caller's workspace must have room: tools/nt_timeline.py).
+#ifndef R3D_NT_PROBE
+#define R3D_NT_PROBE 0
+#endif
+#if R3D_NT_PROBE & 16
+#define R3D_NT_MARK(K) do { if (blockIdx.x == 16 && (threadIdx.x & 255) == 0)                                                       \
+        reinterpret_cast<unsigned long long*>(d.partial + (size_t)NG * d.M * d.N)[(threadIdx.x >> 8) * 64 + (K)] = wall_clock64(); } while (0)
+#define R3D_NT_CYC(K) do { if (blockIdx.x == 16 && (threadIdx.x & 255) == 0)                                                        \
+        reinterpret_cast<unsigned long long*>(d.partial + (size_t)NG * d.M * d.N)[(threadIdx.x >> 8) * 64 + (K)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define R3D_NT_MARK(K) do { } while (0)
+#define R3D_NT_CYC(K) do { } while (0)
+#endif
+// One MFMA, then three VALU instructions, 24 times; the six LDS stores and four loads of the step spread between
+// (sched_group_barrier masks: 0x008 MFMA, 0x002 VALU, 0x200 DS write, 0x020 VMEM read).  R3D_NTU_NOSCHED: leave it to hipcc.
+#ifdef R3D_NTU_NOSCHED
+#define R3D_NTU_SCHED
+#else
+#ifndef R3D_NTU_V
+#define R3D_NTU_V 3
+#endif
+#define R3D_NTU_SCHED                                                                                    \
+    _Pragma("unroll") for (int g_ = 0; g_ < 24; ++g_) {                                                   \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                \
+        __builtin_amdgcn_sched_group_barrier(0x002, R3D_NTU_V, 0);                                        \
+    }
+#endif
 template <int BM, int BN, int BK>
 __global__ __launch_bounds__(512, 1) void gemm_bf3_nt_kernel(const r3d_gemm_desc d, const int G, const int NG) {
     constexpr int S = BK + 8;                                  // bf16 per image row
@@ -282,6 +329,9 @@ __global__ __launch_bounds__(512, 1) void gemm_bf3_nt_kernel(const r3d_gemm_desc
     const int k_begin = split * d.k_per_split;
     const int k_end = min(d.K, k_begin + d.k_per_split);
     const int nk = (k_end - k_begin + BK - 1) / BK;
+#ifdef R3D_NT_PRIO
+    if (wave < 4) __builtin_amdgcn_s_setprio((R3D_NT_PRIO) & 3); else __builtin_amdgcn_s_setprio(((R3D_NT_PRIO) >> 2) & 3);
+#endif
     if (wave < 4) {
         // ================================= consumers =================================
         const int wm = wave >> 1, wn = wave & 1;
@@ -294,13 +344,15 @@ __global__ __launch_bounds__(512, 1) void gemm_bf3_nt_kernel(const r3d_gemm_desc
                 for (int c = 0; c < (TWO ? 2 : 1); ++c)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[i][j][c][r] = 0.f;
+        R3D_NT_MARK(0);
         __syncthreads();                                            // stage 0 written
         for (int kt = 0; kt < nk; ++kt) {
+            R3D_NT_MARK(1 + 2 * kt);
             const unsigned short* img = lds16 + (kt & 1) * STAGE;
             const unsigned short* ia = img + (size_t)(wm * (BM / 2) + l31) * S + 8 * lhi;
             const unsigned short* ib = img + 3 * PLANE_A + (size_t)(wn * (BN / 2) + l31) * S + 8 * lhi;
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) {
+            for (int ks = 0; ks < ((R3D_NT_PROBE & 1) ? 0 : NKS); ++ks) {
                 uint4 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
@@ -320,6 +372,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf3_nt_kernel(const r3d_gemm_desc
 #define R3D_BF(x) __builtin_bit_cast(bf16x8, x)
 #define R3D_TERM(A_, B_)                                                                                                   \
                 _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)               \
+                    if (R3D_NT_PROBE & 8) { acc[i][j][c][0] += __builtin_bit_cast(float, A_[i].x ^ B_[j].x); } else          \
                     acc[i][j][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(R3D_BF(A_[i]), R3D_BF(B_[j]), acc[i][j][c], 0, 0, 0);
                 R3D_TERM(ah, bl)                                    // small terms first; tiles alternate inside a term
                 R3D_TERM(al, bh)
@@ -330,24 +383,39 @@ __global__ __launch_bounds__(512, 1) void gemm_bf3_nt_kernel(const r3d_gemm_desc
 #undef R3D_TERM
 #undef R3D_BF
             }
+            R3D_NT_MARK(2 + 2 * kt);
             __syncthreads();
         }
+        R3D_NT_MARK(1 + 2 * nk);
         if (nk & 1) __syncthreads();                                // (the producers' loop runs whole pairs of k-steps)
         // raw partial sums -> slab `split` (C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
+        float* slab = d.partial + (size_t)split * d.M * d.N;
+        const bool whole = m0 + BM <= d.M && n0 + BN <= d.N;        // (uniform: a whole tile stores without per-element branches)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int n = n0 + wn * (BN / 2) + j * 32 + l31;
+                const int mb = m0 + wm * (BM / 2) + i * 32 + 4 * lhi;
+                if (whole) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float v = acc[i][j][0][r];
+                        if (TWO) v += acc[i][j][TWO ? 1 : 0][r];
+                        slab[(size_t)(mb + (r & 3) + 8 * (r >> 2)) * d.N + n] = v;
+                    }
+                    continue;
+                }
                 if (n >= d.N) continue;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    const int m = mb + (r & 3) + 8 * (r >> 2);
                     float v = acc[i][j][0][r];
                     if (TWO) v += acc[i][j][TWO ? 1 : 0][r];
-                    if (m < d.M) d.partial[((size_t)split * d.M + m) * d.N + n] = v;
+                    if (m < d.M) slab[(size_t)m * d.N + n] = v;
                 }
             }
+        R3D_NT_MARK(2 + 2 * nk);
     } else {
         // ================================= producers =================================
         const int pt = tid - 256;
@@ -380,58 +448,255 @@ __global__ __launch_bounds__(512, 1) void gemm_bf3_nt_kernel(const r3d_gemm_desc
                 reg[2 * t + 1] = *reinterpret_cast<const float4*>(src + 4);
             }
         };
-        auto store_stage = [&](unsigned short* img, const float4* reg, int kt) {
+        // CHECK = false: every row of the tile and every k of the slice exist (the headline shape): no zero-fill selects
+        auto store_stage = [&](unsigned short* img, const float4* reg, int kt, auto check) {
+            constexpr bool CHECK = decltype(check)::value;
             const int k0 = k_begin + kt * BK;
 #pragma unroll
             for (int t = 0; t < NOCT; ++t) {
                 const int e = pt + 256 * t, row = e / OPR, o = e % OPR;
                 const bool isa = row < BM;
-                const bool ok = rok[t] && (k0 + 8 * o < k_end);
                 const float4 x = reg[2 * t], y = reg[2 * t + 1];
                 float v[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
-                if (!ok) {
+                if (CHECK) {
+                    const bool ok = rok[t] && (k0 + 8 * o < k_end);
+                    if (!ok) {
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) v[q] = 0.f;
+                        for (int q = 0; q < 8; ++q) v[q] = 0.f;
+                    }
                 }
                 uint4 h, m, l;
-                split3_oct(v, h, m, l);
+                if (R3D_NT_PROBE & 2) {
+                    h = __builtin_bit_cast(uint4, x); m = __builtin_bit_cast(uint4, y); l = h;
+                } else {
+                    split3_oct(v, h, m, l);
+                }
                 unsigned short* dst = img + (isa ? (size_t)row * S : (size_t)3 * PLANE_A + (size_t)(row - BM) * S) + 8 * o;
                 const int plane = isa ? PLANE_A : PLANE_B;
-                *reinterpret_cast<uint4*>(dst) = h;
-                *reinterpret_cast<uint4*>(dst + plane) = m;
-                *reinterpret_cast<uint4*>(dst + 2 * plane) = l;
+                if (R3D_NT_PROBE & 4) {
+                    if ((h.x ^ m.y ^ l.z) == 0x12345678u) *reinterpret_cast<uint4*>(dst) = h;
+                } else {
+                    *reinterpret_cast<uint4*>(dst) = h;
+                    *reinterpret_cast<uint4*>(dst + plane) = m;
+                    *reinterpret_cast<uint4*>(dst + 2 * plane) = l;
+                }
             }
         };
         // Every load below is UNCONDITIONAL (tile indices are clamped: a surplus load re-reads the last tile and its image
         // is never consumed): a load under a branch makes hipcc wait vmcnt(0) at the next use, i.e. for the loads issued
         // one step earlier as well -- measured 1.8 us per k-step (one HBM round trip) instead of 0.7.
         const int last = nk - 1;
+        auto run = [&](auto check) {
+            R3D_NT_MARK(0);
+            load_stage(s0, 0);
+            load_stage(s1, min(1, last));
+            store_stage(lds16, s0, 0, check);
+            load_stage(s0, min(2, last));
+            R3D_NT_MARK(1);
+            __syncthreads();                                        // stage 0 written
+            // step kt: tile kt + 1 (register stage) -> the other image; refill that register stage with tile kt + 3
+            // (straight-line body: with an exit between the two halves the compiler re-rolls the loop, rotates the two
+            //  register stages through copies and has to wait for the NEWEST loads at every copy -- s_waitcnt vmcnt(0) once
+            //  per k-step, the whole prefetch distance lost.  An odd nk runs one surplus half whose image nobody reads; the
+            //  consumers match its barrier.)
+            for (int kt = 0; kt < nk; kt += 2) {
+                R3D_NT_MARK(2 + 2 * kt);
+#if R3D_NT_PROBE & 16
+                __builtin_amdgcn_s_waitcnt(0xF78);                  // vmcnt(8): this stage's loads have landed
+                R3D_NT_MARK(32 + 2 * kt);
+#endif
+                store_stage(lds16 + STAGE, s1, min(kt + 1, last), check);
+#if R3D_NT_PROBE & 16
+                __builtin_amdgcn_sched_barrier(0);
+                R3D_NT_MARK(33 + 2 * kt);
+#endif
+                load_stage(s1, min(kt + 3, last));
+                __builtin_amdgcn_sched_barrier(0);                  // (keeps the other stage's split below these loads)
+                R3D_NT_MARK(3 + 2 * kt);
+                __syncthreads();
+                R3D_NT_MARK(4 + 2 * kt);
+                store_stage(lds16, s0, min(kt + 2, last), check);
+                load_stage(s0, min(kt + 4, last));
+                __builtin_amdgcn_sched_barrier(0);
+                R3D_NT_MARK(5 + 2 * kt);
+                __syncthreads();
+            }
+        };
+        const bool full = m0 + BM <= d.M && n0 + BN <= d.N && k_begin + nk * BK <= k_end;
+        if (full) run(std::false_type{}); else run(std::true_type{});
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The same split-K NT product with UNIFORM waves (tile 11: 128 x 128 x 32).  In the role-split kernel above the producers'
+// split (5.5 VALU instructions per operand element) is issued from OTHER waves than the MFMAs it has to hide under, and
+// the SIMD's arbiter does not interleave the two streams well: measured per k-step (tools/nt_timeline.sh) the consumers'
+// 48 MFMAs take 1.0 us, the producers' split + store 1.3-1.45 us beside them, and the consumers wait out the difference at
+// the barrier (matrix cores 70 % busy inside the loop; wave priorities change nothing, v_pk_add_f32 for the subtractions
+// is slower than two v_sub_f32).  Here every wave does both: wave w owns a 32 x 64 slice of the output (2 MFMA tiles, 24
+// MFMAs per k-step) and a 1/8 share of the operand stream (two 8-element octets per lane and k-step: ~70 VALU, 6
+// ds_write_b128, 4 loads), and the split of tile kt + 1 sits in the SAME instruction stream as the MFMAs of tile kt --
+// 3 fillers per MFMA gap, which one wave's stream hides (MI355X_MICROARCH.md: <= 5 single-issue instructions per
+// v_mfma_f32_32x32x16_bf16 gap).  Two register stages of loads in flight, LDS images double-buffered, one barrier per
+// k-step, slabs and placement as above.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 1) void gemm_bf3_nt_u_kernel(const r3d_gemm_desc d, const int G, const int NG) {
+    constexpr int BM = 128, BN = 128, BK = 32;
+    constexpr int S = BK + 8, OPR = BK / 8;
+    constexpr int PLANE = BM * S;                              // bf16 elements per plane (A and B alike)
+    constexpr int STAGE = 6 * PLANE;
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds16[];     // [2 stages][A planes | B planes]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int p = blockIdx.x, idx = p >> 3;
+    const int split = (idx / G) * 8 + (p & 7), tile = idx % G;
+    if (split >= NG) return;
+    const int tiles_n = (d.N + BN - 1) / BN;
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    const int k_begin = split * d.k_per_split;
+    const int k_end = min(d.K, k_begin + d.k_per_split);
+    const int nk = (k_end - k_begin + BK - 1) / BK;
+    const int wm = wave & 3, wn = wave >> 2;                   // rows 32 wm .., columns 64 wn ..
+    // ---- this lane's two octets of the operand stream: e = tid, tid + 512 -> (row e / 4 of A | B, octet e % 4)
+    const float* rowp[2];
+    bool rok[2];
+    int dsto[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int e = tid + 512 * t, row = e / OPR, o = e % OPR;
+        const bool isa = row < BM;                              // (t == 0: A, t == 1: B)
+        const int gr = isa ? m0 + row : n0 + (row - BM);
+        rok[t] = gr < (isa ? d.M : d.N);
+        rowp[t] = (isa ? d.A : d.B) + (size_t)(rok[t] ? gr : 0) * (size_t)(isa ? d.lda : d.ldb) + 8 * o;
+        dsto[t] = (isa ? row * S : 3 * PLANE + (row - BM) * S) + 8 * o;
+    }
+    const int Kt = d.K;
+    float4 s0[4], s1[4];
+    auto load_stage = [&](float4* reg, int kt) {
+        const int k0 = k_begin + kt * BK;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int o8 = 8 * ((tid + 512 * t) % OPR);
+            const int k = k0 + o8;
+            const int kc = k + 8 <= Kt ? k : Kt - 8;            // K % 8 == 0 (validated)
+            const float* src = rowp[t] + (kc - o8);
+            reg[2 * t] = *reinterpret_cast<const float4*>(src);
+            reg[2 * t + 1] = *reinterpret_cast<const float4*>(src + 4);
+        }
+    };
+    auto store_stage = [&](unsigned short* img, const float4* reg, int kt, auto check) {
+        constexpr bool CHECK = decltype(check)::value;
+        const int k0 = k_begin + kt * BK;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float4 x = reg[2 * t], y = reg[2 * t + 1];
+            float v[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
+            if (CHECK) {
+                const bool ok = rok[t] && (k0 + 8 * ((tid + 512 * t) % OPR) < k_end);
+                if (!ok) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = 0.f;
+                }
+            }
+            uint4 h, m, l;
+            split3_oct(v, h, m, l);
+            unsigned short* dst = img + dsto[t];
+            *reinterpret_cast<uint4*>(dst) = h;
+            *reinterpret_cast<uint4*>(dst + PLANE) = m;
+            *reinterpret_cast<uint4*>(dst + 2 * PLANE) = l;
+        }
+    };
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    // the MFMAs of one k-step on image `img` (2 k16 x 2 column tiles x 6 products)
+    auto mma = [&](const unsigned short* img) {
+        const unsigned short* ia = img + (size_t)(wm * 32 + l31) * S + 8 * lhi;
+        const unsigned short* ib = img + 3 * PLANE + (size_t)(wn * 64 + l31) * S + 8 * lhi;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 a[3], b[2][3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                a[pl] = *reinterpret_cast<const uint4*>(ia + pl * PLANE + 16 * ks);
+                b[0][pl] = *reinterpret_cast<const uint4*>(ib + pl * PLANE + 16 * ks);
+                b[1][pl] = *reinterpret_cast<const uint4*>(ib + pl * PLANE + 32 * S + 16 * ks);
+            }
+#define R3D_BF(x) __builtin_bit_cast(bf16x8, x)
+#define R3D_T2(PA, PB)                                                                                              \
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(R3D_BF(a[PA]), R3D_BF(b[0][PB]), acc[0], 0, 0, 0);     \
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(R3D_BF(a[PA]), R3D_BF(b[1][PB]), acc[1], 0, 0, 0);
+            R3D_T2(0, 2)                                            // h . l   (small terms first)
+            R3D_T2(2, 0)                                            // l . h
+            R3D_T2(1, 1)                                            // m . m
+            R3D_T2(0, 1)                                            // h . m
+            R3D_T2(1, 0)                                            // m . h
+            R3D_T2(0, 0)                                            // h . h
+#undef R3D_T2
+#undef R3D_BF
+        }
+    };
+    const int last = nk - 1;
+    auto run = [&](auto check) {
+        R3D_NT_MARK(0);
         load_stage(s0, 0);
         load_stage(s1, min(1, last));
-        store_stage(lds16, s0, 0);
+        store_stage(lds16, s0, 0, check);
         load_stage(s0, min(2, last));
-        __syncthreads();                                            // stage 0 written
-        // step kt: tile kt + 1 (register stage) -> the other image; refill that register stage with tile kt + 3
-        // (straight-line body: with an exit between the two halves the compiler re-rolls the loop, rotates the two register
-        //  stages through copies and has to wait for the NEWEST loads at every copy -- s_waitcnt vmcnt(0) once per k-step,
-        //  the whole prefetch distance lost.  An odd nk runs one surplus half whose image nobody reads; the consumers
-        //  match its barrier.)
+        R3D_NT_MARK(1);
+        __syncthreads();                                            // image 0 written
+        R3D_NT_CYC(60);
+        // step kt: MFMAs on image kt & 1; tile kt + 1 (a register stage) is split into the other image in the same
+        // instruction stream; that register stage is refilled with tile kt + 3.  (Straight-line pairs of steps, surplus
+        // half for an odd nk, unconditional clamped loads: see the role-split kernel.)
         for (int kt = 0; kt < nk; kt += 2) {
-            store_stage(lds16 + STAGE, s1, min(kt + 1, last));
+            R3D_NT_MARK(2 + 2 * kt);
+            mma(lds16);
+            store_stage(lds16 + STAGE, s1, min(kt + 1, last), check);
             load_stage(s1, min(kt + 3, last));
-            __builtin_amdgcn_sched_barrier(0);                      // (keeps the other stage's split below these loads)
+            R3D_NTU_SCHED
+            R3D_NT_MARK(3 + 2 * kt);
             __syncthreads();
-            store_stage(lds16, s0, min(kt + 2, last));
+            R3D_NT_MARK(4 + 2 * kt);
+            if (kt + 1 < nk) mma(lds16 + STAGE);
+            store_stage(lds16, s0, min(kt + 2, last), check);
             load_stage(s0, min(kt + 4, last));
-            __builtin_amdgcn_sched_barrier(0);
+            R3D_NTU_SCHED
+            R3D_NT_MARK(5 + 2 * kt);
             __syncthreads();
         }
+        R3D_NT_MARK(2 + 2 * nk);
+        R3D_NT_CYC(61);
+    };
+    const bool full = m0 + BM <= d.M && n0 + BN <= d.N && k_begin + nk * BK <= k_end;
+    if (full) run(std::false_type{}); else run(std::true_type{});
+    // raw partial sums -> slab `split` (C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
+    float* slab = d.partial + (size_t)split * d.M * d.N;
+    const bool whole = m0 + BM <= d.M && n0 + BN <= d.N;
+    const int mb = m0 + wm * 32 + 4 * lhi;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + l31;
+        if (whole) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) slab[(size_t)(mb + (r & 3) + 8 * (r >> 2)) * d.N + n] = acc[j][r];
+            continue;
+        }
+        if (n >= d.N) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mb + (r & 3) + 8 * (r >> 2);
+            if (m < d.M) slab[(size_t)m * d.N + n] = acc[j][r];
+        }
     }
+    R3D_NT_MARK(3 + 2 * nk);
 }
 
 bool gemm_bf3_nt_ok(const r3d_gemm_desc& d) {
     if (d.layout != R3D_GEMM_NT || d.splitk <= 1 || !d.partial) return false;
-    if ((d.K & 7) || (d.lda & 3) || (d.ldb & 3) || (d.k_per_split & 63) || d.K < 64) return false;
+    if ((d.K & 7) || (d.lda & 3) || (d.ldb & 3) || (d.k_per_split & (d.tile == 9 || d.tile == 11 ? 31 : 63)) || d.K < 64) return false;
     if (d.a_add || d.a_row_xor || d.adam_m || d.alpha != 1.0f) return false;
     return r3d_aligned16(d.A) && r3d_aligned16(d.B);
 }
@@ -456,6 +721,20 @@ int launch_gemm_bf3_nt(const r3d_gemm_desc& d, hipStream_t s) {
     if (!gemm_bf3_nt_ok(d)) return R3D_EINVAL;
     if (d.tile == 8) return launch_bf3_nt_cfg<64, 64, 64>(d, s);
     if (d.tile == 9) return launch_bf3_nt_cfg<128, 128, 32>(d, s);
+    if (d.tile == 11) {
+        const int tiles = r3d_cdiv(d.M, 128) * r3d_cdiv(d.N, 128);
+        const int ns = r3d_cdiv(d.K, d.k_per_split);
+        const size_t lds = (size_t)2 * 6 * 128 * 40 * sizeof(unsigned short);
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute((const void*)gemm_bf3_nt_u_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(gemm_bf3_nt_u_kernel, dim3(8 * tiles * r3d_cdiv(ns, 8)), dim3(512), lds, s, d, tiles, ns);
+        R3D_LAUNCH_CHECK();
+        return R3D_OK;
+    }
     return R3D_EINVAL;
 }
 
@@ -526,8 +805,10 @@ __global__ __launch_bounds__(512, 1) void gemm_bf3_tn_kernel(const r3d_gemm_desc
 #undef R3D_TERM
 #undef R3D_BF
             }
+            R3D_NT_MARK(2 + 2 * kt);
             __syncthreads();
         }
+        R3D_NT_MARK(1 + 2 * nk);
         if (nk & 1) __syncthreads();                                // (the producers' loop runs whole pairs of k-steps)
         // C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
         const float alpha = d.alpha;
@@ -591,10 +872,12 @@ __global__ __launch_bounds__(512, 1) void gemm_bf3_tn_kernel(const r3d_gemm_desc
             }
         };
         const int last = nk - 1;
+        R3D_NT_MARK(0);
         load_stage(s0, 0);
         load_stage(s1, min(1, last));
         store_stage(lds16, s0, 0);
         load_stage(s0, min(2, last));
+        R3D_NT_MARK(1);
         __syncthreads();                                            // stage 0 written
         for (int kt = 0; kt < nk; kt += 2) {                        // (straight-line pairs: see gemm_bf3_nt_kernel)
             store_stage(lds16 + STAGE, s1, min(kt + 1, last));

@@ -818,7 +818,7 @@ static int gemm_validate(const r3d_gemm_desc* d) {
     if (!d || !d->A || !d->B || !d->C) return R3D_EINVAL;
     if (d->M <= 0 || d->N <= 0 || d->K <= 0) return R3D_EINVAL;
     if (d->layout < 0 || d->layout > 2) return R3D_EINVAL;
-    if (d->tile < 1 || d->tile > 10) return R3D_EINVAL;
+    if (d->tile < 1 || d->tile > 11) return R3D_EINVAL;
     const int a_min = (d->layout == R3D_GEMM_TN) ? d->M : d->K;
     const int b_min = (d->layout == R3D_GEMM_NT) ? d->K : d->N;
     if (d->lda < a_min || d->ldb < b_min || d->ldc < d->N) return R3D_EINVAL;
@@ -931,7 +931,7 @@ R3D_EXPORT int r3d_gemm_f32(const r3d_gemm_desc* dp, void* stream) {
     d.vec = gemm_can_vec(d) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     const int ns = nsplits_of(d);
-    if (d.tile == 8 || d.tile == 9) return launch_gemm_bf3_nt(d, s);          // long-K NT split-K on the bf16 matrix cores
+    if (d.tile == 8 || d.tile == 9 || d.tile == 11) return launch_gemm_bf3_nt(d, s);          // long-K NT split-K on the bf16 matrix cores
     if (d.tile == 10) return launch_gemm_bf3_tn(d, s);                        // wide TN (weight gradient) on the same
     if (d.tile == 7) {                   // the same panel kernel on the bf16 matrix cores (exact 3-way operand split)
         if (!wgrad_panel_ok(d) || (d.ldc & 3) || !r3d_aligned16(d.C)) return R3D_EINVAL;

@@ -127,7 +127,8 @@ def gemm(layout, a, b, c, *, ws=None, tile=0, splitk=0, defer_reduce=False, adam
         if splitk == 1:
             d.splitk, d.k_per_split = 1, K
         else:
-            kps = ((K + splitk - 1) // splitk + 15) // 16 * 16
+            q = 64 if d.tile == 8 else (32 if d.tile in (9, 11) else 16)     # the bf16x3 NT kernels step K by 64 / 32
+            kps = ((K + splitk - 1) // splitk + q - 1) // q * q
             d.splitk, d.k_per_split = (K + kps - 1) // kps, kps
             if d.splitk < 2:
                 d.splitk, d.k_per_split = 1, K

@@ -622,6 +622,25 @@ def test_gemm_bf16x3_long_k_projection(ops, M, N, K):
     assert e1 < 3e-6 and e1 < 4 * e0 + 3e-7, (e1, e0)
 
 
+@pytest.mark.parametrize("M,N,K,splits", [(128, 128, 50176, 196), (128, 128, 50176, 224), (100, 96, 8200, 9), (512, 512, 12544, 8),
+                                          (130, 257, 8192, 5)])
+def test_gemm_bf16x3_uniform_wave_tile(ops, M, N, K, splits):
+    """Tile 11 (gemm_bf3_nt_u_kernel: every wave splits its share of the operand stream between its own MFMAs; kept for
+    measurement, the planner does not select it) against an fp64 product, whole and ragged tiles, K tails."""
+    from r3d_amd._lib import GEMM_NT
+    a = torch.rand(M, K, generator=torch.Generator().manual_seed(M))
+    b = rnd(N, K, seed=N) * (3.0 / K) ** 0.5
+    want = a.double() @ b.double().t()
+    scale = float(want.abs().max())
+    c1 = torch.empty(M, N, device="cuda")
+    ws = ops.GemmWorkspace("cuda")
+    d1 = ops.gemm(GEMM_NT, dev(a), dev(b), c1, ws=ws, prec=1, tile=11, splitk=splits)
+    torch.cuda.synchronize()
+    assert d1.tile == 11 and d1.splitk > 1
+    e1 = float((c1.cpu().double() - want).abs().max()) / scale
+    assert e1 < 3e-6, e1
+
+
 # ----------------------------------------------------------------------------------------------------------
 # effective rank
 # ----------------------------------------------------------------------------------------------------------

@@ -11,14 +11,20 @@ c = torch.empty(M, N, device="cuda")
 ws = ops.GemmWorkspace("cuda")
 ref = (a.double() @ b.double().t())
 def run(**kw):
-    d = ops.gemm(GEMM_NT, a, b, c, ws=ws, prec=1, **kw)
+    d = ops.gemm(GEMM_NT, a, b, c, ws=ws, prec=1, defer_reduce=DEFER, **kw)
     return d
-for kw in ({}, dict(tile=8, splitk=4), dict(tile=8, splitk=8), dict(tile=8, splitk=16), dict(tile=9, splitk=16), dict(tile=9, splitk=8),
+DEFER = False
+VARIANTS = ({}, dict(tile=8, splitk=61), dict(tile=9, splitk=196), dict(tile=11, splitk=196), dict(tile=11, splitk=224), dict(tile=9, splitk=224), dict(tile=9, splitk=98),
+            dict(tile=9, splitk=256), dict(tile=8, splitk=122)) if (M, N) == (128, 128) else None
+for kw in VARIANTS or ({}, dict(tile=11, splitk=16), dict(tile=11, splitk=32), dict(tile=9, splitk=32), dict(tile=8, splitk=4), dict(tile=8, splitk=8), dict(tile=8, splitk=16), dict(tile=9, splitk=16), dict(tile=9, splitk=8),
            dict(tile=9, splitk=49), dict(tile=8, splitk=28)):
     try:
         d = run(**kw)
         err = float((c.double() - ref).abs().max() / ref.abs().max())
         t = bench.time_kernel(lambda: run(**kw))
-        print(kw, "tile", d.tile, "splitk", d.splitk, "kps", d.k_per_split, "us", round(t * 1e6, 1), "err", f"{err:.1e}", flush=True)
+        DEFER = True
+        t2 = bench.time_kernel(lambda: run(**kw))
+        DEFER = False
+        print(kw, "tile", d.tile, "splitk", d.splitk, "kps", d.k_per_split, "us", round(t * 1e6, 1), "without the reducer", round(t2 * 1e6, 1), "err", f"{err:.1e}", flush=True)
     except Exception as e:
         print(kw, "failed", repr(e)[:100], flush=True)

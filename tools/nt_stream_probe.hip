@@ -1,0 +1,193 @@
+// Load-skeleton probe for the forward depth projection at the headline shape (A [128, 50176], B [128, 50176], fp32, K-contiguous):
+// one workgroup per K-slice streams ALL 256 rows of its slice (every operand byte requested once), with the loads kept STAGES
+// deep in registers, and does nothing else (the values are summed so that the loads stay).  What it answers: how fast can
+// this access pattern be pulled at all, as a function of the bytes in flight, the segment length per row and the lane mapping.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/_build/nt_stream_probe tools/nt_stream_probe.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+// MAP 0: thread -> 32 contiguous bytes of a row (two float4: the current producers' mapping)
+// MAP 1: lanes -> consecutive float4 of a row segment (a wave instruction covers whole 128-byte lines)
+template <int THREADS, int BK, int STAGES, int MAP, int KS>
+__global__ __launch_bounds__(THREADS) void stream(const float* __restrict__ A, const float* __restrict__ B, int ld, float* out) {
+    constexpr int ROWS = 256;
+    constexpr int F4 = ROWS * BK / 4 / THREADS;            // float4 per thread and k-step
+    constexpr int NK = KS / BK;
+    static_assert(F4 >= 1 && (ROWS * BK / 4) % THREADS == 0, "mapping");
+    const int tid = threadIdx.x;
+    const size_t k0 = (size_t)blockIdx.x * KS;
+    const float* src[F4];
+#pragma unroll
+    for (int t = 0; t < F4; ++t) {
+        int row, kf;
+        if (MAP == 0) {
+            const int e = tid + THREADS * (t >> 1);        // octet index
+            row = e / (BK / 8); kf = 8 * (e % (BK / 8)) + 4 * (t & 1);
+        } else {
+            const int e = tid + THREADS * t;               // float4 index
+            row = e / (BK / 4); kf = 4 * (e % (BK / 4));
+        }
+        src[t] = (row < 128 ? A + (size_t)row * ld : B + (size_t)(row - 128) * ld) + k0 + kf;
+    }
+    float4 st[STAGES][F4];
+    float acc = 0.f;
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+#pragma unroll
+        for (int t = 0; t < F4; ++t) st[s][t] = *reinterpret_cast<const float4*>(src[t] + (size_t)(s < NK ? s : NK - 1) * BK);
+#pragma unroll
+    for (int kt = 0; kt < NK; ++kt) {
+        const int nx = kt + STAGES - 1 < NK ? kt + STAGES - 1 : NK - 1;
+#pragma unroll
+        for (int t = 0; t < F4; ++t) st[(kt + STAGES - 1) % STAGES][t] = *reinterpret_cast<const float4*>(src[t] + (size_t)nx * BK);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < F4; ++t) { const float4 v = st[kt % STAGES][t]; acc += (v.x + v.y) + (v.z + v.w); }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (acc == 12345.678f) out[0] = acc;
+}
+
+// The same stream inside the GEMM's skeleton: 512 threads, the upper 256 load (two register stages, MAP 0 or 1) and, by FLAGS,
+//   1: one workgroup barrier per k-step (the lower 256 threads only take part in the barriers)
+//   2: three 16-byte LDS stores per loaded octet (the raw bits)
+//   4: the lower four waves write a 64 KB slab per workgroup at the end (the split-K partial sums)
+//   8: the lower four waves issue 48 v_mfma_f32_32x32x16_bf16 per k-step on register operands
+template <int BK, int MAP, int KS, int FLAGS>
+__global__ __launch_bounds__(512, 1) void skeleton(const float* __restrict__ A, const float* __restrict__ B, int ld, float* out,
+                                                   float* slabs) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds16[];
+    constexpr int ROWS = 256, THREADS = 256;
+    constexpr int F4 = ROWS * BK / 4 / THREADS;
+    constexpr int NK = KS / BK;
+    constexpr int STAGE = 3 * ROWS * (BK + 8);             // bf16 elements
+    const int tid = threadIdx.x;
+    if (tid >= 256) {
+        const int pt = tid - 256;
+        const size_t k0 = (size_t)blockIdx.x * KS;
+        const float* src[F4];
+        int lrow[F4], lk[F4];
+#pragma unroll
+        for (int t = 0; t < F4; ++t) {
+            int row, kf;
+            if (MAP == 0) { const int e = pt + THREADS * (t >> 1); row = e / (BK / 8); kf = 8 * (e % (BK / 8)) + 4 * (t & 1); }
+            else { const int e = pt + THREADS * t; row = e / (BK / 4); kf = 4 * (e % (BK / 4)); }
+            src[t] = (row < 128 ? A + (size_t)row * ld : B + (size_t)(row - 128) * ld) + k0 + kf;
+            lrow[t] = row; lk[t] = kf;
+        }
+        float4 st[2][F4];
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < F4; ++t) st[0][t] = *reinterpret_cast<const float4*>(src[t]);
+#pragma unroll
+        for (int kt = 0; kt < NK; ++kt) {
+            const int nx = kt + 1 < NK ? kt + 1 : NK - 1;
+#pragma unroll
+            for (int t = 0; t < F4; ++t) st[(kt + 1) & 1][t] = *reinterpret_cast<const float4*>(src[t] + (size_t)nx * BK);
+            __builtin_amdgcn_sched_barrier(0);
+            unsigned short* img = lds16 + (kt & 1) * STAGE;
+#pragma unroll
+            for (int t = 0; t < F4; ++t) {
+                const float4 v = st[kt & 1][t];
+                if (FLAGS & 2) {
+                    unsigned short* dst = img + lrow[t] * (BK + 8) + lk[t];
+                    const uint2 lo = make_uint2(__builtin_bit_cast(unsigned, v.x), __builtin_bit_cast(unsigned, v.y));
+                    const uint2 hi = make_uint2(__builtin_bit_cast(unsigned, v.z), __builtin_bit_cast(unsigned, v.w));
+                    *reinterpret_cast<uint2*>(dst) = lo;
+                    *reinterpret_cast<uint2*>(dst + ROWS * (BK + 8)) = hi;
+                    *reinterpret_cast<uint2*>(dst + 2 * ROWS * (BK + 8)) = lo;
+                } else {
+                    acc += (v.x + v.y) + (v.z + v.w);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (FLAGS & 1) __syncthreads();
+        }
+        if (acc == 12345.678f) out[0] = acc;
+    } else {
+        typedef float f32x16 __attribute__((ext_vector_type(16)));
+        typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+        f32x16 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        uint4 a = make_uint4(tid, 1, 2, 3), b = make_uint4(5, tid, 7, 8);
+#pragma unroll
+        for (int kt = 0; kt < NK; ++kt) {
+            if (FLAGS & 8) {
+#pragma unroll
+                for (int m = 0; m < 12; ++m)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc[i], 0, 0, 0);
+            }
+            if (FLAGS & 1) __syncthreads();
+        }
+        if (FLAGS & 4) {
+            const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
+            float* slab = slabs + (size_t)blockIdx.x * 128 * 128;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = (wave >> 1) * 64 + (i >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    const int n = (wave & 1) * 64 + (i & 1) * 32 + l31;
+                    slab[m * 128 + n] = acc[i][r];
+                }
+        } else if (acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] == 12345.678f) out[1] = 1.f;
+    }
+}
+
+int main() {
+    const int R = 128, K = 50176;
+    const size_t n = (size_t)R * K;
+    float *a, *b, *out, *slabs;
+    CK(hipMalloc(&a, n * 4)); CK(hipMalloc(&b, n * 4)); CK(hipMalloc(&out, 64)); CK(hipMalloc(&slabs, (size_t)512 * 128 * 128 * 4));
+    CK(hipMemset(a, 0, n * 4)); CK(hipMemset(b, 0, n * 4));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto timeit = [&](auto fn, const char* name) {
+        for (int i = 0; i < 3; ++i) fn();
+        hipEventRecord(e0);
+        for (int i = 0; i < 20; ++i) fn();
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("%-64s %8.2f us  %6.2f TB/s\n", name, ms / 20 * 1e3, 2.0 * n * 4 / (ms / 20 * 1e-3) / 1e12);
+    };
+#define RUN(T, BK, ST, MAP, KS) timeit([&] { hipLaunchKernelGGL((stream<T, BK, ST, MAP, KS>), dim3(K / KS), dim3(T), 0, 0, a, b, K, out); }, \
+    "threads " #T "  BK " #BK "  stages " #ST "  map " #MAP "  K-slice " #KS)
+    RUN(256, 32, 2, 0, 256);
+    RUN(256, 32, 3, 0, 256);
+    RUN(256, 32, 4, 0, 256);
+    RUN(256, 32, 3, 1, 256);
+    RUN(512, 32, 3, 0, 256);
+    RUN(512, 32, 5, 0, 256);
+    RUN(512, 32, 5, 1, 256);
+    RUN(512, 64, 3, 0, 256);
+    RUN(512, 64, 3, 1, 256);
+    RUN(256, 64, 2, 0, 256);
+    RUN(256, 64, 2, 1, 256);
+    RUN(512, 32, 5, 1, 128);
+    RUN(512, 64, 3, 1, 128);
+    RUN(512, 128, 2, 1, 256);
+    RUN(1024, 32, 5, 1, 256);
+    RUN(1024, 64, 3, 1, 256);
+#define SK(BK, MAP, KS, FL) { const size_t lds = (size_t)2 * 3 * 256 * (BK + 8) * 2;                                              \
+    CK(hipFuncSetAttribute((const void*)skeleton<BK, MAP, KS, FL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));         \
+    timeit([&] { hipLaunchKernelGGL((skeleton<BK, MAP, KS, FL>), dim3(K / KS), dim3(512), lds, 0, a, b, K, out, slabs); },          \
+    "skeleton BK " #BK "  map " #MAP "  K-slice " #KS "  flags " #FL); }
+    SK(32, 0, 256, 0);
+    SK(32, 0, 256, 1);
+    SK(32, 0, 256, 3);
+    SK(32, 0, 256, 7);
+    SK(32, 0, 256, 15);
+    SK(32, 1, 256, 15);
+    SK(32, 0, 256, 8);
+    SK(32, 0, 256, 9);
+    SK(32, 0, 256, 4);
+    SK(64, 0, 256, 15);
+    SK(64, 1, 256, 15);
+    SK(32, 1, 224, 15);
+    return 0;
+}
