@@ -406,6 +406,14 @@ int r3d_embed_fuse_fwd(const float* rgb_src, int ns_r, const float* bias_r, cons
                        const float* mask_dep, const uint8_t* drop_mask, float drop_scale, const float* ln1_gamma,
                        const float* ln1_beta, float* rgb_out, float* dep_pre_out, float* mean_d, float* rstd_d,
                        float* dep_out, float* x0, float* h1, float* m1, float* r1, int N, int H, void* stream);
+/* r3d_embed_fuse_fwd and r3d_weight_planes (below: jobs_device / njobs / total_blocks as there) in ONE launch: the re-split of
+ * the chain weights rides as extra workgroups of the seam. */
+int r3d_embed_fuse_fwd_planes(const float* rgb_src, int ns_r, const float* bias_r, const float* dep_src, int ns_d,
+                              const float* bias_d, const float* lnd_gamma, const float* lnd_beta, const float* mask_rgb,
+                              const float* mask_dep, const uint8_t* drop_mask, float drop_scale, const float* ln1_gamma,
+                              const float* ln1_beta, float* rgb_out, float* dep_pre_out, float* mean_d, float* rstd_d,
+                              float* dep_out, float* x0, float* h1, float* m1, float* r1, int N, int H,
+                              const r3d_plane_job* jobs_device, int njobs, int total_blocks, void* stream);
 int r3d_embed_fuse_bwd(const float* d_h1, const float* x0, const float* m1, const float* r1, const float* ln1_gamma,
                        const float* add1, const float* add2, const uint8_t* drop_mask, float drop_scale,
                        const float* mask_rgb, const float* mask_dep, const float* rgb, const float* dep_pre,

@@ -19,6 +19,7 @@
 //     and the next stage reads its A operands from them, one k-step (12 registers) ahead of the MFMAs.
 #pragma once
 #include "chain_common.h"
+#include "../../include/r3d_hip.h"
 
 namespace r3d {
 
@@ -112,6 +113,41 @@ __device__ __forceinline__ void bf3_chunk(const unsigned short* img, int pitch, 
         if (s + 1 < NS) bf3_aload(nxt, img, pitch, li, q, s0 + s + 1);
         bf3_mfma6(cur, b.v[s], (s & 1) ? acc1 : acc0);
     }
+}
+
+// One (tile, k-step) block of one job of r3d_weight_planes, by one wave: block `blk` of `total` over all jobs (r3d_hip.h).
+// Also run by rider workgroups of the embedding seam's launch (embed.hip: r3d_embed_fuse_fwd_planes).
+__device__ __forceinline__ void weight_planes_block(const r3d_plane_job* __restrict__ jobs, int njobs, int total, int blk, int lane) {
+    if (blk >= total) return;
+    int j = 0;
+    for (int t = 1; t < njobs; ++t) j += (blk >= jobs[t].first_block) ? 1 : 0;
+    const r3d_plane_job J = jobs[j];
+    const int ksteps = (J.K + 31) / 32;
+    const int local = blk - J.first_block, t = local / ksteps, s = local - t * ksteps;
+    const int n = 16 * t + (lane & 15), k0 = 32 * s + 8 * (lane >> 4);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = k0 + e;
+        const bool in = n < J.N && k < J.K;
+        const size_t idx = J.transposed ? (size_t)(in ? k : 0) * J.ld + (in ? n : 0) : (size_t)(in ? n : 0) * J.ld + (in ? k : 0);
+        const float x = J.src[idx];
+        v[e] = in ? x : 0.f;
+    }
+    unsigned hh[4], mm[4], ll[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        unsigned short h0, m0, l0, h1, m1, l1;
+        bf3_split1(v[2 * p], h0, m0, l0);
+        bf3_split1(v[2 * p + 1], h1, m1, l1);
+        hh[p] = (unsigned)h0 | ((unsigned)h1 << 16);
+        mm[p] = (unsigned)m0 | ((unsigned)m1 << 16);
+        ll[p] = (unsigned)l0 | ((unsigned)l1 << 16);
+    }
+    uint4* dst = reinterpret_cast<uint4*>(J.dst) + (size_t)local * (3 * 64) + lane;
+    dst[0] = make_uint4(hh[0], hh[1], hh[2], hh[3]);
+    dst[64] = make_uint4(mm[0], mm[1], mm[2], mm[3]);
+    dst[128] = make_uint4(ll[0], ll[1], ll[2], ll[3]);
 }
 
 // rows 0..15 of a [3][16][pitch] image <- 16 rows x 128 columns of a dense fp32 matrix (thread = (row, 4 columns))

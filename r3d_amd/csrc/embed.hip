@@ -9,6 +9,7 @@
 // issued up front.  Reductions are wave shuffles / fixed-order LDS sums -> bitwise reproducible.
 #include "common.h"
 #include "../../include/r3d_hip.h"
+#include "chain_bf3.h"
 
 namespace r3d {
 
@@ -22,11 +23,17 @@ struct EmbedFwdArgs {
     float* rgb_out; float* dep_pre_out; float* mean_d; float* rstd_d; float* dep_out;
     float* x0; float* h1; float* m1; float* r1;
     int N, H;
+    // riders (r3d_embed_fuse_fwd_planes): workgroups N .. N + ceil(pl_total / 4) - 1 re-split the chain weights (chain_bf3.h)
+    const r3d_plane_job* pl_jobs; int pl_njobs, pl_total;
 };
 
 template <int EPL>
 __global__ __launch_bounds__(256) void embed_fuse_fwd_kernel(const EmbedFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float red[];       // [8 partials = 4 waves x 2 halves][2 projections][H]
+    if ((int)blockIdx.x >= a.N) {                                     // rider: four (tile, k-step) blocks of the weight planes
+        weight_planes_block(a.pl_jobs, a.pl_njobs, a.pl_total, ((int)blockIdx.x - a.N) * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
+        return;
+    }
     const int n = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, H = a.H;
     const size_t stride = (size_t)a.N * H, rowo = (size_t)n * H;
     int cc[EPL];
@@ -335,21 +342,43 @@ R3D_EXPORT int r3d_embed_fuse_bwd(const float* d_h1, const float* x0, const floa
  * (ns_d >= 1; a finished pre-LayerNorm matrix is one slab), bias_d optional.  Outputs: rgb_out, dep_pre_out (pre-LN),
  * mean_d / rstd_d [N], dep_out (post ReLU), x0 [2N,H] (exchanged + dropped tokens), h1 = norm1(x0), m1 / r1 [2N].
  * All matrices contiguous with leading dimension H; H <= 1024. */
+static int embed_fuse_fwd_launch(EmbedFwdArgs a, hipStream_t s) {
+    R3D_REQUIRE(a.rgb_src && a.dep_src && a.lnd_g && a.lnd_b && a.m_rgb && a.m_dep && a.ln1_g && a.ln1_b);
+    R3D_REQUIRE(a.rgb_out && a.dep_pre_out && a.mean_d && a.rstd_d && a.dep_out && a.x0 && a.h1 && a.m1 && a.r1);
+    R3D_REQUIRE(a.N > 0 && a.H > 0 && a.H <= 1024 && a.ns_r >= 0 && a.ns_d >= 1);
+    const size_t shmem = (size_t)16 * a.H * sizeof(float);
+    const int grid = a.N + (a.pl_jobs ? r3d_cdiv(a.pl_total, 4) : 0);
+    if (a.H <= 128) hipLaunchKernelGGL(embed_fuse_fwd_kernel<2>, dim3(grid), dim3(256), shmem, s, a);
+    else if (a.H <= 512) hipLaunchKernelGGL(embed_fuse_fwd_kernel<8>, dim3(grid), dim3(256), shmem, s, a);
+    else hipLaunchKernelGGL(embed_fuse_fwd_kernel<16>, dim3(grid), dim3(256), shmem, s, a);
+    R3D_LAUNCH_CHECK();
+    return R3D_OK;
+}
+
 R3D_EXPORT int r3d_embed_fuse_fwd(const float* rgb_src, int ns_r, const float* bias_r, const float* dep_src, int ns_d,
                                   const float* bias_d, const float* lnd_gamma, const float* lnd_beta, const float* mask_rgb,
                                   const float* mask_dep, const uint8_t* drop_mask, float drop_scale, const float* ln1_gamma,
                                   const float* ln1_beta, float* rgb_out, float* dep_pre_out, float* mean_d, float* rstd_d,
                                   float* dep_out, float* x0, float* h1, float* m1, float* r1, int N, int H, void* stream) {
-    R3D_REQUIRE(rgb_src && dep_src && lnd_gamma && lnd_beta && mask_rgb && mask_dep && ln1_gamma && ln1_beta);
-    R3D_REQUIRE(rgb_out && dep_pre_out && mean_d && rstd_d && dep_out && x0 && h1 && m1 && r1);
-    R3D_REQUIRE(N > 0 && H > 0 && H <= 1024 && ns_r >= 0 && ns_d >= 1);
     EmbedFwdArgs a{rgb_src, ns_r, bias_r, dep_src, ns_d, bias_d, lnd_gamma, lnd_beta, mask_rgb, mask_dep, drop_mask,
-                   drop_scale, ln1_gamma, ln1_beta, rgb_out, dep_pre_out, mean_d, rstd_d, dep_out, x0, h1, m1, r1, N, H};
-    const size_t shmem = (size_t)16 * H * sizeof(float);
-    hipStream_t s = (hipStream_t)stream;
-    if (H <= 128) hipLaunchKernelGGL(embed_fuse_fwd_kernel<2>, dim3(N), dim3(256), shmem, s, a);
-    else if (H <= 512) hipLaunchKernelGGL(embed_fuse_fwd_kernel<8>, dim3(N), dim3(256), shmem, s, a);
-    else hipLaunchKernelGGL(embed_fuse_fwd_kernel<16>, dim3(N), dim3(256), shmem, s, a);
-    R3D_LAUNCH_CHECK();
-    return R3D_OK;
+                   drop_scale, ln1_gamma, ln1_beta, rgb_out, dep_pre_out, mean_d, rstd_d, dep_out, x0, h1, m1, r1, N, H,
+                   nullptr, 0, 0};
+    return embed_fuse_fwd_launch(a, (hipStream_t)stream);
+}
+
+/* r3d_embed_fuse_fwd + r3d_weight_planes(jobs_device, njobs, total_blocks) in ONE launch: the re-split of the chain weights
+ * (which depends on the parameters only) rides as extra workgroups of the seam, whose own 128 workgroups are latency-bound
+ * and leave half the chip idle. */
+R3D_EXPORT int r3d_embed_fuse_fwd_planes(const float* rgb_src, int ns_r, const float* bias_r, const float* dep_src, int ns_d,
+                                         const float* bias_d, const float* lnd_gamma, const float* lnd_beta,
+                                         const float* mask_rgb, const float* mask_dep, const uint8_t* drop_mask,
+                                         float drop_scale, const float* ln1_gamma, const float* ln1_beta, float* rgb_out,
+                                         float* dep_pre_out, float* mean_d, float* rstd_d, float* dep_out, float* x0, float* h1,
+                                         float* m1, float* r1, int N, int H, const r3d_plane_job* jobs_device, int njobs,
+                                         int total_blocks, void* stream) {
+    R3D_REQUIRE(jobs_device && njobs > 0 && total_blocks > 0);
+    EmbedFwdArgs a{rgb_src, ns_r, bias_r, dep_src, ns_d, bias_d, lnd_gamma, lnd_beta, mask_rgb, mask_dep, drop_mask,
+                   drop_scale, ln1_gamma, ln1_beta, rgb_out, dep_pre_out, mean_d, rstd_d, dep_out, x0, h1, m1, r1, N, H,
+                   jobs_device, njobs, total_blocks};
+    return embed_fuse_fwd_launch(a, (hipStream_t)stream);
 }

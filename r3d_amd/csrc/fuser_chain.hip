@@ -589,44 +589,7 @@ __global__ __launch_bounds__(512) void fuser_chain_fwd_bf3_kernel(const FcFwd A)
 // operand-order bf16x3 planes of the chain weights (chain_bf3.h): one wave per (tile, k-step) block of one job
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void weight_planes_kernel(const r3d_plane_job* __restrict__ jobs, int njobs, int total) {
-    const int lane = threadIdx.x & 63;
-    const int blk = (int)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (blk >= total) return;
-    int j = 0;
-    for (int t = 1; t < njobs; ++t) j += (blk >= jobs[t].first_block) ? 1 : 0;
-    const r3d_plane_job J = jobs[j];
-    const int ksteps = (J.K + 31) / 32;
-    const int local = blk - J.first_block, t = local / ksteps, s = local - t * ksteps;
-    const int n = 16 * t + (lane & 15), k0 = 32 * s + 8 * (lane >> 4);
-    float v[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int k = k0 + e;
-        const bool in = n < J.N && k < J.K;
-        const size_t idx = J.transposed ? (size_t)(in ? k : 0) * J.ld + (in ? n : 0) : (size_t)(in ? n : 0) * J.ld + (in ? k : 0);
-        const float x = J.src[idx];
-        v[e] = in ? x : 0.f;
-    }
-    uint4 h, m, l;
-    {
-        unsigned hh[4], mm[4], ll[4];
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            unsigned short h0, m0, l0, h1, m1, l1;
-            bf3_split1(v[2 * p], h0, m0, l0);
-            bf3_split1(v[2 * p + 1], h1, m1, l1);
-            hh[p] = (unsigned)h0 | ((unsigned)h1 << 16);
-            mm[p] = (unsigned)m0 | ((unsigned)m1 << 16);
-            ll[p] = (unsigned)l0 | ((unsigned)l1 << 16);
-        }
-        h = make_uint4(hh[0], hh[1], hh[2], hh[3]);
-        m = make_uint4(mm[0], mm[1], mm[2], mm[3]);
-        l = make_uint4(ll[0], ll[1], ll[2], ll[3]);
-    }
-    uint4* dst = reinterpret_cast<uint4*>(J.dst) + (size_t)local * (3 * 64) + lane;
-    dst[0] = h;
-    dst[64] = m;
-    dst[128] = l;
+    weight_planes_block(jobs, njobs, total, (int)blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
 }
 
 __global__ __launch_bounds__(512) void fuser_chain_fwd_kernel(const FcFwd A) {

@@ -234,6 +234,10 @@ class FusionEngine:
         # side-stream query branch; only the 0.5 ms Jacobi sweep is long enough to pay for its join).
         self.overlap_planes = False
         self.overlap_param_tail = False
+        # ... what does pay: the re-split as RIDER workgroups of the embedding seam's launch (csrc/embed.hip: the seam's 128
+        # workgroups are latency-bound and leave half the chip idle) -- one launch and ~6 us less per step
+        self.ride_planes = True
+        self._planes_rode = False
         self._planes_forked = False
         self._tail_pending = False
         self._overlap_tail_now = False
@@ -439,10 +443,15 @@ class FusionEngine:
                 dep_src, ns_d, bias_d = fw["slabs"], d.splitk, a.p("depth_projection.bias")
             else:
                 dep_src, ns_d, bias_d = w.dep_pre, 1, None
+            ride = bool(self.ride_planes and self.chain_bf3 and not self._planes_forked and self.L == 1 and H < 512 and
+                        not self.use_side_stream and not self.use_fused_decoder and self.use_paired_launches and
+                        ((self.use_fuser_chain and self._chain_shape_ok(w)) or self._dec_chain_ok(w)))
             ops.embed_fuse_fwd(fw["slabs_r"] if dr.splitk > 1 else w.rgb, dr.splitk if dr.splitk > 1 else 0,
                                a.p("input_embed.bias"), dep_src, ns_d, bias_d, a.p("depth_layernorm.weight"),
                                a.p("depth_layernorm.bias"), mask[0], mask[1], dm("x0"), dsc, a.p(pre + "norm1.weight"),
-                               a.p(pre + "norm1.bias"), w.rgb, w.dep_pre, w.mean_d, w.rstd_d, w.dep, w.x0, w.h1, w.m1, w.r1)
+                               a.p(pre + "norm1.bias"), w.rgb, w.dep_pre, w.mean_d, w.rstd_d, w.dep, w.x0, w.h1, w.m1, w.r1,
+                               planes=self.chain_planes() if ride else None)
+            self._planes_rode = ride
         # ---- depth LayerNorm + ReLU first: it drains the deferred split-K slabs (:196-197)
         elif tp is not None:                      # the exchanged sum of the ranks' partial products, bias still to add
             ops.layernorm_fwd(tp.summed(w), a.p("depth_layernorm.weight"), a.p("depth_layernorm.bias"), w.dep, w.mean_d,
@@ -552,6 +561,7 @@ class FusionEngine:
         if self._planes_forked:                # (no chain launch consumed the branch: eval shapes the decoder chain skips)
             main.wait_stream(self.side)
             self._planes_forked = False
+        self._planes_rode = False
         er = self.erank_weight != 0.0 and hasattr(w, "glayers")
         if er and not w.__dict__.get("_er_forked", False):
             self._erank_forward(w)
@@ -653,6 +663,8 @@ class FusionEngine:
         if self._planes_forked:
             torch.cuda.current_stream().wait_stream(self.side)
             self._planes_forked = False
+        elif self._planes_rode:                 # (the seam's launch of this forward carried the re-split)
+            pass
         else:
             self.chain_planes().refresh()
 

@@ -692,8 +692,15 @@ def decoder_tail_bwd(d_out, w_head, t3, mF, rF, gF, x, m3, r3, g3, drop_mask, dr
 
 
 def embed_fuse_fwd(rgb_src, ns_r, bias_r, dep_src, ns_d, bias_d, lnd_g, lnd_b, m_rgb, m_dep, drop, drop_scale, ln1_g, ln1_b,
-                   rgb_out, dep_pre_out, mean_d, rstd_d, dep_out, x0, h1, m1, r1):
+                   rgb_out, dep_pre_out, mean_d, rstd_d, dep_out, x0, h1, m1, r1, planes=None):
+    """planes (a WeightPlanes): its refresh() rides in the same launch as extra workgroups."""
     N, H = dep_out.shape
+    if planes is not None:
+        check(_lib.load().r3d_embed_fuse_fwd_planes(
+            _p(rgb_src), ns_r, _p(bias_r), _p(dep_src), ns_d, _p(bias_d), _p(lnd_g), _p(lnd_b), _p(m_rgb), _p(m_dep), _p(drop),
+            drop_scale, _p(ln1_g), _p(ln1_b), _p(rgb_out), _p(dep_pre_out), _p(mean_d), _p(rstd_d), _p(dep_out), _p(x0), _p(h1),
+            _p(m1), _p(r1), N, H, _p(planes.jobs_dev), planes.njobs, planes.blocks, _stream()), "r3d_embed_fuse_fwd_planes")
+        return
     check(_lib.load().r3d_embed_fuse_fwd(_p(rgb_src), ns_r, _p(bias_r), _p(dep_src), ns_d, _p(bias_d), _p(lnd_g), _p(lnd_b),
                                          _p(m_rgb), _p(m_dep), _p(drop), drop_scale, _p(ln1_g), _p(ln1_b), _p(rgb_out),
                                          _p(dep_pre_out), _p(mean_d), _p(rstd_d), _p(dep_out), _p(x0), _p(h1), _p(m1),
