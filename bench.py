@@ -319,6 +319,11 @@ def main():
     ap.add_argument("--no-decoder-chain", action="store_true",
                     help="the decoder layer's query side as separate attention / GEMM / LayerNorm / loss launches instead of "
                          "the one-launch decoder chain kernel (A/B)")
+    ap.add_argument("--no-ride-planes", action="store_true",
+                    help="re-split the chain weights in a launch of its own instead of as rider workgroups of the embedding seam (A/B)")
+    ap.add_argument("--no-pair-embeddings", action="store_true",
+                    help="the RGB embedding as a launch of its own (fp32 MFMA) instead of as a second product of the depth "
+                         "projection's launch (A/B)")
     ap.add_argument("--overlap-planes", action="store_true",
                     help="re-split the chain weights on a parallel branch of the graph beside the input projections instead "
                          "of in stream order in front of the fuser chain (measured slower: the join costs more; A/B)")
@@ -398,6 +403,8 @@ def main():
     eng.use_decoder_chain = not a.no_decoder_chain
     eng.chain_bf3 = not a.chain_fp32
     eng.overlap_planes = a.overlap_planes
+    eng.ride_planes = not a.no_ride_planes
+    eng.pair_embeddings = not a.no_pair_embeddings
     eng.overlap_param_tail = a.overlap_param_tail
     eng.erank_side_stream = not a.erank_main_stream
     if a.no_paired:

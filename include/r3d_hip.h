@@ -120,6 +120,11 @@ int r3d_gemm_f32(const r3d_gemm_desc* d, void* stream);
 int r3d_splitk_reduce(const r3d_gemm_desc* d, void* stream);
 /* Workspace floats r3d_gemm_f32 needs in d->partial for this (M,N,splitk). */
 int64_t r3d_gemm_partial_floats(int32_t M, int32_t N, int32_t splitk);
+/* Two split-K NT products with the same M x N, both on tile 8 (prec == 1; K % 8 == 0, k_per_split % 64 == 0, partial set and
+ * distinct), in ONE launch: the second product's K-splits take the workgroups after the first's; the raw slabs of both are left
+ * for the caller's reducer (r3d_embed_fuse_fwd: the depth projection and the RGB embedding of
+ * model/futr_safuser_tokenfusion.py:179,194-195 side by side). */
+int r3d_gemm_bf3_nt_pair(const r3d_gemm_desc* first, const r3d_gemm_desc* second, void* stream);
 /* Heuristic the host uses to pick (tile, splitk, k_per_split) for a shape on a 256-CU part; fills the desc. */
 int r3d_gemm_plan(r3d_gemm_desc* d);
 /* Grouped launch: n independent problems of one layout in ONE kernel (all weight gradients of a step; each is

@@ -210,6 +210,7 @@ _SIGNATURES = {
     "r3d_decoder_layer_fwd": ([_P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P], C.c_int),
     "r3d_embed_fuse_fwd": ([_P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I,
                             _P], C.c_int),
+    "r3d_gemm_bf3_nt_pair": ([_P, _P, _P], C.c_int),
     "r3d_embed_fuse_fwd_planes": ([_P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I,
                                    _I, _P, _I, _I, _P], C.c_int),
     "r3d_embed_fuse_bwd": ([_P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],

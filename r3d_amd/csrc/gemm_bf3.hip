@@ -306,8 +306,12 @@ __global__ __launch_bounds__(512, 1) void wgrad_panel_bf3_kernel(const r3d_gemm_
         __builtin_amdgcn_sched_group_barrier(0x002, R3D_NTU_V, 0);                                        \
     }
 #endif
+// An optional SECOND product with the same M x N (r3d_gemm_bf3_nt_pair: the RGB embedding beside the depth projection): its
+// K-splits take the workgroups after the first product's -- at the headline shape exactly the 12 of the 256 placed workgroups
+// that the first product's 61 splits x 4 tiles leave without work.
+struct NtSecond { const float* A; const float* B; float* partial; int lda, ldb, K, k_per_split, NG2; };
 template <int BM, int BN, int BK>
-__global__ __launch_bounds__(512, 1) void gemm_bf3_nt_kernel(const r3d_gemm_desc d, const int G, const int NG) {
+__global__ __launch_bounds__(512, 1) void gemm_bf3_nt_kernel(const r3d_gemm_desc d, const int G, const int NG, const NtSecond s2) {
     constexpr int S = BK + 8;                                  // bf16 per image row
     constexpr int OPR = BK / 8;                                // octets per row
     constexpr int PLANE_A = BM * S, PLANE_B = BN * S;
@@ -322,12 +326,21 @@ __global__ __launch_bounds__(512, 1) void gemm_bf3_nt_kernel(const r3d_gemm_desc
     const int l31 = lane & 31, lhi = lane >> 5;
     // XCD-aware placement (see gemm_f32_kernel): group g = one K-split goes to XCD g % 8, its G tiles sit at stride 8
     const int p = blockIdx.x, idx = p >> 3;
-    const int split = (idx / G) * 8 + (p & 7), tile = idx % G;
-    if (split >= NG) return;
+    int split = (idx / G) * 8 + (p & 7);
+    const int tile = idx % G;
+    const float* pA = d.A;
+    const float* pB = d.B;
+    float* ppart = d.partial;
+    int plda = d.lda, pldb = d.ldb, pK = d.K, pkps = d.k_per_split;
+    if (split >= NG) {                                              // (uniform) the second product's splits, or nothing
+        split -= NG;
+        if (split >= s2.NG2) return;
+        pA = s2.A; pB = s2.B; ppart = s2.partial; plda = s2.lda; pldb = s2.ldb; pK = s2.K; pkps = s2.k_per_split;
+    }
     const int tiles_n = (d.N + BN - 1) / BN;
     const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
-    const int k_begin = split * d.k_per_split;
-    const int k_end = min(d.K, k_begin + d.k_per_split);
+    const int k_begin = split * pkps;
+    const int k_end = min(pK, k_begin + pkps);
     const int nk = (k_end - k_begin + BK - 1) / BK;
 #ifdef R3D_NT_PRIO
     if (wave < 4) __builtin_amdgcn_s_setprio((R3D_NT_PRIO) & 3); else __builtin_amdgcn_s_setprio(((R3D_NT_PRIO) >> 2) & 3);
@@ -389,7 +402,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf3_nt_kernel(const r3d_gemm_desc
         R3D_NT_MARK(1 + 2 * nk);
         if (nk & 1) __syncthreads();                                // (the producers' loop runs whole pairs of k-steps)
         // raw partial sums -> slab `split` (C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
-        float* slab = d.partial + (size_t)split * d.M * d.N;
+        float* slab = ppart + (size_t)split * d.M * d.N;
         const bool whole = m0 + BM <= d.M && n0 + BN <= d.N;        // (uniform: a whole tile stores without per-element branches)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -431,10 +444,10 @@ __global__ __launch_bounds__(512, 1) void gemm_bf3_nt_kernel(const r3d_gemm_desc
             const int gr = isa ? m0 + row : n0 + (row - BM);
             const int lim = isa ? d.M : d.N;
             rok[t] = gr < lim;
-            const size_t off = (size_t)(rok[t] ? gr : 0) * (size_t)(isa ? d.lda : d.ldb);
-            rowp[t] = (isa ? d.A : d.B) + off + 8 * (e % OPR);
+            const size_t off = (size_t)(rok[t] ? gr : 0) * (size_t)(isa ? plda : pldb);
+            rowp[t] = (isa ? pA : pB) + off + 8 * (e % OPR);
         }
-        const int Kt = d.K;
+        const int Kt = pK;
         float4 s0[2 * NOCT], s1[2 * NOCT];
         auto load_stage = [&](float4* reg, int kt) {
             const int k0 = k_begin + kt * BK;
@@ -702,7 +715,7 @@ bool gemm_bf3_nt_ok(const r3d_gemm_desc& d) {
 }
 
 template <int BM, int BN, int BK>
-static int launch_bf3_nt_cfg(const r3d_gemm_desc& d, hipStream_t s) {
+static int launch_bf3_nt_cfg(const r3d_gemm_desc& d, hipStream_t s, const NtSecond s2 = NtSecond{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0}) {
     const int tiles = r3d_cdiv(d.M, BM) * r3d_cdiv(d.N, BN);
     const int ns = r3d_cdiv(d.K, d.k_per_split);
     const size_t lds = (size_t)2 * 3 * (BM + BN) * (BK + 8) * sizeof(unsigned short);
@@ -712,9 +725,17 @@ static int launch_bf3_nt_cfg(const r3d_gemm_desc& d, hipStream_t s) {
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_bf3_nt_kernel<BM, BN, BK>), dim3(8 * tiles * r3d_cdiv(ns, 8)), dim3(512), lds, s, d, tiles, ns);
+    hipLaunchKernelGGL((gemm_bf3_nt_kernel<BM, BN, BK>), dim3(8 * tiles * r3d_cdiv(ns + s2.NG2, 8)), dim3(512), lds, s, d, tiles, ns, s2);
     R3D_LAUNCH_CHECK();
     return R3D_OK;
+}
+
+// two planned split-K NT products with the same M x N in one launch of the 64 x 64 x 64 tile (see NtSecond)
+int launch_gemm_bf3_nt_pair(const r3d_gemm_desc& d, const r3d_gemm_desc& e, hipStream_t s) {
+    if (d.tile != 8 || e.tile != 8 || !gemm_bf3_nt_ok(d) || !gemm_bf3_nt_ok(e)) return R3D_EINVAL;
+    if (d.M != e.M || d.N != e.N || d.partial == e.partial) return R3D_EINVAL;
+    const NtSecond s2{e.A, e.B, e.partial, e.lda, e.ldb, e.K, e.k_per_split, r3d_cdiv(e.K, e.k_per_split)};
+    return launch_bf3_nt_cfg<64, 64, 64>(d, s, s2);
 }
 
 int launch_gemm_bf3_nt(const r3d_gemm_desc& d, hipStream_t s) {

@@ -735,6 +735,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_panel_kernel(const r3d_gemm_desc
 
 int launch_wgrad_panel_bf3(const r3d_gemm_desc& d, hipStream_t s);         // gemm_bf3.hip
 int launch_gemm_bf3_nt(const r3d_gemm_desc& d, hipStream_t s);
+int launch_gemm_bf3_nt_pair(const r3d_gemm_desc& d, const r3d_gemm_desc& e, hipStream_t s);
 bool gemm_bf3_nt_ok(const r3d_gemm_desc& d);
 int launch_gemm_bf3_tn(const r3d_gemm_desc& d, hipStream_t s);
 bool gemm_bf3_tn_ok(const r3d_gemm_desc& d);
@@ -922,6 +923,16 @@ R3D_EXPORT int r3d_gemm_plan(r3d_gemm_desc* d) {
         }
     }
     return R3D_OK;
+}
+
+/* Two split-K NT products with the same M x N (both planned onto tile 8: prec == 1, splitk > 1, partial set, raw slabs left
+ * for the caller's reducer) in ONE launch: the second product's K-splits take the workgroups after the first's. */
+R3D_EXPORT int r3d_gemm_bf3_nt_pair(const r3d_gemm_desc* first, const r3d_gemm_desc* second, void* stream) {
+    int rc = gemm_validate(first);
+    if (rc != R3D_OK) return rc;
+    rc = gemm_validate(second);
+    if (rc != R3D_OK) return rc;
+    return launch_gemm_bf3_nt_pair(*first, *second, (hipStream_t)stream);
 }
 
 R3D_EXPORT int r3d_gemm_f32(const r3d_gemm_desc* dp, void* stream) {

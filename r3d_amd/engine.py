@@ -238,6 +238,10 @@ class FusionEngine:
         # workgroups are latency-bound and leave half the chip idle) -- one launch and ~6 us less per step
         self.ride_planes = True
         self._planes_rode = False
+        # the RGB embedding (input_embed, K = 2048) as a second product of the depth projection's launch: 61 K-splits x 4 tiles
+        # occupy 244 of the 256 placed workgroups, the RGB product's 3 K-splits x 4 tiles take the other 12 -- one launch less,
+        # no workgroup works longer than before; the RGB product then runs on the bf16 matrix cores too (same exact split)
+        self.pair_embeddings = True
         self._planes_forked = False
         self._tail_pending = False
         self._overlap_tail_now = False
@@ -369,12 +373,22 @@ class FusionEngine:
             self._planes_forked = True
         # (running this GEMM on the side stream beside the 5x longer depth projection was measured: the cross-queue
         #  join costs more than the 5 us it hides)
-        dr = ops.gemm(GEMM_NT, x_rgb, a.p("input_embed.weight"), w.rgb, bias=a.p("input_embed.bias"), act=1,
-                      ws=self.ws_side if seam else self.ws, defer_reduce=seam)
         rgb_done = None
+        dr = d = None
+        if seam and tp is None and self.depth_prec == 1 and self.pair_embeddings:
+            # both input projections in ONE launch: the RGB embedding's K-splits take the workgroup slots the depth
+            # projection's leave empty (ops.gemm_bf3_nt_pair); bias / ReLU / LayerNorm are the seam's either way
+            pr = ops.gemm_bf3_nt_pair(x_dep, a.p("depth_projection.weight"), w.dep_pre, self.ws,
+                                      x_rgb, a.p("input_embed.weight"), w.rgb, self.ws_side)
+            if pr is not None:
+                d, dr = pr
+        if dr is None:
+            dr = ops.gemm(GEMM_NT, x_rgb, a.p("input_embed.weight"), w.rgb, bias=a.p("input_embed.bias"), act=1,
+                          ws=self.ws_side if seam else self.ws, defer_reduce=seam)
         slabs_r = self.ws_side.buf if (seam and dr.splitk > 1) else None
-        d = None
-        if tp is None:
+        if d is not None:
+            pass
+        elif tp is None:
             d = ops.gemm(GEMM_NT, x_dep, a.p("depth_projection.weight"), w.dep_pre, bias=a.p("depth_projection.bias"),
                          ws=self.ws, defer_reduce=True, prec=self.depth_prec)    # (:194-195)
         else:

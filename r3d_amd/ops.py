@@ -144,6 +144,33 @@ def gemm(layout, a, b, c, *, ws=None, tile=0, splitk=0, defer_reduce=False, adam
     return d
 
 
+def gemm_bf3_nt_pair(a1, b1, c1, ws1, a2, b2, c2, ws2):
+    """The long-K product C1 = A1 B1^T (planned onto the bf16x3 split-K tile 8) and a second NT product with the same M x N in
+    ONE launch (r3d_gemm_bf3_nt_pair): the second product's K-splits fill the workgroup slots the first leaves empty in its last
+    group of 8 (61 splits x 4 tiles = 244 of 256 at the headline shape).  Both leave raw slabs (ws1.buf, ws2.buf) for the
+    caller's reducer.  Returns (d1, d2), or None when the shapes do not allow it (the caller launches them separately)."""
+    lib = _lib.load()
+    d1, d2 = GemmDesc(), GemmDesc()
+    M, N, K1 = _fill_desc(d1, GEMM_NT, a1, b1, c1, prec=1)
+    M2, N2, K2 = _fill_desc(d2, GEMM_NT, a2, b2, c2, prec=1)
+    check(lib.r3d_gemm_plan(C.byref(d1)), "r3d_gemm_plan")
+    if d1.tile != 8 or d1.splitk < 2 or (M2, N2) != (M, N) or K2 % 8 or K2 < 64:
+        return None
+    spare = -d1.splitk % 8
+    if spare == 0:
+        return None
+    kps2 = ((K2 + spare - 1) // spare + 63) // 64 * 64
+    if kps2 > d1.k_per_split:                   # (its workgroups would outlast the first product's)
+        return None
+    d2.tile, d2.k_per_split, d2.splitk = 8, kps2, (K2 + kps2 - 1) // kps2
+    if d2.splitk < 2:
+        return None
+    d1.partial = ws1.get(lib.r3d_gemm_partial_floats(M, N, d1.splitk)).data_ptr()
+    d2.partial = ws2.get(lib.r3d_gemm_partial_floats(M, N, d2.splitk)).data_ptr()
+    check(lib.r3d_gemm_bf3_nt_pair(C.byref(d1), C.byref(d2), _stream()), "r3d_gemm_bf3_nt_pair")
+    return d1, d2
+
+
 class GemmGroup:
     """A set of independent GEMMs of one layout that run as ONE launch (r3d_gemm_grouped_*).  Built once per shape:
     descriptors and the workgroup prefix table are uploaded to device memory; launch() replays them.  The problems may

@@ -395,7 +395,7 @@ def test_adamw_in_weight_gradient_epilogue_equals_flat_adamw():
                                    dict(ride_attention_bwd=True), dict(split_k4h=True), dict(use_fuser_chain=False),
                                    dict(use_decoder_chain=False), dict(use_decoder_chain=False, use_fuser_chain=False),
                                    dict(use_decoder_chain=True, use_fused_tail=False), dict(chain_bf3=False),
-                                   dict(overlap_planes=True), dict(overlap_param_tail=True), dict(ride_planes=False)])
+                                   dict(overlap_planes=True), dict(overlap_param_tail=True), dict(ride_planes=False), dict(pair_embeddings=False)])
 @pytest.mark.parametrize("tag,training", [("step_cfg2", True), ("step_k122_dec2", False)])
 def test_launch_fusion_paths_agree(tag, training, flags):
     """Every launch-fusion switch of the engine (decoder tail kernel, paired GEMM launches, embedding seam, side stream,
