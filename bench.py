@@ -101,7 +101,8 @@ def kernel_rooflines(eng, c):
                      prec=eng.depth_prec)
         return d
     t = time_kernel(fwd)
-    out["depth_projection_fwd (" + ("gemm_bf3_nt_kernel split-K: bf16x3 split, fp32 accumulate" if bf3
+    out["depth_projection_fwd (" + ("gemm_bf3_nt_kernel split-K: bf16x3 split, fp32 accumulate; timed alone -- in the step the "
+                                    "same launch also carries the RGB embedding's 12 workgroups" if bf3
                                     else "gemm_f32 NT split-K") + ")"] = dict(
         seconds=t, flops=2.0 * N * P * H, bytes=4.0 * (N * P + H * P + N * H))
     lr_t, step_t = eng.lr_t, eng.step_t

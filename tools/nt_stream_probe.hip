@@ -186,8 +186,6 @@ int main() {
     SK(32, 0, 256, 8);
     SK(32, 0, 256, 9);
     SK(32, 0, 256, 4);
-    SK(64, 0, 256, 15);
-    SK(64, 1, 256, 15);
     SK(32, 1, 224, 15);
     return 0;
 }
