@@ -156,6 +156,8 @@ def gemm_bf3_nt_pair(a1, b1, c1, ws1, a2, b2, c2, ws2):
     check(lib.r3d_gemm_plan(C.byref(d1)), "r3d_gemm_plan")
     if d1.tile != 8 or d1.splitk < 2 or (M2, N2) != (M, N) or K2 % 8 or K2 < 64:
         return None
+    if any(t.data_ptr() % 16 or t.stride(0) % 4 for t in (a2, b2)):      # (the bf16x3 kernel loads 16-byte row segments)
+        return None
     spare = -d1.splitk % 8
     if spare == 0:
         return None
