@@ -90,6 +90,58 @@ __global__ __launch_bounds__(256) void embed_fuse_fwd_kernel(const EmbedFwdArgs 
             *reinterpret_cast<float4*>(red + ((size_t)(wave * 2 + j) * 2 + 0) * H + 4 * c4) = ra;
             *reinterpret_cast<float4*>(red + ((size_t)(wave * 2 + j) * 2 + 1) * H + 4 * c4) = da;
         }
+    } else if (EPL >= 4 && (H & 3) == 0 && (((uintptr_t)a.rgb_src | (uintptr_t)a.dep_src) & 15) == 0) {
+        // wide rows (hidden 256 .. 1024): a lane takes EPL / 4 float4 columns of the row; the wave's slabs (w, w + 4, ...) go
+        // four at a time, so EPL loads per projection are in flight per lane instead of dependent batches of scalar loads
+        // (cfg4's per-GPU shape: 24.2 -> see DESIGN 4)
+        constexpr int NV = EPL >= 4 ? EPL / 4 : 1;              // (EPL 2 never takes this branch)
+        const int H4 = H >> 2;
+        const size_t st4 = stride >> 2;
+        int c4[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) c4[v] = lane + 64 * v < H4 ? lane + 64 * v : 0;
+        const float4* pr = reinterpret_cast<const float4*>(a.rgb_src + rowo);
+        const float4* pd = reinterpret_cast<const float4*>(a.dep_src + rowo);
+        auto slab_sum = [&](const float4* p, int ns, float4 (&acc)[NV]) {
+            for (int base = 0; base < ns; base += 16) {
+                float4 x[4][NV];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int sl = base + wave + 4 * i;
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) x[i][v] = p[(size_t)(sl < ns ? sl : ns - 1) * st4 + c4[v]];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool in = base + wave + 4 * i < ns;
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) {
+                        acc[v].x += in ? x[i][v].x : 0.f; acc[v].y += in ? x[i][v].y : 0.f;
+                        acc[v].z += in ? x[i][v].z : 0.f; acc[v].w += in ? x[i][v].w : 0.f;
+                    }
+                }
+            }
+        };
+        float4 ra[NV], da[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) { ra[v] = make_float4(0.f, 0.f, 0.f, 0.f); da[v] = ra[v]; }
+        if (a.ns_r > 0) slab_sum(pr, a.ns_r, ra);
+        else if (wave == 0) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) ra[v] = pr[c4[v]];
+        }
+        slab_sum(pd, a.ns_d, da);
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int c = lane + 64 * v;
+            if (c < H4) {
+                *reinterpret_cast<float4*>(red + ((size_t)(wave * 2) * 2 + 0) * H + 4 * c) = ra[v];
+                *reinterpret_cast<float4*>(red + ((size_t)(wave * 2) * 2 + 1) * H + 4 * c) = da[v];
+                *reinterpret_cast<float4*>(red + ((size_t)(wave * 2 + 1) * 2 + 0) * H + 4 * c) = z4;
+                *reinterpret_cast<float4*>(red + ((size_t)(wave * 2 + 1) * 2 + 1) * H + 4 * c) = z4;
+            }
+        }
     } else {
         float ar[EPL], ad[EPL];
 #pragma unroll

@@ -895,7 +895,8 @@ R3D_EXPORT int r3d_gemm_plan(r3d_gemm_desc* d) {
     d->tile = bt;
     d->splitk = bs;
     d->k_per_split = (bs > 1) ? bk : d->K;
-    if (d->prec == 1 && d->layout == R3D_GEMM_NT && d->K >= 8192 && (d->K & 7) == 0 && !d->a_add && !d->a_row_xor &&
+    if (d->prec == 1 && d->layout == R3D_GEMM_NT && (d->K >= 8192 || (d->K >= 2048 && (long)d->M * d->N >= 256L * 256L)) && (d->K & 7) == 0 &&
+        !d->a_add && !d->a_row_xor &&
         d->alpha == 1.0f && (d->lda & 3) == 0 && (d->ldb & 3) == 0 && r3d_aligned16(d->A) && r3d_aligned16(d->B)) {
         // long-K NT product on the bf16 matrix cores (gemm_bf3.hip): 64 x 64 tiles while they are few, 128 x 128 beyond;
         // as many K-splits as fill the chip once (one workgroup per CU), each a multiple of 64 deep

@@ -267,6 +267,9 @@ class FusionEngine:
         # the two depth-projection GEMMs (83 % of the step's FLOPs) on the bf16 matrix cores through an exact three-way
         # operand split (csrc/gemm_bf3.hip; error per product <= 3 * 2^-24); 0 = the fp32 MFMA everywhere
         self.depth_prec = 1
+        # (the fuser MLP's two forward products at hidden >= 512 through the same split-K bf16x3 kernel + reducer: measured
+        #  SLOWER -- cfg4's per-GPU shape 1.157 -> 1.236 ms, cfg5's 1.716 -> 1.746: two K-splits of 8 k-steps pay the kernel's
+        #  prologue / epilogue twice and the reducer re-reads 16 MB of slabs; they stay on the fp32 64 x 64 tiles)
         self.use_fused_embed = not self.bn       # train mode: projections' slab sums + LN + exchange + norm1 in one launch
         # False: train()-state steps without dropout (parity runs against a reference whose dropout probabilities were
         # set to 0; RNG streams cannot match).  Read from the module so that it survives model.to() re-creating the engine.
@@ -383,8 +386,10 @@ class FusionEngine:
             if pr is not None:
                 d, dr = pr
         if dr is None:
+            # (prec: the planner takes the bf16x3 split-K kernel for it only where the output is large -- hidden >= 256: 29.9 ->
+            #  ~15 us at cfg4's per-GPU shape; the headline shape's RGB product rides in the pair launch above)
             dr = ops.gemm(GEMM_NT, x_rgb, a.p("input_embed.weight"), w.rgb, bias=a.p("input_embed.bias"), act=1,
-                          ws=self.ws_side if seam else self.ws, defer_reduce=seam)
+                          ws=self.ws_side if seam else self.ws, defer_reduce=seam, prec=self.depth_prec)
         slabs_r = self.ws_side.buf if (seam and dr.splitk > 1) else None
         if d is not None:
             pass
