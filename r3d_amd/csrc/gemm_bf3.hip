@@ -15,6 +15,10 @@
 namespace r3d {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// register stages of global loads are NATIVE vectors: with HIP's float4 struct the members become separate scalars, and where the
+// register allocator fails to coalesce them with a load's 128-bit tuple it copies the just-loaded registers at the loop's back
+// edge -- s_waitcnt vmcnt(0) on the newest loads every iteration (found in gemm_bf3_nt_kernel's ISA, round 3)
+typedef float f32x4n __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // Two consecutive-k values -> the three bf16 terms of each, already packed (element k in the low half of the dword:
@@ -188,18 +192,18 @@ __global__ __launch_bounds__(512, 1) void wgrad_panel_bf3_kernel(const r3d_gemm_
         // ================================= producers =================================
         const int pt = tid - 256;                                  // 0..255
         const int kq = pt >> 4, c4 = pt & 15;                      // two blocks per thread: k0 = 4 kq and 4 kq + 64; n = 4 c4 ..
-        float4 st0[8], st1[8], st2[8];
-        auto load_panel = [&](float4* breg, int turn) {
+        f32x4n st0[8], st1[8], st2[8];
+        auto load_panel = [&](f32x4n* breg, int turn) {
             const int n0 = pid(turn) * kP3N;
             const int nc = n0 + 4 * c4 < N ? n0 + 4 * c4 : 0;   // N % 4 == 0 (validated): a float4 is all-in or all-out
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
                 const int k = 4 * kq + (t & 3) + 64 * (t >> 2);
                 const int kc = k < K ? k : K - 1;
-                breg[t] = *reinterpret_cast<const float4*>(d.B + (size_t)kc * d.ldb + nc);
+                breg[t] = *reinterpret_cast<const f32x4n*>(d.B + (size_t)kc * d.ldb + nc);
             }
         };
-        auto store_panel = [&](unsigned short* img, const float4* breg, int turn) {
+        auto store_panel = [&](unsigned short* img, const f32x4n* breg, int turn) {
             const bool n_ok = pid(turn) * kP3N + 4 * c4 < N;
 #pragma unroll
             for (int hb = 0; hb < 2; ++hb) {
@@ -208,8 +212,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_panel_bf3_kernel(const r3d_gemm_
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const bool ok = n_ok && (k0 + t < K);
-                    const float4 b = breg[4 * hb + t];
-                    v[0][t] = ok ? b.x : 0.f; v[1][t] = ok ? b.y : 0.f; v[2][t] = ok ? b.z : 0.f; v[3][t] = ok ? b.w : 0.f;
+                    const f32x4n b = breg[4 * hb + t];
+                    v[0][t] = ok ? b[0] : 0.f; v[1][t] = ok ? b[1] : 0.f; v[2][t] = ok ? b[2] : 0.f; v[3][t] = ok ? b[3] : 0.f;
                 }
                 const int chunk = (k0 >> 2) ^ ((c4 >> 2) << 1);     // 8-byte chunk index, swizzled by (n >> 4) & 3
 #pragma unroll
@@ -244,7 +248,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_panel_bf3_kernel(const r3d_gemm_
         };
         // turn p: the C tile of panel p - 1 leaves, panel p + 1 (a register stage) goes to the other image, the stage
         // panel p came from is refilled with panel p + 3.  Stage of panel q = q % 3; 6 = lcm(2 images, 3 stages).
-        auto turn = [&](int p, unsigned short* oth, float4* nxt, float4* mine) {
+        auto turn = [&](int p, unsigned short* oth, f32x4n* nxt, f32x4n* mine) {
             if (p > 0) drain_c(p - 1);
             if (p + 1 < nturn) store_panel(oth, nxt, p + 1);
             load_panel(mine, min(p + 3, lastt));
@@ -448,29 +452,86 @@ __global__ __launch_bounds__(512, 1) void gemm_bf3_nt_kernel(const r3d_gemm_desc
             rowp[t] = (isa ? pA : pB) + off + 8 * (e % OPR);
         }
         const int Kt = pK;
-        float4 s0[2 * NOCT], s1[2 * NOCT];
-        auto load_stage = [&](float4* reg, int kt) {
-            const int k0 = k_begin + kt * BK;
-#pragma unroll
-            for (int t = 0; t < NOCT; ++t) {
-                const int o8 = 8 * ((pt + 256 * t) % OPR);
-                const int k = k0 + o8;
-                const int kc = k + 8 <= Kt ? k : Kt - 8;            // K % 8 == 0 (validated): an octet is all-in or all-out
-                const float* src = rowp[t] + (kc - o8);
-                reg[2 * t] = *reinterpret_cast<const float4*>(src);
-                reg[2 * t + 1] = *reinterpret_cast<const float4*>(src + 4);
-            }
-        };
-        // CHECK = false: every row of the tile and every k of the slice exist (the headline shape): no zero-fill selects
-        auto store_stage = [&](unsigned short* img, const float4* reg, int kt, auto check) {
+        // (native 4-vectors: with HIP's float4 STRUCT the members become separate scalars and the register allocator, failing to
+        //  coalesce one octet's members with the load's 128-bit tuple, copied the JUST-LOADED registers at the loop's back edge --
+        //  s_waitcnt vmcnt(0) on the newest loads every iteration, the whole prefetch distance lost: seen in the ISA, round 3)
+        f32x4n s0[2 * NOCT], s1[2 * NOCT];
+        // CHECK = false (whole tile, whole slice): the k offset of a step is UNIFORM -- no per-lane clamp, so it stays a scalar and
+        // the per-thread row pointers are the only vector address registers that live across the loop
+        auto load_stage = [&](f32x4n* reg, int kt, auto check) {
             constexpr bool CHECK = decltype(check)::value;
             const int k0 = k_begin + kt * BK;
 #pragma unroll
             for (int t = 0; t < NOCT; ++t) {
+                const float* src;
+                if (CHECK) {
+                    const int o8 = 8 * ((pt + 256 * t) % OPR);
+                    const int k = k0 + o8;
+                    const int kc = k + 8 <= Kt ? k : Kt - 8;        // K % 8 == 0 (validated): an octet is all-in or all-out
+                    src = rowp[t] + (kc - o8);
+                } else {
+                    src = rowp[t] + k0;
+                }
+                reg[2 * t] = *reinterpret_cast<const f32x4n*>(src);
+                reg[2 * t + 1] = *reinterpret_cast<const f32x4n*>(src + 4);
+            }
+        };
+        // CHECK = false: every row of the tile and every k of the slice exist (the headline shape): no zero-fill selects
+        auto store_stage = [&](unsigned short* img, const f32x4n* reg, int kt, auto check) {
+            constexpr bool CHECK = decltype(check)::value;
+            const int k0 = k_begin + kt * BK;
+#ifdef R3D_SPLIT_WIDE
+            if (!CHECK) {
+                // all NOCT octets level by level, a scheduling barrier between the levels: every instruction of a level is
+                // independent of the others (ILP = 8 NOCT instead of the two dependent chains per pair hipcc emits by itself)
+                constexpr int NE = 8 * NOCT;
+                float x[NE], r[NE], q[NE];
+                unsigned u[NE], w[NE], hp[NE / 2], mp[NE / 2], lp[NE / 2];
+#pragma unroll
+                for (int t = 0; t < NOCT; ++t) {
+                    const f32x4n a4 = reg[2 * t], b4 = reg[2 * t + 1];
+                    x[8 * t + 0] = a4[0]; x[8 * t + 1] = a4[1]; x[8 * t + 2] = a4[2]; x[8 * t + 3] = a4[3];
+                    x[8 * t + 4] = b4[0]; x[8 * t + 5] = b4[1]; x[8 * t + 6] = b4[2]; x[8 * t + 7] = b4[3];
+                }
+#pragma unroll
+                for (int i = 0; i < NE; ++i) u[i] = __builtin_bit_cast(unsigned, x[i]) & 0xffff0000u;
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < NE; ++i) r[i] = x[i] - __builtin_bit_cast(float, u[i]);
+#pragma unroll
+                for (int i = 0; i < NE / 2; ++i) hp[i] = __builtin_amdgcn_perm(u[2 * i + 1], u[2 * i], 0x07060302u);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < NE; ++i) w[i] = __builtin_bit_cast(unsigned, r[i]) & 0xffff0000u;
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < NE; ++i) q[i] = r[i] - __builtin_bit_cast(float, w[i]);
+#pragma unroll
+                for (int i = 0; i < NE / 2; ++i) mp[i] = __builtin_amdgcn_perm(w[2 * i + 1], w[2 * i], 0x07060302u);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < NE / 2; ++i)
+                    lp[i] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, q[2 * i + 1]), __builtin_bit_cast(unsigned, q[2 * i]), 0x07060302u);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < NOCT; ++t) {
+                    const int e = pt + 256 * t, row = e / OPR, o = e % OPR;
+                    const bool isa = row < BM;
+                    unsigned short* dst = img + (isa ? (size_t)row * S : (size_t)3 * PLANE_A + (size_t)(row - BM) * S) + 8 * o;
+                    const int plane = isa ? PLANE_A : PLANE_B;
+                    *reinterpret_cast<uint4*>(dst) = make_uint4(hp[4 * t], hp[4 * t + 1], hp[4 * t + 2], hp[4 * t + 3]);
+                    *reinterpret_cast<uint4*>(dst + plane) = make_uint4(mp[4 * t], mp[4 * t + 1], mp[4 * t + 2], mp[4 * t + 3]);
+                    *reinterpret_cast<uint4*>(dst + 2 * plane) = make_uint4(lp[4 * t], lp[4 * t + 1], lp[4 * t + 2], lp[4 * t + 3]);
+                }
+                return;
+            }
+#endif
+#pragma unroll
+            for (int t = 0; t < NOCT; ++t) {
                 const int e = pt + 256 * t, row = e / OPR, o = e % OPR;
                 const bool isa = row < BM;
-                const float4 x = reg[2 * t], y = reg[2 * t + 1];
-                float v[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
+                const f32x4n x = reg[2 * t], y = reg[2 * t + 1];
+                float v[8] = {x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
                 if (CHECK) {
                     const bool ok = rok[t] && (k0 + 8 * o < k_end);
                     if (!ok) {
@@ -501,10 +562,10 @@ __global__ __launch_bounds__(512, 1) void gemm_bf3_nt_kernel(const r3d_gemm_desc
         const int last = nk - 1;
         auto run = [&](auto check) {
             R3D_NT_MARK(0);
-            load_stage(s0, 0);
-            load_stage(s1, min(1, last));
+            load_stage(s0, 0, check);
+            load_stage(s1, min(1, last), check);
             store_stage(lds16, s0, 0, check);
-            load_stage(s0, min(2, last));
+            load_stage(s0, min(2, last), check);
             R3D_NT_MARK(1);
             __syncthreads();                                        // stage 0 written
             // step kt: tile kt + 1 (register stage) -> the other image; refill that register stage with tile kt + 3
@@ -523,13 +584,13 @@ __global__ __launch_bounds__(512, 1) void gemm_bf3_nt_kernel(const r3d_gemm_desc
                 __builtin_amdgcn_sched_barrier(0);
                 R3D_NT_MARK(33 + 2 * kt);
 #endif
-                load_stage(s1, min(kt + 3, last));
+                load_stage(s1, min(kt + 3, last), check);
                 __builtin_amdgcn_sched_barrier(0);                  // (keeps the other stage's split below these loads)
                 R3D_NT_MARK(3 + 2 * kt);
                 __syncthreads();
                 R3D_NT_MARK(4 + 2 * kt);
                 store_stage(lds16, s0, min(kt + 2, last), check);
-                load_stage(s0, min(kt + 4, last));
+                load_stage(s0, min(kt + 4, last), check);
                 __builtin_amdgcn_sched_barrier(0);
                 R3D_NT_MARK(5 + 2 * kt);
                 __syncthreads();
@@ -584,8 +645,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf3_nt_u_kernel(const r3d_gemm_de
         dsto[t] = (isa ? row * S : 3 * PLANE + (row - BM) * S) + 8 * o;
     }
     const int Kt = d.K;
-    float4 s0[4], s1[4];
-    auto load_stage = [&](float4* reg, int kt) {
+    f32x4n s0[4], s1[4];
+    auto load_stage = [&](f32x4n* reg, int kt) {
         const int k0 = k_begin + kt * BK;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -593,17 +654,17 @@ __global__ __launch_bounds__(512, 1) void gemm_bf3_nt_u_kernel(const r3d_gemm_de
             const int k = k0 + o8;
             const int kc = k + 8 <= Kt ? k : Kt - 8;            // K % 8 == 0 (validated)
             const float* src = rowp[t] + (kc - o8);
-            reg[2 * t] = *reinterpret_cast<const float4*>(src);
-            reg[2 * t + 1] = *reinterpret_cast<const float4*>(src + 4);
+            reg[2 * t] = *reinterpret_cast<const f32x4n*>(src);
+            reg[2 * t + 1] = *reinterpret_cast<const f32x4n*>(src + 4);
         }
     };
-    auto store_stage = [&](unsigned short* img, const float4* reg, int kt, auto check) {
+    auto store_stage = [&](unsigned short* img, const f32x4n* reg, int kt, auto check) {
         constexpr bool CHECK = decltype(check)::value;
         const int k0 = k_begin + kt * BK;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const float4 x = reg[2 * t], y = reg[2 * t + 1];
-            float v[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
+            const f32x4n x = reg[2 * t], y = reg[2 * t + 1];
+            float v[8] = {x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
             if (CHECK) {
                 const bool ok = rok[t] && (k0 + 8 * ((tid + 512 * t) % OPR) < k_end);
                 if (!ok) {
@@ -863,24 +924,24 @@ __global__ __launch_bounds__(512, 1) void gemm_bf3_tn_kernel(const r3d_gemm_desc
         const size_t ld = (size_t)(isa ? d.lda : d.ldb);
         unsigned short* imgrow = lds16 + (isa ? 0 : 3 * PLANE) + (size_t)(4 * x4) * S;
         const int sw = (x4 >> 2) & 3;                              // (row >> 4) & 3 for rows 4 x4 .. 4 x4 + 3
-        float4 s0[8], s1[8];
+        f32x4n s0[8], s1[8];
         // (unconditional loads from clamped rows: see gemm_bf3_nt_kernel)
-        auto load_stage = [&](float4* reg, int kt) {
+        auto load_stage = [&](f32x4n* reg, int kt) {
             const int kb = kt * BK + 8 * ko;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int k = kb + j < K ? kb + j : K - 1;
-                reg[j] = *reinterpret_cast<const float4*>(colp + (size_t)k * ld);
+                reg[j] = *reinterpret_cast<const f32x4n*>(colp + (size_t)k * ld);
             }
         };
-        auto store_stage = [&](unsigned short* img, const float4* reg, int kt) {
+        auto store_stage = [&](unsigned short* img, const f32x4n* reg, int kt) {
             const int kb = kt * BK + 8 * ko;
             float v[4][8];                                          // [column][k]
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const bool ok = x_ok && (kb + j < K);
-                v[0][j] = ok ? reg[j].x : 0.f; v[1][j] = ok ? reg[j].y : 0.f;
-                v[2][j] = ok ? reg[j].z : 0.f; v[3][j] = ok ? reg[j].w : 0.f;
+                v[0][j] = ok ? reg[j][0] : 0.f; v[1][j] = ok ? reg[j][1] : 0.f;
+                v[2][j] = ok ? reg[j][2] : 0.f; v[3][j] = ok ? reg[j][3] : 0.f;
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
