@@ -361,47 +361,62 @@ __global__ __launch_bounds__(512, 1) void gemm_bf3_nt_kernel(const r3d_gemm_desc
                 for (int c = 0; c < (TWO ? 2 : 1); ++c)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[i][j][c][r] = 0.f;
+        // Operands in two register sets, one k16 ahead: the reads of k16 g + 1 are issued BEFORE the MFMAs of k16 g -- also across
+        // the stage boundary, where the barrier comes first and the next stage's first operands are then read under the current
+        // stage's last MFMAs (the matrix pipe no longer drains at every barrier while the first ds_read of a stage is in flight).
+        // The read at the very end fetches a stale stage and is dropped.
+        const int oa = (wm * (BM / 2) + l31) * S + 8 * lhi, ob = 3 * PLANE_A + (wn * (BN / 2) + l31) * S + 8 * lhi;
+        uint4 oah[2][TM], oam[2][TM], oal[2][TM], obh[2][TN], obm[2][TN], obl[2][TN];
+        auto rd = [&](int set, const unsigned short* img, int ks) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const unsigned short* q = img + oa + (size_t)i * 32 * S + 16 * ks;
+                oah[set][i] = *reinterpret_cast<const uint4*>(q);
+                oam[set][i] = *reinterpret_cast<const uint4*>(q + PLANE_A);
+                oal[set][i] = *reinterpret_cast<const uint4*>(q + 2 * PLANE_A);
+            }
+#pragma unroll
+            for (int jj = 0; jj < TN; ++jj) {
+                const unsigned short* q = img + ob + (size_t)jj * 32 * S + 16 * ks;
+                obh[set][jj] = *reinterpret_cast<const uint4*>(q);
+                obm[set][jj] = *reinterpret_cast<const uint4*>(q + PLANE_B);
+                obl[set][jj] = *reinterpret_cast<const uint4*>(q + 2 * PLANE_B);
+            }
+        };
         R3D_NT_MARK(0);
         __syncthreads();                                            // stage 0 written
+        rd(0, lds16, 0);
         for (int kt = 0; kt < nk; ++kt) {
             R3D_NT_MARK(1 + 2 * kt);
             const unsigned short* img = lds16 + (kt & 1) * STAGE;
-            const unsigned short* ia = img + (size_t)(wm * (BM / 2) + l31) * S + 8 * lhi;
-            const unsigned short* ib = img + 3 * PLANE_A + (size_t)(wn * (BN / 2) + l31) * S + 8 * lhi;
+            const unsigned short* nimg = lds16 + ((kt + 1) & 1) * STAGE;
 #pragma unroll
             for (int ks = 0; ks < ((R3D_NT_PROBE & 1) ? 0 : NKS); ++ks) {
-                uint4 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const unsigned short* q = ia + (size_t)i * 32 * S + 16 * ks;
-                    ah[i] = *reinterpret_cast<const uint4*>(q);
-                    am[i] = *reinterpret_cast<const uint4*>(q + PLANE_A);
-                    al[i] = *reinterpret_cast<const uint4*>(q + 2 * PLANE_A);
-                }
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const unsigned short* q = ib + (size_t)j * 32 * S + 16 * ks;
-                    bh[j] = *reinterpret_cast<const uint4*>(q);
-                    bm[j] = *reinterpret_cast<const uint4*>(q + PLANE_B);
-                    bl[j] = *reinterpret_cast<const uint4*>(q + 2 * PLANE_B);
+                constexpr int kDummy = 0; (void)kDummy;
+                const int cur = ks & 1, nxt = cur ^ 1;              // (NKS is even: the parity carries over the stage boundary)
+                if (ks + 1 < NKS) {
+                    rd(nxt, img, ks + 1);
+                } else {
+                    R3D_NT_MARK(2 + 2 * kt);
+                    __syncthreads();                                // every wave has read stage kt; stage kt + 1 is written
+                    rd(nxt, nimg, 0);
                 }
                 const int c = TWO ? (ks & 1) : 0;
 #define R3D_BF(x) __builtin_bit_cast(bf16x8, x)
 #define R3D_TERM(A_, B_)                                                                                                   \
-                _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)               \
-                    if (R3D_NT_PROBE & 8) { acc[i][j][c][0] += __builtin_bit_cast(float, A_[i].x ^ B_[j].x); } else          \
-                    acc[i][j][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(R3D_BF(A_[i]), R3D_BF(B_[j]), acc[i][j][c], 0, 0, 0);
-                R3D_TERM(ah, bl)                                    // small terms first; tiles alternate inside a term
-                R3D_TERM(al, bh)
-                R3D_TERM(am, bm)
-                R3D_TERM(ah, bm)
-                R3D_TERM(am, bh)
-                R3D_TERM(ah, bh)
+                _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int jj = 0; jj < TN; ++jj)             \
+                    if (R3D_NT_PROBE & 8) { acc[i][jj][c][0] += __builtin_bit_cast(float, A_[cur][i].x ^ B_[cur][jj].x); } else \
+                    acc[i][jj][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(R3D_BF(A_[cur][i]), R3D_BF(B_[cur][jj]), acc[i][jj][c], 0, 0, 0);
+                R3D_TERM(oah, obl)                                  // small terms first; tiles alternate inside a term
+                R3D_TERM(oal, obh)
+                R3D_TERM(oam, obm)
+                R3D_TERM(oah, obm)
+                R3D_TERM(oam, obh)
+                R3D_TERM(oah, obh)
 #undef R3D_TERM
 #undef R3D_BF
             }
-            R3D_NT_MARK(2 + 2 * kt);
-            __syncthreads();
+            if (R3D_NT_PROBE & 1) __syncthreads();
         }
         R3D_NT_MARK(1 + 2 * nk);
         if (nk & 1) __syncthreads();                                // (the producers' loop runs whole pairs of k-steps)
