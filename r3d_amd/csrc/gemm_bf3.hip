@@ -940,21 +940,24 @@ __global__ __launch_bounds__(512, 1) void gemm_bf3_tn_kernel(const r3d_gemm_desc
         unsigned short* imgrow = lds16 + (isa ? 0 : 3 * PLANE) + (size_t)(4 * x4) * S;
         const int sw = (x4 >> 2) & 3;                              // (row >> 4) & 3 for rows 4 x4 .. 4 x4 + 3
         f32x4n s0[8], s1[8];
-        // (unconditional loads from clamped rows: see gemm_bf3_nt_kernel)
-        auto load_stage = [&](f32x4n* reg, int kt) {
+        // (unconditional loads from clamped rows: see gemm_bf3_nt_kernel.  CHECK = false -- a whole tile and K a multiple of 32, the
+        //  training shapes: no row clamps, no zero-fill selects, the row offsets of a step are scalars)
+        auto load_stage = [&](f32x4n* reg, int kt, auto check) {
+            constexpr bool CHECK = decltype(check)::value;
             const int kb = kt * BK + 8 * ko;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int k = kb + j < K ? kb + j : K - 1;
+                const int k = CHECK ? (kb + j < K ? kb + j : K - 1) : kb + j;
                 reg[j] = *reinterpret_cast<const f32x4n*>(colp + (size_t)k * ld);
             }
         };
-        auto store_stage = [&](unsigned short* img, const f32x4n* reg, int kt) {
+        auto store_stage = [&](unsigned short* img, const f32x4n* reg, int kt, auto check) {
+            constexpr bool CHECK = decltype(check)::value;
             const int kb = kt * BK + 8 * ko;
             float v[4][8];                                          // [column][k]
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const bool ok = x_ok && (kb + j < K);
+                const bool ok = !CHECK || (x_ok && (kb + j < K));
                 v[0][j] = ok ? reg[j][0] : 0.f; v[1][j] = ok ? reg[j][1] : 0.f;
                 v[2][j] = ok ? reg[j][2] : 0.f; v[3][j] = ok ? reg[j][3] : 0.f;
             }
@@ -969,23 +972,27 @@ __global__ __launch_bounds__(512, 1) void gemm_bf3_tn_kernel(const r3d_gemm_desc
             }
         };
         const int last = nk - 1;
-        R3D_NT_MARK(0);
-        load_stage(s0, 0);
-        load_stage(s1, min(1, last));
-        store_stage(lds16, s0, 0);
-        load_stage(s0, min(2, last));
-        R3D_NT_MARK(1);
-        __syncthreads();                                            // stage 0 written
-        for (int kt = 0; kt < nk; kt += 2) {                        // (straight-line pairs: see gemm_bf3_nt_kernel)
-            store_stage(lds16 + STAGE, s1, min(kt + 1, last));
-            load_stage(s1, min(kt + 3, last));
-            __builtin_amdgcn_sched_barrier(0);                      // (keeps the other stage's split below these loads)
-            __syncthreads();
-            store_stage(lds16, s0, min(kt + 2, last));
-            load_stage(s0, min(kt + 4, last));
-            __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();
-        }
+        auto run = [&](auto check) {
+            R3D_NT_MARK(0);
+            load_stage(s0, 0, check);
+            load_stage(s1, min(1, last), check);
+            store_stage(lds16, s0, 0, check);
+            load_stage(s0, min(2, last), check);
+            R3D_NT_MARK(1);
+            __syncthreads();                                        // stage 0 written
+            for (int kt = 0; kt < nk; kt += 2) {                    // (straight-line pairs: see gemm_bf3_nt_kernel)
+                store_stage(lds16 + STAGE, s1, min(kt + 1, last), check);
+                load_stage(s1, min(kt + 3, last), check);
+                __builtin_amdgcn_sched_barrier(0);                  // (keeps the other stage's split below these loads)
+                __syncthreads();
+                store_stage(lds16, s0, min(kt + 2, last), check);
+                load_stage(s0, min(kt + 4, last), check);
+                __builtin_amdgcn_sched_barrier(0);
+                __syncthreads();
+            }
+        };
+        const bool full = m0 + BM <= M && n0 + BN <= N && (K % BK) == 0;
+        if (full) run(std::false_type{}); else run(std::true_type{});
     }
 }
 
