@@ -292,9 +292,13 @@ __global__ __launch_bounds__(512, 1) void wgrad_panel_bf3_kernel(const r3d_gemm_
         reinterpret_cast<unsigned long long*>(d.partial + (size_t)NG * d.M * d.N)[(threadIdx.x >> 8) * 64 + (K)] = wall_clock64(); } while (0)
 #define R3D_NT_CYC(K) do { if (blockIdx.x == 16 && (threadIdx.x & 255) == 0)                                                        \
         reinterpret_cast<unsigned long long*>(d.partial + (size_t)NG * d.M * d.N)[(threadIdx.x >> 8) * 64 + (K)] = __builtin_readcyclecounter(); } while (0)
+// (the weight-gradient kernel has no workspace: its marks go behind the C matrix, whose allocation the probe tool oversizes)
+#define R3D_TN_MARK(K) do { if (blockIdx.x == 16 && (threadIdx.x & 255) == 0)                                                       \
+        reinterpret_cast<unsigned long long*>(d.C + (size_t)d.M * d.ldc)[(threadIdx.x >> 8) * 64 + (K)] = wall_clock64(); } while (0)
 #else
 #define R3D_NT_MARK(K) do { } while (0)
 #define R3D_NT_CYC(K) do { } while (0)
+#define R3D_TN_MARK(K) do { } while (0)
 #endif
 // One MFMA, then three VALU instructions, 24 times; the six LDS stores and four loads of the step spread between
 // (sched_group_barrier masks: 0x008 MFMA, 0x002 VALU, 0x200 DS write, 0x020 VMEM read).  R3D_NTU_NOSCHED: leave it to hipcc.
@@ -314,8 +318,13 @@ __global__ __launch_bounds__(512, 1) void wgrad_panel_bf3_kernel(const r3d_gemm_
 // K-splits take the workgroups after the first product's -- at the headline shape exactly the 12 of the 256 placed workgroups
 // that the first product's 61 splits x 4 tiles leave without work.
 struct NtSecond { const float* A; const float* B; float* partial; int lda, ldb, K, k_per_split, NG2; };
+// R3D_NT_PROD producer threads (256: four producer waves, one per SIMD beside a consumer wave; 512: eight, two per SIMD, each with
+// half the octets of a stage -- more independent split chains for the SIMD's issue port to pick from)
+#ifndef R3D_NT_PROD
+#define R3D_NT_PROD 512
+#endif
 template <int BM, int BN, int BK>
-__global__ __launch_bounds__(512, 1) void gemm_bf3_nt_kernel(const r3d_gemm_desc d, const int G, const int NG, const NtSecond s2) {
+__global__ __launch_bounds__(256 + R3D_NT_PROD, 1) void gemm_bf3_nt_kernel(const r3d_gemm_desc d, const int G, const int NG, const NtSecond s2) {
     constexpr int S = BK + 8;                                  // bf16 per image row
     constexpr int OPR = BK / 8;                                // octets per row
     constexpr int PLANE_A = BM * S, PLANE_B = BN * S;
@@ -323,8 +332,9 @@ __global__ __launch_bounds__(512, 1) void gemm_bf3_nt_kernel(const r3d_gemm_desc
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int NKS = BK / 16;
     constexpr bool TWO = (TM * TN == 1);                       // one tile per wave: split the k-steps over two chains
-    constexpr int NOCT = (BM + BN) * OPR / 256;                // octets per producer thread and stage
-    static_assert((BM + BN) * OPR % 256 == 0, "producer mapping");
+    constexpr int NPROD = R3D_NT_PROD;
+    constexpr int NOCT = (BM + BN) * OPR / NPROD;              // octets per producer thread and stage
+    static_assert((BM + BN) * OPR % NPROD == 0, "producer mapping");
     extern __shared__ __attribute__((aligned(16))) unsigned short lds16[];     // [2 stages][A planes | B planes]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lhi = lane >> 5;
@@ -458,7 +468,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf3_nt_kernel(const r3d_gemm_desc
         bool rok[NOCT];
 #pragma unroll
         for (int t = 0; t < NOCT; ++t) {
-            const int e = pt + 256 * t, row = e / OPR;
+            const int e = pt + NPROD * t, row = e / OPR;
             const bool isa = row < BM;                               // (compile-time per t when 256 * t is a multiple of BM * OPR)
             const int gr = isa ? m0 + row : n0 + (row - BM);
             const int lim = isa ? d.M : d.N;
@@ -480,7 +490,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf3_nt_kernel(const r3d_gemm_desc
             for (int t = 0; t < NOCT; ++t) {
                 const float* src;
                 if (CHECK) {
-                    const int o8 = 8 * ((pt + 256 * t) % OPR);
+                    const int o8 = 8 * ((pt + NPROD * t) % OPR);
                     const int k = k0 + o8;
                     const int kc = k + 8 <= Kt ? k : Kt - 8;        // K % 8 == 0 (validated): an octet is all-in or all-out
                     src = rowp[t] + (kc - o8);
@@ -530,7 +540,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf3_nt_kernel(const r3d_gemm_desc
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int t = 0; t < NOCT; ++t) {
-                    const int e = pt + 256 * t, row = e / OPR, o = e % OPR;
+                    const int e = pt + NPROD * t, row = e / OPR, o = e % OPR;
                     const bool isa = row < BM;
                     unsigned short* dst = img + (isa ? (size_t)row * S : (size_t)3 * PLANE_A + (size_t)(row - BM) * S) + 8 * o;
                     const int plane = isa ? PLANE_A : PLANE_B;
@@ -543,7 +553,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf3_nt_kernel(const r3d_gemm_desc
 #endif
 #pragma unroll
             for (int t = 0; t < NOCT; ++t) {
-                const int e = pt + 256 * t, row = e / OPR, o = e % OPR;
+                const int e = pt + NPROD * t, row = e / OPR, o = e % OPR;
                 const bool isa = row < BM;
                 const f32x4n x = reg[2 * t], y = reg[2 * t + 1];
                 float v[8] = {x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
@@ -801,7 +811,7 @@ static int launch_bf3_nt_cfg(const r3d_gemm_desc& d, hipStream_t s, const NtSeco
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_bf3_nt_kernel<BM, BN, BK>), dim3(8 * tiles * r3d_cdiv(ns + s2.NG2, 8)), dim3(512), lds, s, d, tiles, ns, s2);
+    hipLaunchKernelGGL((gemm_bf3_nt_kernel<BM, BN, BK>), dim3(8 * tiles * r3d_cdiv(ns + s2.NG2, 8)), dim3(256 + R3D_NT_PROD), lds, s, d, tiles, ns, s2);
     R3D_LAUNCH_CHECK();
     return R3D_OK;
 }
@@ -871,6 +881,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf3_tn_kernel(const r3d_gemm_desc
         const int xa0 = (ra >> 4) & 3, xa1 = ((ra + 32) >> 4) & 3, xb0 = (rb >> 4) & 3, xb1 = ((rb + 32) >> 4) & 3;
         __syncthreads();                                            // stage 0 written
         for (int kt = 0; kt < nk; ++kt) {
+            R3D_TN_MARK(1 + 2 * kt);
             const unsigned short* ia = lds16 + (kt & 1) * STAGE;
             const unsigned short* ib = ia + 3 * PLANE;
 #pragma unroll
@@ -902,10 +913,10 @@ __global__ __launch_bounds__(512, 1) void gemm_bf3_tn_kernel(const r3d_gemm_desc
 #undef R3D_TERM
 #undef R3D_BF
             }
-            R3D_NT_MARK(2 + 2 * kt);
+            R3D_TN_MARK(2 + 2 * kt);
             __syncthreads();
         }
-        R3D_NT_MARK(1 + 2 * nk);
+        R3D_TN_MARK(1 + 2 * nk);
         if (nk & 1) __syncthreads();                                // (the producers' loop runs whole pairs of k-steps)
         // C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
         const float alpha = d.alpha;
@@ -964,7 +975,14 @@ __global__ __launch_bounds__(512, 1) void gemm_bf3_tn_kernel(const r3d_gemm_desc
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 uint4 h, m, l;
+#ifdef R3D_TN_STUB            /* profiling builds: 1 = producers store the raw bits (no split), 2 = producers store nothing */
+                h = make_uint4(__builtin_bit_cast(unsigned, v[c][0]), __builtin_bit_cast(unsigned, v[c][1]),
+                               __builtin_bit_cast(unsigned, v[c][2]), __builtin_bit_cast(unsigned, v[c][3]));
+                m = h; l = h;
+                if (R3D_TN_STUB == 2) { if (h.x == 0x12345678u) *reinterpret_cast<uint4*>(img) = h; continue; }
+#else
                 split3_oct(v[c], h, m, l);
+#endif
                 unsigned short* dst = img + (imgrow - lds16) + (size_t)c * S + 8 * (ko ^ sw);
                 *reinterpret_cast<uint4*>(dst) = h;
                 *reinterpret_cast<uint4*>(dst + PLANE) = m;
@@ -973,21 +991,25 @@ __global__ __launch_bounds__(512, 1) void gemm_bf3_tn_kernel(const r3d_gemm_desc
         };
         const int last = nk - 1;
         auto run = [&](auto check) {
-            R3D_NT_MARK(0);
+            R3D_TN_MARK(0);
             load_stage(s0, 0, check);
             load_stage(s1, min(1, last), check);
             store_stage(lds16, s0, 0, check);
             load_stage(s0, min(2, last), check);
-            R3D_NT_MARK(1);
+            R3D_TN_MARK(1);
             __syncthreads();                                        // stage 0 written
             for (int kt = 0; kt < nk; kt += 2) {                    // (straight-line pairs: see gemm_bf3_nt_kernel)
+                R3D_TN_MARK(2 + 2 * kt);
                 store_stage(lds16 + STAGE, s1, min(kt + 1, last), check);
                 load_stage(s1, min(kt + 3, last), check);
                 __builtin_amdgcn_sched_barrier(0);                  // (keeps the other stage's split below these loads)
+                R3D_TN_MARK(3 + 2 * kt);
                 __syncthreads();
+                R3D_TN_MARK(4 + 2 * kt);
                 store_stage(lds16, s0, min(kt + 2, last), check);
                 load_stage(s0, min(kt + 4, last), check);
                 __builtin_amdgcn_sched_barrier(0);
+                R3D_TN_MARK(5 + 2 * kt);
                 __syncthreads();
             }
         };
