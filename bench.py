@@ -320,6 +320,9 @@ def main():
     ap.add_argument("--no-decoder-chain", action="store_true",
                     help="the decoder layer's query side as separate attention / GEMM / LayerNorm / loss launches instead of "
                          "the one-launch decoder chain kernel (A/B)")
+    ap.add_argument("--no-fused-adamw", action="store_true",
+                    help="never update depth_projection.weight inside its weight-gradient kernel (by default it is, where the "
+                         "product runs on the tiled bf16x3 kernel: the wide / long per-GPU shapes, not the headline one; A/B)")
     ap.add_argument("--no-ride-planes", action="store_true",
                     help="re-split the chain weights in a launch of its own instead of as rider workgroups of the embedding seam (A/B)")
     ap.add_argument("--no-pair-embeddings", action="store_true",
@@ -437,7 +440,8 @@ def main():
             tp.exchange_forward(eng._fw["w"])
         eng.forward_finish()
         eng.losses(lab, tgt, dur, tick=True)
-        fuse = fuse_adam and (dp is None or tp is not None)      # that gradient needs no exchange
+        fuse = (fuse_adam and (dp is None or tp is not None)) or (      # that gradient needs no exchange
+            dp is None and not a.no_fused_adamw and eng.depth_adamw_fusable())   # ... and the engine finds it pays (tile 10)
         eng.backward(fused_adamw=dict(lr=c["lr"], weight_decay=c["wd"], grad_scale=gscale) if fuse else None,
                      adamw_next=dp is None)
         if dp is not None:

@@ -856,6 +856,7 @@ int launch_gemm_bf3_nt(const r3d_gemm_desc& d, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512, 1) void gemm_bf3_tn_kernel(const r3d_gemm_desc d, const int G, const int NG) {
     constexpr int BM = 128, BN = 128, BK = 32, S = BK + 8;
+    constexpr int kTnCS = BN + 4;                               // floats per row of the AdamW epilogue's tile image
     constexpr int PLANE = BM * S;                               // BM == BN: same plane size for both operands
     constexpr int STAGE = 6 * PLANE;
     extern __shared__ __attribute__((aligned(16))) unsigned short lds16[];     // [2 stages][A planes | B planes]
@@ -921,6 +922,16 @@ __global__ __launch_bounds__(512, 1) void gemm_bf3_tn_kernel(const r3d_gemm_desc
         // C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
         const float alpha = d.alpha;
         const bool accum = d.accumulate != 0;
+        if (d.adam_m) {                                             // AdamW epilogue (below): the raw tile goes to LDS
+            float* ct = reinterpret_cast<float*>(lds16);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        ct[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * kTnCS + wn * 64 + j * 32 + l31] = acc[i][j][r];
+        } else
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1016,13 +1027,73 @@ __global__ __launch_bounds__(512, 1) void gemm_bf3_tn_kernel(const r3d_gemm_desc
         const bool full = m0 + BM <= M && n0 + BN <= N && (K % BK) == 0;
         if (full) run(std::false_type{}); else run(std::true_type{});
     }
+    if (!d.adam_m) return;
+    // ---- AdamW in the epilogue (r3d_gemm_desc::adam_*: C is the PARAMETER, the product its gradient, which is never stored).
+    // All 512 threads stream parameter and both moments row-contiguously with 16-byte accesses while the other workgroups of
+    // the chip multiply: at hidden >= 512 this kernel is bound by the matrix cores / the issue port and leaves HBM idle, and
+    // the flat AdamW launch no longer reads and re-writes 86 % of the model.  Same arithmetic and order as adamw_kernel
+    // (optim.hip) and as gemm_f32_kernel's epilogue.
+    __syncthreads();                                                // the tile is in LDS (every wave is past its last stage)
+    {
+        const float* ct = reinterpret_cast<const float*>(lds16);
+        const float lr = *d.adam_lr;
+        const double stepd = (double)*d.adam_step;
+        const float bc1 = (float)(1.0 - pow((double)d.adam_beta1, stepd));
+        const float bc2_sqrt = (float)sqrt(1.0 - pow((double)d.adam_beta2, stepd));
+        const float decay = 1.0f - lr * d.adam_wd;
+        const float step_size = lr / bc1;
+        const float b2 = d.adam_beta2, eps = d.adam_eps, gs = d.alpha * d.adam_gscale;
+        const float omb1 = 1.0f - d.adam_beta1, omb2 = 1.0f - b2;
+        // 8 float4 per thread and array, in two batches of four: all twelve loads of a batch are in flight before the first
+        // update (unconditional, from clamped addresses; the stores of out-of-range elements are skipped)
+#define R3D_ADAM_E(c)                                              \
+            {                                                      \
+                const float gr = gg.c * gs;                        \
+                pp[u].c *= decay;                                  \
+                mm[u].c = mm[u].c + (gr - mm[u].c) * omb1;         \
+                vv[u].c = vv[u].c * b2 + gr * gr * omb2;           \
+                const float den = sqrtf(vv[u].c) / bc2_sqrt + eps; \
+                pp[u].c -= step_size * (mm[u].c / den);            \
+            }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            float4 pp[4], mm[4], vv[4];
+            size_t off[4];
+            bool in[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int f = tid + 512 * (4 * half + u);
+                const int row = f / (BN / 4), c4 = f % (BN / 4);
+                const int gm = m0 + row, gn = n0 + 4 * c4;
+                in[u] = gm < M && gn < N;
+                off[u] = in[u] ? (size_t)gm * d.ldc + gn : 0;
+                pp[u] = *reinterpret_cast<const float4*>(d.C + off[u]);
+                mm[u] = *reinterpret_cast<const float4*>(d.adam_m + off[u]);
+                vv[u] = *reinterpret_cast<const float4*>(d.adam_v + off[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int f = tid + 512 * (4 * half + u);
+                const int row = f / (BN / 4), c4 = f % (BN / 4);
+                const float4 gg = *reinterpret_cast<const float4*>(ct + row * kTnCS + 4 * c4);
+                R3D_ADAM_E(x) R3D_ADAM_E(y) R3D_ADAM_E(z) R3D_ADAM_E(w)
+                if (in[u]) {
+                    *reinterpret_cast<float4*>(d.C + off[u]) = pp[u];
+                    *reinterpret_cast<float4*>(d.adam_m + off[u]) = mm[u];
+                    *reinterpret_cast<float4*>(d.adam_v + off[u]) = vv[u];
+                }
+            }
+        }
+#undef R3D_ADAM_E
+    }
 }
 
 bool gemm_bf3_tn_ok(const r3d_gemm_desc& d) {
     if (d.layout != R3D_GEMM_TN || d.splitk > 1 || d.K < 16) return false;
     if ((d.M & 3) || (d.N & 3) || (d.lda & 3) || (d.ldb & 3)) return false;
     if (d.b_add || d.bias || d.pre_out || d.act || d.drop_mask || d.mul || d.res1 || d.res2) return false;
-    if (d.bias_grad || d.c_row_xor || d.adam_m) return false;
+    if (d.bias_grad || d.c_row_xor) return false;
+    if (d.adam_m && (d.accumulate || (d.ldc & 3) || (d.N & 3) || !r3d_aligned16(d.C))) return false;
     return r3d_aligned16(d.A) && r3d_aligned16(d.B);
 }
 

@@ -833,7 +833,7 @@ static int gemm_validate(const r3d_gemm_desc* d) {
     if (d->bias_grad && (d->layout != R3D_GEMM_TN || d->splitk > 1)) return R3D_EINVAL;
     if (d->adam_m) {                     // AdamW epilogue: nothing else may want the product
         if (!d->adam_v || !d->adam_lr || !d->adam_step || d->splitk > 1) return R3D_EINVAL;
-        if (d->tile != 2 && d->tile != 3) return R3D_EINVAL;           // tiles without k-split waves
+        if (d->tile != 2 && d->tile != 3 && d->tile != 10) return R3D_EINVAL;   // tiles without k-split waves; the bf16x3 TN tile
         if ((d->N & 3) || (d->ldc & 3) || d->c_row_xor || d->alpha == 0.f) return R3D_EINVAL;
         if (!r3d_aligned16(d->C) || !r3d_aligned16(d->adam_m) || !r3d_aligned16(d->adam_v)) return R3D_EALIGN;
         if (d->bias || d->pre_out || d->act || d->drop_mask || d->mul || d->res1 || d->res2 || d->accumulate) return R3D_EINVAL;

@@ -238,6 +238,7 @@ class FusionEngine:
         # workgroups are latency-bound and leave half the chip idle) -- one launch and ~6 us less per step
         self.ride_planes = True
         self._planes_rode = False
+        self.fuse_depth_adamw = True             # see depth_adamw_fusable(); False: always the flat AdamW launch
         # the RGB embedding (input_embed, K = 2048) as a second product of the depth projection's launch: 61 K-splits x 4 tiles
         # occupy 244 of the 256 placed workgroups, the RGB product's 3 K-splits x 4 tiles take the other 12 -- one launch less,
         # no workgroup works longer than before; the RGB product then runs on the bf16 matrix cores too (same exact split)
@@ -1015,6 +1016,22 @@ class FusionEngine:
         if self.grad_hook is not None:
             self.grad_hook("big_ready")
 
+    def depth_adamw_fusable(self):
+        """True when depth_projection.weight can be updated inside its weight-gradient kernel at a gain: one rank (its gradient
+        needs no exchange) and the product runs on the tiled bf16x3 TN kernel (tile 10: more than 128 token rows or hidden units),
+        whose epilogue then streams parameter and moments while the rest of the chip multiplies -- the flat AdamW launch no
+        longer reads and re-writes 86 % of the model (cfg4's per-GPU shape 1.127 -> 1.082 ms, cfg5's 1.644 -> 1.553; at the
+        headline shape the product runs on the panel kernel, where fusing was measured neutral, so it stays off there)."""
+        st = self.last
+        if (not self.fuse_depth_adamw or st is None or self.tp is not None or st["tp"] is not None or
+                self.grad_hook is not None or self.depth_prec != 1):
+            return False
+        w = st["w"]
+        if not hasattr(w, "_depth_tile"):
+            w._depth_tile = ops.gemm_planned_tile(GEMM_TN, w.d_dep_pre, st["x_dep"], self.arena.p("depth_projection.weight"),
+                                                  prec=self.depth_prec)
+        return w._depth_tile == 10
+
     def prepare_fused_adamw(self, cfg):
         """cfg: None or dict(lr, weight_decay[, betas, eps, grad_scale]); consumed by backward_depth_wgrad()."""
         self._adam = None
@@ -1035,7 +1052,7 @@ class FusionEngine:
         if adam is not None:
             a = self.arena
             o, n, shp = a.offsets["depth_projection.weight"]
-            ops.gemm(GEMM_TN, st["w"].d_dep_pre, st["x_dep"], a.p("depth_projection.weight"), ws=self.ws,
+            ops.gemm(GEMM_TN, st["w"].d_dep_pre, st["x_dep"], a.p("depth_projection.weight"), ws=self.ws, prec=self.depth_prec,
                      adam=dict(adam, m=a.exp_avg[o:o + n].view(shp), v=a.exp_avg_sq[o:o + n].view(shp)))
             return
         ops.gemm(GEMM_TN, st["w"].d_dep_pre, st["x_dep"], self.arena.g("depth_projection.weight"), ws=self.ws,
@@ -1540,8 +1557,10 @@ class FusionEngine:
             loss, counts = self.losses(past_label, target, target_dur, tick=True)
         finally:
             self.defer_tail, self.defer_loss_reduce = keep, keep_r
-        # (backward(fused_adamw=...) + adamw(skip_depth=True) would update depth_projection.weight inside its
-        #  weight-gradient GEMM; measured neutral at the bench shape, so the plain sequence stays the default)
-        self.backward(adamw_next=True)
-        self.adamw(lr, weight_decay, ticked=True, prefill_dropout=True)
+        # depth_projection.weight updated inside its weight-gradient kernel where that pays (depth_adamw_fusable: the tiled
+        # bf16x3 kernel of the wide / long shapes; measured neutral on the headline shape's panel kernel, which keeps the
+        # plain sequence)
+        fuse = self.depth_adamw_fusable()
+        self.backward(fused_adamw=dict(lr=lr, weight_decay=weight_decay) if fuse else None, adamw_next=True)
+        self.adamw(lr, weight_decay, ticked=True, prefill_dropout=True, skip_depth=fuse)
         return loss, counts

@@ -120,7 +120,8 @@ def gemm(layout, a, b, c, *, ws=None, tile=0, splitk=0, defer_reduce=False, adam
         d.adam_beta1, d.adam_beta2, d.adam_eps = adam["beta1"], adam["beta2"], adam["eps"]
         d.adam_wd, d.adam_gscale = adam["weight_decay"], adam["grad_scale"]
         d.splitk, d.k_per_split = 1, K
-        d.tile = 3 if d.tile in (3, 5) else 2           # the AdamW epilogue needs a tile without k-split waves
+        if d.tile != 10:                                # (the bf16x3 TN tile has the epilogue itself)
+            d.tile = 3 if d.tile in (3, 5) else 2       # the AdamW epilogue needs a tile without k-split waves
     if tile:
         d.tile = tile
     if splitk:
@@ -142,6 +143,14 @@ def gemm(layout, a, b, c, *, ws=None, tile=0, splitk=0, defer_reduce=False, adam
     if d.splitk > 1 and not defer_reduce:
         check(lib.r3d_splitk_reduce(C.byref(d), s), "r3d_splitk_reduce")
     return d
+
+
+def gemm_planned_tile(layout, a, b, c, **epi):
+    """The tile r3d_gemm_plan picks for this product (no launch)."""
+    d = GemmDesc()
+    _fill_desc(d, layout, a, b, c, **epi)
+    check(_lib.load().r3d_gemm_plan(C.byref(d)), "r3d_gemm_plan")
+    return int(d.tile)
 
 
 def gemm_bf3_nt_pair(a1, b1, c1, ws1, a2, b2, c2, ws2):

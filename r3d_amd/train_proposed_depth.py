@@ -168,8 +168,9 @@ class _GraphedSteps:
         finally:
             if fused:
                 eng.defer_tail, eng.defer_loss_reduce, eng.loss_acc = keep
-        eng.backward(adamw_next=True)
-        eng.adamw(lr, wd, betas=betas, eps=eps, ticked=True)     # (no dropout prefill: every captured step generates its
+        fuse = bool(fused and eng.depth_adamw_fusable())         # (wide / long shapes: AdamW of the depth weight in its wgrad kernel)
+        eng.backward(fused_adamw=dict(lr=lr, weight_decay=wd, betas=betas, eps=eps) if fuse else None, adamw_next=True)
+        eng.adamw(lr, wd, betas=betas, eps=eps, ticked=True, skip_depth=fuse)     # (no dropout prefill: every captured step generates its
         if not folded:                                            #  own masks, so graphs of different shapes can interleave)
             self.acc_loss += loss
             self.acc_cnt += counts
@@ -433,12 +434,15 @@ def train(args, model, train_loader, optimizer, scheduler, criterion, model_save
             eng.forward(features, depth_features, past_label, "train", training=model.training)
             fused_opt = isinstance(optimizer, FlatAdamW)
             loss, counts = eng.losses(past_label, trans_future_target, trans_dur_future, tick=fused_opt)
-            eng.backward(adamw_next=fused_opt and dp is None)
+            fuse = bool(fused_opt and dp is None and hasattr(eng, "depth_adamw_fusable") and eng.depth_adamw_fusable())
+            eng.backward(fused_adamw=dict(lr=g["lr"], weight_decay=g["weight_decay"], betas=g["betas"], eps=g["eps"])
+                         if fuse else None, adamw_next=fused_opt and dp is None)
             if dp is not None:
                 dp.wait_grads()
             if fused_opt:
                 eng.adamw(g["lr"], g["weight_decay"], betas=g["betas"], eps=g["eps"],
-                          grad_scale=dp.grad_scale if dp is not None else 1.0, ticked=True, prefill_dropout=True)
+                          grad_scale=dp.grad_scale if dp is not None else 1.0, ticked=True, prefill_dropout=True,
+                          skip_depth=fuse)
             else:                                   # any other torch optimiser: expose the arena gradients to it
                 if dp is not None:
                     eng.arena.grads.mul_(dp.grad_scale)

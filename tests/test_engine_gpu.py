@@ -387,6 +387,37 @@ def test_adamw_in_weight_gradient_epilogue_equals_flat_adamw():
         assert float((dlt <= 1e-5 * (1 + states[0][k][0].abs())).double().mean()) > 0.99
 
 
+@pytest.mark.parametrize("B,S,H", [(4, 64, 256), (8, 32, 128)])
+def test_depth_adamw_in_the_bf16x3_weight_gradient_kernel(B, S, H):
+    """train_step() updates depth_projection.weight inside its weight-gradient kernel where that product runs on the tiled
+    bf16x3 kernel (more than 128 token rows or hidden units: engine.depth_adamw_fusable()); two steps must leave the same
+    parameters and moments as the flat AdamW launch on the stored gradient (same kernel, same products: agreement to rounding)."""
+    from oracle import synth
+    from r3d_amd.model.futr_safuser_tokenfusion import FUTR
+    K, pad = 17, 18
+    args = argparse.Namespace(input_dim=2048, seg=True, anticipate=True, max_pos_len=2000, input_type="i3d_transcript")
+    states = []
+    for fuse in (False, True):
+        model = FUTR(K, H, pad, torch.device("cuda"), args, n_query=8, n_head=8, num_encoder_layers=2, num_decoder_layers=1)
+        names = [(n, tuple(p.shape)) for n, p in model.named_parameters()]
+        model.load_state_dict({n: torch.from_numpy(v) for n, v in synth.fill_state(names).items()}, strict=False)
+        model = model.to("cuda").eval()
+        eng = model.engine()
+        eng.fuse_depth_adamw = fuse
+        d = [torch.from_numpy(x).cuda() for x in synth.make_batch(B, S, K, pad, 77)]
+        for _ in range(2):
+            eng.train_step(d[0], d[1], d[2], d[3], d[4], 1e-3, 5e-3, training=False)
+        torch.cuda.synchronize()
+        assert eng.depth_adamw_fusable() == fuse
+        a = eng.arena
+        states.append((a.params[:a.n_live].clone(), a.exp_avg.clone(), a.exp_avg_sq.clone()))
+    close_rel(states[1][1], states[0][1], "exp_avg", rtol=1e-5)
+    close_rel(states[1][2], states[0][2], "exp_avg_sq", rtol=1e-5)
+    dlt = (states[0][0] - states[1][0]).abs()
+    assert float(dlt.max()) <= 2.1 * 1e-3 * 2                       # (Adam turns a noise-level sign difference into +-lr per step)
+    assert float((dlt <= 1e-5 * (1 + states[0][0].abs())).double().mean()) > 0.99
+
+
 @pytest.mark.parametrize("flags", [dict(use_fused_tail=False), dict(use_paired_launches=False),
                                    dict(use_fused_tail=False, use_paired_launches=False),
                                    dict(use_fused_tail=False, use_paired_launches=False, use_fused_embed=False),

@@ -600,6 +600,34 @@ def test_gemm_bf16x3_weight_gradient_tiled(ops, K, M, N):
     assert e1 < 3e-6 and e1 < 4 * e0 + 3e-7, (e1, e0)
 
 
+@pytest.mark.parametrize("K,M,N", [(256, 256, 8192), (512, 512, 6272), (130, 132, 2052)])
+def test_gemm_bf16x3_weight_gradient_tiled_with_adamw_epilogue(ops, K, M, N):
+    """Tile 10 with r3d_gemm_desc::adam_*: the parameter and both moments are updated where the gradient tile is finished (the
+    gradient is never stored) -- against the same kernel's stored gradient followed by the flat AdamW launch, two steps."""
+    from r3d_amd._lib import GEMM_TN
+    a = dev(rnd(K, M, seed=K + M) * 0.05)
+    b = dev(torch.rand(K, N, generator=torch.Generator().manual_seed(N)))
+    p0 = rnd(M, N, seed=5) * 0.1
+    lr_t = torch.full((1,), 1e-3, dtype=torch.float32, device="cuda")
+    step_t = torch.zeros(1, dtype=torch.int64, device="cuda")
+    ws = ops.GemmWorkspace("cuda")
+    pf, mf, vf = dev(p0.clone()), torch.zeros(M, N, device="cuda"), torch.zeros(M, N, device="cuda")
+    pr, mr, vr = dev(p0.clone()), torch.zeros(M, N, device="cuda"), torch.zeros(M, N, device="cuda")
+    g = torch.empty(M, N, device="cuda")
+    for step in range(2):
+        ops.tick(step_t, None)
+        d1 = ops.gemm(GEMM_TN, a, b, pf, ws=ws, prec=1, alpha=0.5,
+                      adam=dict(m=mf, v=vf, lr_t=lr_t, step_t=step_t, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=5e-3,
+                                grad_scale=0.25))
+        d0 = ops.gemm(GEMM_TN, a, b, g, ws=ws, prec=1, alpha=0.5)
+        ops.adamw_flat(pr.view(-1), g.view(-1), mr.view(-1), vr.view(-1), lr_t, step_t, weight_decay=5e-3, grad_scale=0.25)
+        torch.cuda.synchronize()
+        assert d1.tile == 10 and d0.tile == 10
+        assert_close(mf.cpu(), mr.cpu(), 1e-6, 1e-9, f"step {step} exp_avg")
+        assert_close(vf.cpu(), vr.cpu(), 1e-6, 1e-12, f"step {step} exp_avg_sq")
+        assert_close(pf.cpu(), pr.cpu(), 1e-6, 1e-7, f"step {step} parameter")
+
+
 @pytest.mark.parametrize("M,N,K", [(128, 128, 50176), (128, 128, 19200), (512, 512, 50176), (100, 96, 8200), (256, 1024, 16384),
                                    (8, 40, 8192)])
 def test_gemm_bf16x3_long_k_projection(ops, M, N, K):
