@@ -1044,7 +1044,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf3_tn_kernel(const r3d_gemm_desc
         const float step_size = lr / bc1;
         const float b2 = d.adam_beta2, eps = d.adam_eps, gs = d.alpha * d.adam_gscale;
         const float omb1 = 1.0f - d.adam_beta1, omb2 = 1.0f - b2;
-        // 8 float4 per thread and array, in two batches of four: all twelve loads of a batch are in flight before the first
+        // 8 float4 per thread and array in R3D_TN_ADAM_BATCH batches: all loads of a batch are in flight before the first
         // update (unconditional, from clamped addresses; the stores of out-of-range elements are skipped)
 #define R3D_ADAM_E(c)                                              \
             {                                                      \
@@ -1055,14 +1055,18 @@ __global__ __launch_bounds__(512, 1) void gemm_bf3_tn_kernel(const r3d_gemm_desc
                 const float den = sqrtf(vv[u].c) / bc2_sqrt + eps; \
                 pp[u].c -= step_size * (mm[u].c / den);            \
             }
+#ifndef R3D_TN_ADAM_BATCH
+#define R3D_TN_ADAM_BATCH 2
+#endif
+        constexpr int NB = 8 / R3D_TN_ADAM_BATCH;
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            float4 pp[4], mm[4], vv[4];
-            size_t off[4];
-            bool in[4];
+        for (int half = 0; half < R3D_TN_ADAM_BATCH; ++half) {
+            float4 pp[NB], mm[NB], vv[NB];
+            size_t off[NB];
+            bool in[NB];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int f = tid + 512 * (4 * half + u);
+            for (int u = 0; u < NB; ++u) {
+                const int f = tid + 512 * (NB * half + u);
                 const int row = f / (BN / 4), c4 = f % (BN / 4);
                 const int gm = m0 + row, gn = n0 + 4 * c4;
                 in[u] = gm < M && gn < N;
@@ -1072,8 +1076,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf3_tn_kernel(const r3d_gemm_desc
                 vv[u] = *reinterpret_cast<const float4*>(d.adam_v + off[u]);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int f = tid + 512 * (4 * half + u);
+            for (int u = 0; u < NB; ++u) {
+                const int f = tid + 512 * (NB * half + u);
                 const int row = f / (BN / 4), c4 = f % (BN / 4);
                 const float4 gg = *reinterpret_cast<const float4*>(ct + row * kTnCS + 4 * c4);
                 R3D_ADAM_E(x) R3D_ADAM_E(y) R3D_ADAM_E(z) R3D_ADAM_E(w)
