@@ -101,8 +101,8 @@ typedef struct r3d_gemm_desc {
                                 6 = persistent 64-column panels with A^T resident in registers (TN, K <= 128, M <= 128,
                                     plain epilogue: the weight gradient of a wide layer from few rows) */
     int32_t vec;             /* filled by the library: operands allow 16-byte loads */
-    /* AdamW in the epilogue (adam_m != NULL; weight-gradient GEMMs with splitk == 1, tile 2 or 3, N % 4 == 0, 16-byte
-     * aligned C / moments, no other epilogue operand): the
+    /* AdamW in the epilogue (adam_m != NULL; weight-gradient GEMMs with splitk == 1, tile 2, 3 or -- TN, prec == 1 -- 10,
+     * N % 4 == 0, 16-byte aligned C / moments, no other epilogue operand): the
      * product alpha * A.B is the GRADIENT and is not stored; C is the PARAMETER, adam_m / adam_v its moments (same
      * layout and ldc), all three updated in place exactly as r3d_adamw_flat would (lr, step: device scalars).  Saves the
      * gradient's write and re-read and one pass over the parameter: depth_projection.weight is 86 % of the model. */
