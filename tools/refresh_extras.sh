@@ -15,6 +15,9 @@ echo "== bench.py (default)" >> $O/ab_lines.txt
 timeout -k 10 200 python3 $R/bench.py --steps 400 --no-cpu-baseline 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'])" >> $O/ab_lines.txt
 # in-kernel timeline of the forward depth projection (builds a probe variant, restores the product build)
 bash $R/tools/nt_timeline.sh > $O/nt_timeline.txt 2>&1
+mkdir -p $R/tools/_build
+[ -x $R/tools/_build/nt_stream_probe ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -o $R/tools/_build/nt_stream_probe $R/tools/nt_stream_probe.hip
+[ -x $R/tools/_build/split_probe ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -I $R/r3d_amd/csrc -I $R/include -o $R/tools/_build/split_probe $R/tools/split_probe.hip
 timeout -k 10 60 $R/tools/_build/nt_stream_probe > $O/nt_stream_probe.txt 2>&1
 timeout -k 10 60 $R/tools/_build/split_probe > $O/split_probe.txt 2>&1
 ls $O
