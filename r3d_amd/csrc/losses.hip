@@ -61,6 +61,27 @@ __global__ __launch_bounds__(512) void tail_losses_kernel(const r3d_tail_losses_
     tail_losses_finish(t, a, part, arrivals, &is_last);
 }
 
+// The same launch for hidden sizes 129 .. 512 (tail_clip_body_wide<8>): head weights and LayerNorm partials in dynamic LDS.
+__global__ __launch_bounds__(512) void tail_losses_wide_kernel(const r3d_tail_losses_args t, const LossArgs a, float* part,
+                                                               unsigned* arrivals) {
+    extern __shared__ __attribute__((aligned(16))) float dyn[];       // [n_head][H] head weights | [8][4][H] partials
+    __shared__ float lg[8][kTLHeads + 8];
+    __shared__ float dl[8][kTLHeads + 8];
+    __shared__ int is_last;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if ((int)blockIdx.x < a.B) {
+        float* whs = dyn;
+        float* red = dyn + (size_t)t.n_head * t.H;
+        for (int i = threadIdx.x; i < t.n_head * t.H; i += 512) whs[i] = t.w_head[i];
+        __syncthreads();
+        tail_clip_body_wide<8>(t, a, part, (int)blockIdx.x, lg, dl, whs, red);
+    } else {
+        const int u = ((int)blockIdx.x - a.B) * 8 + wave;
+        if (u < a.B * a.S) losses_unit(a, part, u, lane);
+    }
+    tail_losses_finish(t, a, part, arrivals, &is_last);
+}
+
 __global__ __launch_bounds__(256) void losses_finalize_kernel(const r3d_loss_finalize_job j) {
     __shared__ double red[4][3][3];
     loss_finalize_block<4>(j, red);
@@ -107,7 +128,7 @@ R3D_EXPORT int r3d_losses_fwd_bwd(const float* seg_logits, int ld_seg, const flo
 /* Training step only: r3d_decoder_tail_fwd + r3d_losses_fwd_bwd + r3d_decoder_tail_bwd as one launch (see
  * tail_losses_kernel).  Supported when r3d_decoder_tail_losses_supported(...) != 0; ws as for r3d_losses_fwd_bwd. */
 R3D_EXPORT int r3d_decoder_tail_losses_supported(int H, int n_head, int Q, int rows) {
-    return (H > 0 && H <= 128 && n_head > 0 && n_head <= kTLHeads && Q == 8 && rows > 0 && rows <= 1024 && rows % 8 == 0) ? 1 : 0;
+    return (H > 0 && H <= 512 && n_head > 0 && n_head <= kTLHeads && Q == 8 && rows > 0 && rows <= 1024 && rows % 8 == 0) ? 1 : 0;
 }
 
 R3D_EXPORT int r3d_decoder_tail_losses(const r3d_tail_losses_args* p, float* ws, void* stream) {
@@ -125,6 +146,15 @@ R3D_EXPORT int r3d_decoder_tail_losses(const r3d_tail_losses_args* p, float* ws,
                t.d_out + t.K, t.ld_dout, t.loss_out, t.counts, t.tick_a, t.tick_b};
     const int units = t.B * t.S + t.B * t.Q + t.B;
     const int grid = t.B + r3d_cdiv(t.B * t.S, 8);
+    if (t.H > 128) {                      // hidden 129 .. 512: head weights + LayerNorm partials in dynamic LDS
+        const size_t lds = ((size_t)t.n_head * t.H + (size_t)8 * 4 * t.H) * sizeof(float);
+        hipError_t e = hipFuncSetAttribute((const void*)tail_losses_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(tail_losses_wide_kernel, dim3(grid), dim3(512), lds, (hipStream_t)stream, t, a, ws,
+                           reinterpret_cast<unsigned*>(ws + 4 * (size_t)units));
+        R3D_LAUNCH_CHECK();
+        return R3D_OK;
+    }
     hipLaunchKernelGGL(tail_losses_kernel, dim3(grid), dim3(512), 0, (hipStream_t)stream, t, a, ws,
                        reinterpret_cast<unsigned*>(ws + 4 * (size_t)units));
     R3D_LAUNCH_CHECK();

@@ -426,6 +426,218 @@ __device__ __forceinline__ void tail_clip_body(const r3d_tail_losses_args& t, co
     }
 }
 
+template <int EPL>
+__device__ __forceinline__ void lnw_apply(const float (&x)[EPL], const float (&g)[EPL], const float (&b)[EPL], int H, int lane,
+                                          float (&y)[EPL], float& mean, float& rstd) {
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) s += (lane + 64 * e < H) ? x[e] : 0.f;
+    mean = wave_sum(s) / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const float dl = (lane + 64 * e < H) ? x[e] - mean : 0.f;
+        q += dl * dl;
+    }
+    rstd = 1.0f / sqrtf(wave_sum(q) / (float)H + kLnEpsTL);
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) y[e] = (lane + 64 * e < H) ? (x[e] - mean) * rstd * g[e] + b[e] : 0.f;
+}
+
+// The same role for hidden sizes up to 64 EPL (tail_losses_wide_kernel: EPL = 8, hidden <= 512): a lane holds EPL columns of its
+// row; the head weights (n_head x H) and the LayerNorm parameter partials ([8][4][H]) live in dynamic LDS instead of registers /
+// a fixed [8][4][128] array (whs is filled by the caller, behind a barrier).  Same arithmetic and order per row.
+template <int EPL>
+__device__ __forceinline__ void tail_clip_body_wide(const r3d_tail_losses_args& t, const LossArgs& a, float* part, const int b,
+                                                    float (*lg)[kTLHeads + 8], float (*dl)[kTLHeads + 8], const float* whs,
+                                                    float* red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int H = t.H, K = a.K, Q = a.Q, NH = t.n_head, N = a.B * a.S, BQ = a.B * a.Q;
+    const int row = b * Q + wave;            // Q == 8 == waves (validated by the host)
+    int cc[EPL];
+    float x[EPL], g3[EPL], b3[EPL], gF[EPL], bF[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const int c = lane + 64 * e;
+        cc[e] = c < H ? c : H - 1;
+        x[e] = t.x[(size_t)row * H + cc[e]];
+        g3[e] = t.g3[cc[e]]; b3[e] = t.b3[cc[e]]; gF[e] = t.gF[cc[e]]; bF[e] = t.bF[cc[e]];
+    }
+    // backward operands that do not depend on anything computed here: issued now, consumed after the barrier
+    float keep[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) keep[e] = t.drop ? t.drop_scale * (float)t.drop[(size_t)row * H + cc[e]] : 1.f;
+    // ... and the clip's labels, targets and durations (S <= 64, B*Q <= 64: one per lane -- validated by the host):
+    // one round trip under the forward tail instead of four dependent ones after the barrier
+    const bool small = a.S <= 64 && BQ <= 64;                    // (beyond that the label / mask scans loop, below)
+    const int64_t pl_pre = a.past_label[(size_t)b * a.S + (lane < a.S ? lane : 0)];
+    const int64_t tgt_first = a.target[(size_t)b * Q];
+    const int64_t tgt_row = a.target[row];
+    const float td_all = a.target_dur[lane < BQ ? lane : 0];
+    const float td_clip = a.target_dur[(size_t)b * Q + (lane < Q ? lane : 0)];
+    const float dden_pre = a.dur_den ? *a.dur_den : 0.f;
+    // ---- forward tail: norm3 -> decoder.norm -> heads
+    float y3[EPL], yF[EPL], m3, r3, mF, rF;
+    lnw_apply<EPL>(x, g3, b3, H, lane, y3, m3, r3);
+    lnw_apply<EPL>(y3, gF, bF, H, lane, yF, mF, rF);
+    if (lane == 0) { t.m3[row] = m3; t.r3[row] = r3; t.mF[row] = mF; t.rF[row] = rF; }
+#pragma unroll
+    for (int e = 0; e < EPL; ++e)
+        if (lane + 64 * e < H) {
+            t.t3[(size_t)row * H + lane + 64 * e] = y3[e];
+            t.tgtF[(size_t)row * H + lane + 64 * e] = yF[e];
+        }
+    {
+        float p[kTLHeads];
+#pragma unroll
+        for (int k = 0; k < kTLHeads; ++k) {
+            const int kc = k < NH ? k : NH - 1;
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) s += yF[e] * whs[(size_t)kc * H + cc[e]];      // (yF is 0 beyond H)
+            p[k] = s;
+        }
+#pragma unroll
+        for (int k = 0; k < kTLHeads; ++k) {
+            if (k < NH) {                                     // wave-uniform
+                const float v = wave_sum(p[k]) + t.b_head[k];
+                if (lane == 0) { t.out[(size_t)row * t.ld_out + k] = v; lg[wave][k] = v; }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- losses of this row: anticipation CE (cal_weighted_loss) ...
+    float out_l, out_c, out_v;
+    {
+        // last observed (non-pad) label of the clip: highest lane whose label is not the pad index
+        int last = -1;
+        int64_t ref = (int64_t)a.pad_idx;
+        if (small) {
+            const unsigned long long obs = __ballot(lane < a.S && pl_pre != (int64_t)a.pad_idx);
+            last = obs ? 63 - __builtin_clzll(obs) : -1;
+            const int lsel = __builtin_amdgcn_readfirstlane(last < 0 ? 0 : last);
+            const unsigned rlo = __builtin_amdgcn_readlane((unsigned)(unsigned long long)pl_pre, lsel);
+            const unsigned rhi = __builtin_amdgcn_readlane((unsigned)((unsigned long long)pl_pre >> 32), lsel);
+            if (last >= 0) ref = (int64_t)(((unsigned long long)rhi << 32) | rlo);
+        } else {
+            for (int s = lane; s < a.S; s += 64)
+                if (a.past_label[(size_t)b * a.S + s] != (int64_t)a.pad_idx) last = s;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) last = max(last, __shfl_xor(last, off, 64));
+            if (last >= 0) ref = a.past_label[(size_t)b * a.S + last];
+        }
+        const float w = (ref == tgt_first) ? 1.0f : 10.0f;
+        const int64_t lab = tgt_row;
+        const bool valid = (lab != (int64_t)a.pad_idx) && (lab != (int64_t)a.exclude_idx) && lab >= 0 && lab < K;
+        int am;
+        const float l = ce_row(&lg[wave][0], K, lab, valid, a.pad_idx, w * a.grad_scale / (float)BQ, &dl[wave][0], lane, &am);
+        out_l = l * w; out_v = valid ? 1.f : 0.f; out_c = (valid && (int64_t)am == lab) ? 1.f : 0.f;
+        if (lane == 0) {
+            __hip_atomic_store(part + 4 * (size_t)(N + row) + 0, out_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(part + 4 * (size_t)(N + row) + 1, out_c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(part + 4 * (size_t)(N + row) + 2, out_v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // ... and the duration MSE (normalize_duration over the clip's Q queries; every wave redoes the clip's sums,
+    // wave 0 reports the clip's loss term)
+    {
+        float mc = 0.f;
+        if (small) mc = (lane < BQ && td_all != (float)a.pad_idx) ? 1.f : 0.f;
+        else
+            for (int e = lane; e < BQ; e += 64) mc += (a.target_dur[e] != (float)a.pad_idx) ? 1.f : 0.f;
+        mc = wave_sum(mc);
+        const float dur_den = a.dur_den ? dden_pre : mc;
+        const float mkq = (lane < Q && td_clip != (float)a.pad_idx) ? 1.f : 0.f;      // lane q < Q holds query q
+        const float eq = lane < Q ? expf(lg[lane < Q ? lane : 0][K]) * mkq : 0.f;
+        const float ssum = wave_sum(fabsf(eq));
+        const float den = fmaxf(ssum, 1e-12f);
+        float sq = 0.f, gp = 0.f;
+        if (lane < Q) {
+            const float p = eq / den;
+            const float tt = td_clip * mkq * mkq;
+            const float diff = p - tt;
+            sq = diff * diff;
+            gp = (2.f * diff / dur_den) * p;
+        }
+        sq = wave_sum(sq);
+        gp = wave_sum(gp);
+        const float td_w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(unsigned, td_clip),
+                                                                               __builtin_amdgcn_readfirstlane(wave)));
+        if (lane == 0) {
+            const float td = td_w;
+            const float mk = (td != (float)a.pad_idx) ? 1.f : 0.f;
+            const float p = expf(lg[wave][K]) * mk / den;
+            const float g = 2.f * (p - td * mk * mk) / dur_den;
+            dl[wave][K] = ((ssum >= 1e-12f) ? p * (g - gp) : 0.f) * a.grad_scale;
+            if (wave == 0) {
+                const size_t u = (size_t)N + BQ + b;
+                __hip_atomic_store(part + 4 * u + 0, sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(part + 4 * u + 1, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(part + 4 * u + 2, mc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    // the row's gradient leaves for the heads' weight gradient (a later grouped GEMM reads it from memory)
+    for (int k = lane; k < NH; k += 64) t.d_out[(size_t)row * t.ld_dout + k] = dl[wave][k];
+    // ---- backward tail: heads' input gradient -> decoder.norm backward -> norm3 backward (+ dropout3)
+    float d[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) d[e] = 0.f;
+#pragma unroll
+    for (int k = 0; k < kTLHeads; ++k) {
+        if (k < NH) {
+            const float dk = dl[wave][k];
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) d[e] += dk * whs[(size_t)k * H + cc[e]];
+        }
+    }
+    float agF[EPL], abF[EPL], ag3[EPL], ab3[EPL], xh[EPL], gg[EPL], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const bool in = lane + 64 * e < H;
+        xh[e] = in ? (y3[e] - mF) * rF : 0.f;
+        const float dd = in ? d[e] : 0.f;
+        agF[e] = dd * xh[e]; abF[e] = dd;
+        gg[e] = dd * gF[e];
+        s1 += gg[e]; s2 += gg[e] * xh[e];
+    }
+    s1 = wave_sum(s1) / (float)H; s2 = wave_sum(s2) / (float)H;
+    float dt[EPL], u1 = 0.f, u2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) dt[e] = rF * (gg[e] - s1 - xh[e] * s2);
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const bool in = lane + 64 * e < H;
+        xh[e] = in ? (x[e] - m3) * r3 : 0.f;
+        const float dd = in ? dt[e] : 0.f;
+        ag3[e] = dd * xh[e]; ab3[e] = dd;
+        gg[e] = dd * g3[e];
+        u1 += gg[e]; u2 += gg[e] * xh[e];
+    }
+    u1 = wave_sum(u1) / (float)H; u2 = wave_sum(u2) / (float)H;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const int c = lane + 64 * e;
+        if (c < H) {
+            const float o = r3 * (gg[e] - u1 - xh[e] * u2);
+            t.dx[(size_t)row * H + c] = o;
+            t.dx2[(size_t)row * H + c] = o * keep[e];
+            red[(wave * 4 + 0) * H + c] = agF[e]; red[(wave * 4 + 1) * H + c] = abF[e];
+            red[(wave * 4 + 2) * H + c] = ag3[e]; red[(wave * 4 + 3) * H + c] = ab3[e];
+        }
+    }
+    __syncthreads();
+    // partials per 4 rows (waves 0-3 -> partial block 2b, waves 4-7 -> 2b+1): r3d_layernorm_bwd's layout for B*Q rows
+    for (int i = threadIdx.x; i < 2 * 4 * H; i += 512) {
+        const int half = i / (4 * H), j = i - half * 4 * H, which = j / H, c = j - which * H;
+        const int w0 = 4 * half;
+        const float s = (red[(w0 * 4 + which) * H + c] + red[((w0 + 1) * 4 + which) * H + c]) +
+                        (red[((w0 + 2) * 4 + which) * H + c] + red[((w0 + 3) * 4 + which) * H + c]);
+        float* ws = which < 2 ? t.wsF : t.ws3;
+        ws[((size_t)(2 * b + half) * 2 + (which & 1)) * H + c] = s;
+    }
+}
+
 // The common end of the loss launches: counters / deferred or last-arrival reduction of the loss partials.
 __device__ __forceinline__ void tail_losses_finish(const r3d_tail_losses_args& t, const LossArgs& a, float* part,
                                                    unsigned* arrivals, int* is_last) {

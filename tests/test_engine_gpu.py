@@ -387,6 +387,46 @@ def test_adamw_in_weight_gradient_epilogue_equals_flat_adamw():
         assert float((dlt <= 1e-5 * (1 + states[0][k][0].abs())).double().mean()) > 0.99
 
 
+@pytest.mark.parametrize("H", [256, 512])
+def test_wide_tail_losses_launch_equals_the_three_launches(H):
+    """Hidden 129 .. 512: decoder tail forward + the three losses + tail backward as ONE launch (tail_losses_wide_kernel: head
+    weights and LayerNorm partials in dynamic LDS) against the three kernels it replaces -- losses, counters, every gradient."""
+    from oracle import synth
+    from r3d_amd.model.futr_safuser_tokenfusion import FUTR
+    from r3d_amd import ops
+    K, pad, B, S = 17, 18, 4, 32
+    args = argparse.Namespace(input_dim=2048, seg=True, anticipate=True, max_pos_len=2000, input_type="i3d_transcript")
+    model = FUTR(K, H, pad, torch.device("cuda"), args, n_query=8, n_head=8, num_encoder_layers=2, num_decoder_layers=1)
+    names = [(n, tuple(p.shape)) for n, p in model.named_parameters()]
+    model.load_state_dict({n: torch.from_numpy(v) for n, v in synth.fill_state(names).items()}, strict=False)
+    model = model.to("cuda").eval()
+    eng = model.engine()
+    assert ops.tail_losses_supported(H, K + 1, 8, B * 8)
+    d = [torch.from_numpy(x).cuda() for x in synth.make_batch(B, S, K, pad, 77)]
+    res, calls = [], []
+    real = ops.decoder_tail_losses
+    ops.decoder_tail_losses = lambda *a_, **k_: (calls.append(1), real(*a_, **k_))[1]
+    try:
+        for fused in (False, True):
+            eng.use_fused_tail = fused
+            eng.defer_tail = fused
+            eng.forward(d[0], d[1], d[2], "train", training=False)
+            loss, counts = eng.losses(d[2], d[4], d[3])
+            eng.backward()
+            torch.cuda.synchronize()
+            res.append((loss.clone(), counts.clone(), eng.arena.grads.clone()))
+            assert len(calls) == (1 if fused else 0), "the one-launch tail must run exactly in the fused pass"
+    finally:
+        ops.decoder_tail_losses = real
+        eng.defer_tail = False
+    close_rel(res[1][0], res[0][0], "loss", rtol=1e-5)
+    assert torch.equal(res[1][1], res[0][1])
+    a = eng.arena
+    for n in a.live_names:
+        o, k, _ = a.offsets[n]
+        close_rel(res[1][2][o:o + k], res[0][2][o:o + k], f"H{H} grad {n}", rtol=5e-4)
+
+
 @pytest.mark.parametrize("B,S,H", [(4, 64, 256), (8, 32, 128)])
 def test_depth_adamw_in_the_bf16x3_weight_gradient_kernel(B, S, H):
     """train_step() updates depth_projection.weight inside its weight-gradient kernel where that product runs on the tiled
