@@ -281,6 +281,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eval-dropout-off", action="store_true", help="bench the eval()-state step (dropout off)")
     ap.add_argument("--side-stream", action="store_true", help="run the query self-attention branch on a second HIP stream")
+    ap.add_argument("--no-auto-side-stream", action="store_true",
+                    help="hidden >= 512: keep the query self-attention branch on the launch stream (by default it is forked "
+                         "there on one rank; A/B)")
     ap.add_argument("--fused-decoder", action="store_true", help="run the decoder layer as decoder.hip (one workgroup per "
                                                                  "clip) instead of composed GEMM / attention / LN launches")
     ap.add_argument("--fused-adamw", action="store_true",
@@ -401,6 +404,7 @@ def main():
     eng.erank_weight = a.erank_weight
     eng.erank_warm_start = a.erank_warm
     eng.use_side_stream = a.side_stream
+    eng.auto_side_stream = not a.no_auto_side_stream
     eng.use_fused_decoder = a.fused_decoder
     eng.use_gemm_ln = not a.no_gemm_ln
     eng.use_fuser_chain = not a.no_fuser_chain

@@ -194,6 +194,10 @@ class FusionEngine:
         self.side = torch.cuda.Stream(self.device)      # weight-gradient stream: off the backward's critical path
         self.side2 = torch.cuda.Stream(self.device)     # independent branch (self-attention of the queries)
         self.ws_side2 = ops.GemmWorkspace(self.device)
+        # hidden >= 512 on one rank: the branch is 45-50 us long per direction there and pays for its join -- cfg4's per-GPU
+        # shape 1.10 -> 1.08 ms, cfg5's 1.57 -> 1.44 (auto_side_stream; multi-rank flows keep one stream: their capture
+        # with RCCL on the launch stream was never rehearsed with a second one)
+        self.auto_side_stream = True
         self.use_side_stream = False            # parameter-only branches on a second HIP stream: the cross-queue joins cost
                                                 # more than the branches hide (352 vs 339 us/step at the bench shape)
         self.use_fused_decoder = False          # decoder.hip (one workgroup per clip and layer): measured 2 % slower than
@@ -420,7 +424,7 @@ class FusionEngine:
             assert labels.dtype == torch.int64 and labels.is_cuda and labels.is_contiguous()
             key_labels = labels
         main = torch.cuda.current_stream()
-        multi = self.use_side_stream
+        multi = self._multi_stream()
         s2 = self.side2 if multi else main
         ws2 = self.ws_side2 if multi else self.ws
         qpos = a.p("query_embed.weight")
@@ -464,7 +468,7 @@ class FusionEngine:
             else:
                 dep_src, ns_d, bias_d = w.dep_pre, 1, None
             ride = bool(self.ride_planes and self.chain_bf3 and not self._planes_forked and self.L == 1 and H < 512 and
-                        not self.use_side_stream and not self.use_fused_decoder and self.use_paired_launches and
+                        not self._multi_stream() and not self.use_fused_decoder and self.use_paired_launches and
                         ((self.use_fuser_chain and self._chain_shape_ok(w)) or self._dec_chain_ok(w)))
             ops.embed_fuse_fwd(fw["slabs_r"] if dr.splitk > 1 else w.rgb, dr.splitk if dr.splitk > 1 else 0,
                                a.p("input_embed.bias"), dep_src, ns_d, bias_d, a.p("depth_layernorm.weight"),
@@ -676,6 +680,11 @@ class FusionEngine:
                 ent["pl_" + k + "_t"] = (w_, True)       # B[n][k] = W[k][n]: the input-gradient products dx = dy W
             self._planes = ops.WeightPlanes(ent, self.device)
         return self._planes
+
+    def _multi_stream(self):
+        """The query self-attention branch (parameters only for a one-layer decoder) on a second stream?"""
+        return bool(self.use_side_stream or (self.auto_side_stream and self.H >= 512 and self.tp is None and
+                                             self.grad_hook is None))
 
     def _planes_refresh(self):
         """The planes of the current parameters, before the first chain launch of a forward: joins the branch forward_begin
@@ -1207,7 +1216,7 @@ class FusionEngine:
         dm = (lambda k, r, c: w.drop[k].view(r, c)) if drop else (lambda k, r, c: None)
         dmf = (lambda k: w.drop[k]) if drop else (lambda k: None)
         main = torch.cuda.current_stream()
-        multi = self.use_side_stream
+        multi = self._multi_stream()
         s2 = self.side2 if multi else main
         ws2 = self.ws_side2 if multi else ws
         joined = True
