@@ -196,7 +196,9 @@ class FusionEngine:
         self.ws_side2 = ops.GemmWorkspace(self.device)
         # hidden >= 512 on one rank: the branch is 45-50 us long per direction there and pays for its join -- cfg4's per-GPU
         # shape 1.10 -> 1.08 ms, cfg5's 1.57 -> 1.44 (auto_side_stream; multi-rank flows keep one stream: their capture
-        # with RCCL on the launch stream was never rehearsed with a second one)
+        # with RCCL on the launch stream was never rehearsed with a second one).  The same switch forks the parameter-gradient
+        # tail of the backward (overlap_param_tail below: the 108 us grouped weight-gradient launch beside the 270 us depth
+        # weight gradient + its AdamW epilogue): cfg4 1.09 -> 1.03 ms
         self.auto_side_stream = True
         self.use_side_stream = False            # parameter-only branches on a second HIP stream: the cross-queue joins cost
                                                 # more than the branches hide (352 vs 339 us/step at the bench shape)
@@ -1008,8 +1010,9 @@ class FusionEngine:
         updated INSIDE its weight-gradient GEMM (the gradient is never written); follow with adamw(..., skip_depth=True).
         Only valid when that gradient needs no exchange (one GPU, or the pixel-sharded projection)."""
         self.prepare_fused_adamw(fused_adamw)
-        self._overlap_tail_now = bool(self.overlap_param_tail and self.last["tp"] is None and self.tp is None and
-                                      self.grad_hook is None and self._adam is None and
+        self._overlap_tail_now = bool((self.overlap_param_tail or (self.auto_side_stream and self.H >= 512)) and
+                                      self.last["tp"] is None and self.tp is None and
+                                      self.grad_hook is None and (self._adam is None or self.H >= 512) and
                                       "depth_projection.weight" in self.arena.offsets)
         try:
             self.backward_main(d_seg, d_actdur)

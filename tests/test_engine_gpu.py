@@ -387,6 +387,32 @@ def test_adamw_in_weight_gradient_epilogue_equals_flat_adamw():
         assert float((dlt <= 1e-5 * (1 + states[0][k][0].abs())).double().mean()) > 0.99
 
 
+def test_wide_model_parallel_branches_change_no_bit():
+    """Hidden 512 on one rank: train_step() forks the query self-attention branch and the parameter-gradient tail to second
+    streams (auto_side_stream) and updates depth_projection.weight in its weight-gradient kernel; against the single-stream
+    sequence the parameters, moments and losses after three steps must be bit-identical (no arithmetic changes, only order of
+    independent launches)."""
+    from oracle import synth
+    from r3d_amd.model.futr_safuser_tokenfusion import FUTR
+    K, pad, B, S, H = 17, 18, 4, 64, 512
+    args = argparse.Namespace(input_dim=2048, seg=True, anticipate=True, max_pos_len=2000, input_type="i3d_transcript")
+    outs = []
+    for auto in (False, True):
+        model = FUTR(K, H, pad, torch.device("cuda"), args, n_query=8, n_head=8, num_encoder_layers=2, num_decoder_layers=1)
+        names = [(n, tuple(p.shape)) for n, p in model.named_parameters()]
+        model.load_state_dict({n: torch.from_numpy(v) for n, v in synth.fill_state(names).items()}, strict=False)
+        model = model.to("cuda").train()
+        eng = model.engine()
+        eng.auto_side_stream = auto
+        d = [torch.from_numpy(x).cuda() for x in synth.make_batch(B, S, K, pad, 77)]
+        for _ in range(3):
+            loss, _ = eng.train_step(d[0], d[1], d[2], d[3], d[4], 1e-3, 5e-3, training=True)
+        torch.cuda.synchronize()
+        assert not eng._tail_pending
+        outs.append((eng.arena.params.clone(), eng.arena.exp_avg.clone(), eng.last["w"].loss.clone()))
+    assert torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 @pytest.mark.parametrize("H", [256, 512])
 def test_wide_tail_losses_launch_equals_the_three_launches(H):
     """Hidden 129 .. 512: decoder tail forward + the three losses + tail backward as ONE launch (tail_losses_wide_kernel: head
