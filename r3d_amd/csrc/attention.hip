@@ -230,7 +230,7 @@ __global__ __launch_bounds__(64) void mha_bwd_small_kernel(const MhaArgs a) {
 
 // small path: compile-time (dh, Lq) instance exists, Lk <= 64 and 16-byte aligned rows
 static bool mha_small_ok(const MhaArgs& a, bool bwd) {
-    if (a.Lk > 64 || a.Lq != 8 || !(a.dh == 16 || a.dh == 32 || a.dh == 64)) return false;
+    if (a.Lk > 64 || a.Lq != 8 || !(a.dh == 16 || a.dh == 32 || a.dh == 64 || a.dh == 128)) return false;
     if ((a.ldk | a.ldv) & 3) return false;
     if (!r3d_aligned16(a.k) || !r3d_aligned16(a.v)) return false;
     if (bwd && (((a.lddk | a.lddv) & 3) || !r3d_aligned16(a.dk) || !r3d_aligned16(a.dv))) return false;
@@ -243,11 +243,13 @@ static void mha_small_launch(const MhaArgs& a, hipStream_t s) {
     if (BWD) {
         if (a.dh == 16) hipLaunchKernelGGL((mha_bwd_small_kernel<16, 8>), g, blk, 0, s, a);
         else if (a.dh == 32) hipLaunchKernelGGL((mha_bwd_small_kernel<32, 8>), g, blk, 0, s, a);
-        else hipLaunchKernelGGL((mha_bwd_small_kernel<64, 8>), g, blk, 0, s, a);
+        else if (a.dh == 64) hipLaunchKernelGGL((mha_bwd_small_kernel<64, 8>), g, blk, 0, s, a);
+        else hipLaunchKernelGGL((mha_bwd_small_kernel<128, 8>), g, blk, 0, s, a);   // hidden 1024: one wave may use 512 registers
     } else {
         if (a.dh == 16) hipLaunchKernelGGL((mha_fwd_small_kernel<16, 8>), g, blk, 0, s, a);
         else if (a.dh == 32) hipLaunchKernelGGL((mha_fwd_small_kernel<32, 8>), g, blk, 0, s, a);
-        else hipLaunchKernelGGL((mha_fwd_small_kernel<64, 8>), g, blk, 0, s, a);
+        else if (a.dh == 64) hipLaunchKernelGGL((mha_fwd_small_kernel<64, 8>), g, blk, 0, s, a);
+        else hipLaunchKernelGGL((mha_fwd_small_kernel<128, 8>), g, blk, 0, s, a);
     }
 }
 

@@ -451,7 +451,9 @@ def test_token_exchange_fwd_bwd(ops):
 # attention core
 # ----------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("B,heads,Lq,Lk,dh,masked,drop", [(3, 8, 8, 8, 16, False, False), (2, 8, 8, 21, 16, True, False),
-                                                           (2, 4, 8, 130, 64, True, True), (1, 8, 8, 700, 4, False, False)])
+                                                           (2, 4, 8, 130, 64, True, True), (1, 8, 8, 700, 4, False, False),
+                                                           (2, 8, 8, 16, 128, True, True), (3, 8, 8, 8, 128, False, False),
+                                                           (2, 8, 8, 64, 64, True, True), (2, 8, 8, 32, 32, False, True)])
 def test_mha_core(ops, B, heads, Lq, Lk, dh, masked, drop):
     H = heads * dh
     q, kv = rnd(B * Lq, H, seed=1), rnd(B * Lk, 2 * H, seed=2)
