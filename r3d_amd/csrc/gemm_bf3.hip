@@ -402,7 +402,6 @@ __global__ __launch_bounds__(256 + R3D_NT_PROD, 1) void gemm_bf3_nt_kernel(const
             const unsigned short* nimg = lds16 + ((kt + 1) & 1) * STAGE;
 #pragma unroll
             for (int ks = 0; ks < ((R3D_NT_PROBE & 1) ? 0 : NKS); ++ks) {
-                constexpr int kDummy = 0; (void)kDummy;
                 const int cur = ks & 1, nxt = cur ^ 1;              // (NKS is even: the parity carries over the stage boundary)
                 if (ks + 1 < NKS) {
                     rd(nxt, img, ks + 1);
