@@ -445,7 +445,7 @@ def main():
         eng.forward_finish()
         eng.losses(lab, tgt, dur, tick=True)
         fuse = (fuse_adam and (dp is None or tp is not None)) or (      # that gradient needs no exchange
-            dp is None and not a.no_fused_adamw and eng.depth_adamw_fusable())   # ... and the engine finds it pays (tile 10)
+            dp is None and not a.no_fused_adamw and eng.depth_adamw_fusable())   # ... and the engine finds it pays (tiles 10 / 12)
         eng.backward(fused_adamw=dict(lr=c["lr"], weight_decay=c["wd"], grad_scale=gscale) if fuse else None,
                      adamw_next=dp is None)
         if dp is not None:

@@ -94,14 +94,16 @@ typedef struct r3d_gemm_desc {
     int32_t tile;            /* 0 = auto; workgroup tile: 1 = 32x32 (4 k-split waves), 2 = 64x64, 3 = 128x128,
                                 4 = 64x64 with 2 k-split wave groups, 5 = 128x128 with 2 k-split wave groups,
                                 10 = TN product with 128 x 128 tiles on the bf16 matrix cores (prec == 1; M, N, lda, ldb % 4 == 0,
-                                    alpha / accumulate epilogue only: the depth weight gradient beyond tile 7's limits),
+                                    alpha / accumulate epilogue or adam_*: the depth weight gradient beyond tile 7's limits),
+                                12 = tile 10's kernel with ONE LDS stage and <= 128 registers: two workgroups per CU (the planner's pick),
+                                11 = tile 9 with uniform waves (kept for measurement),
                                 8 / 9 = split-K NT product with 64 x 64 / 128 x 128 tiles on the bf16 matrix cores (prec == 1,
                                     K % 8 == 0, 16-byte aligned K-contiguous operands, no prologue: the forward depth projection),
                                 7 = tile 6 on the bf16 matrix cores (prec == 1),
                                 6 = persistent 64-column panels with A^T resident in registers (TN, K <= 128, M <= 128,
                                     plain epilogue: the weight gradient of a wide layer from few rows) */
     int32_t vec;             /* filled by the library: operands allow 16-byte loads */
-    /* AdamW in the epilogue (adam_m != NULL; weight-gradient GEMMs with splitk == 1, tile 2, 3 or -- TN, prec == 1 -- 10,
+    /* AdamW in the epilogue (adam_m != NULL; weight-gradient GEMMs with splitk == 1, tile 2, 3 or -- TN, prec == 1 -- 10 / 12,
      * N % 4 == 0, 16-byte aligned C / moments, no other epilogue operand): the
      * product alpha * A.B is the GRADIENT and is not stored; C is the PARAMETER, adam_m / adam_v its moments (same
      * layout and ldc), all three updated in place exactly as r3d_adamw_flat would (lr, step: device scalars).  Saves the

@@ -853,7 +853,13 @@ int launch_gemm_bf3_nt(const r3d_gemm_desc& d, hipStream_t s) {
 // octet position XOR-swizzled by (row >> 4) & 3 (conflict-free stores and operand reads).
 // Placement: the tiles of one N panel (they share the B operand) get equal linear id mod 8, i.e. one XCD's L2.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512, 1) void gemm_bf3_tn_kernel(const r3d_gemm_desc d, const int G, const int NG) {
+// ONE = true (tile 12): a SINGLE LDS stage (61 KB; 68 KB with the AdamW epilogue's tile image) and at most 128 registers, so TWO
+// workgroups share a CU.  Inside a workgroup the producers then store a stage only after the consumers have read the previous
+// one (two barriers per k-step, no overlap of the LDS stores with the MFMAs) -- the overlap comes from the OTHER workgroup of the
+// CU, which is not in lockstep with this one: its MFMAs run under this one's split and stores, and its epilogue (the AdamW
+// streaming) under this one's k-loop.
+template <bool ONE>
+__global__ __launch_bounds__(512, ONE ? 2 : 1) void gemm_bf3_tn_kernel(const r3d_gemm_desc d, const int G, const int NG) {
     constexpr int BM = 128, BN = 128, BK = 32, S = BK + 8;
     constexpr int kTnCS = BN + 4;                               // floats per row of the AdamW epilogue's tile image
     constexpr int PLANE = BM * S;                               // BM == BN: same plane size for both operands
@@ -879,10 +885,11 @@ __global__ __launch_bounds__(512, 1) void gemm_bf3_tn_kernel(const r3d_gemm_desc
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         const int ra = wm * 64 + l31, rb = wn * 64 + l31;       // rows of tile i = 0 / j = 0; i, j = 1: + 32
         const int xa0 = (ra >> 4) & 3, xa1 = ((ra + 32) >> 4) & 3, xb0 = (rb >> 4) & 3, xb1 = ((rb + 32) >> 4) & 3;
-        __syncthreads();                                            // stage 0 written
+        if (!ONE) __syncthreads();                                  // stage 0 written
         for (int kt = 0; kt < nk; ++kt) {
+            if (ONE) __syncthreads();                               // (A) the stage holds tile kt
             R3D_TN_MARK(1 + 2 * kt);
-            const unsigned short* ia = lds16 + (kt & 1) * STAGE;
+            const unsigned short* ia = lds16 + (ONE ? 0 : (kt & 1) * STAGE);
             const unsigned short* ib = ia + 3 * PLANE;
 #pragma unroll
             for (int ks = 0; ks < BK / 16; ++ks) {
@@ -917,7 +924,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf3_tn_kernel(const r3d_gemm_desc
             __syncthreads();
         }
         R3D_TN_MARK(1 + 2 * nk);
-        if (nk & 1) __syncthreads();                                // (the producers' loop runs whole pairs of k-steps)
+        if (!ONE && (nk & 1)) __syncthreads();                      // (the producers' loop runs whole pairs of k-steps)
         // C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
         const float alpha = d.alpha;
         const bool accum = d.accumulate != 0;
@@ -1002,6 +1009,25 @@ __global__ __launch_bounds__(512, 1) void gemm_bf3_tn_kernel(const r3d_gemm_desc
         const int last = nk - 1;
         auto run = [&](auto check) {
             R3D_TN_MARK(0);
+            if (ONE) {
+                load_stage(s0, 0, check);
+                load_stage(s1, min(1, last), check);
+                for (int kt = 0; kt < nk; kt += 2) {                // straight-line pairs (register stages s0 / s1 alternate)
+                    store_stage(lds16, s0, kt, check);
+                    load_stage(s0, min(kt + 2, last), check);
+                    __builtin_amdgcn_sched_barrier(0);
+                    __syncthreads();                                // (A)
+                    __syncthreads();                                // (B) the consumers have read the stage
+                    if (kt + 1 < nk) {
+                        store_stage(lds16, s1, kt + 1, check);
+                        load_stage(s1, min(kt + 3, last), check);
+                        __builtin_amdgcn_sched_barrier(0);
+                        __syncthreads();
+                        __syncthreads();
+                    }
+                }
+                return;
+            }
             load_stage(s0, 0, check);
             load_stage(s1, min(1, last), check);
             store_stage(lds16, s0, 0, check);
@@ -1103,14 +1129,26 @@ bool gemm_bf3_tn_ok(const r3d_gemm_desc& d) {
 int launch_gemm_bf3_tn(const r3d_gemm_desc& d, hipStream_t s) {
     if (!gemm_bf3_tn_ok(d)) return R3D_EINVAL;
     const int tm = r3d_cdiv(d.M, 128), tn = r3d_cdiv(d.N, 128);
+    if (d.tile == 12) {                      // single LDS stage, two workgroups per CU
+        const size_t lds1 = (size_t)128 * 132 * sizeof(float);      // >= one stage (61 440 B): the AdamW epilogue's tile image
+        static bool attr1 = false;
+        if (!attr1) {
+            hipError_t e = hipFuncSetAttribute((const void*)gemm_bf3_tn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+            if (e != hipSuccess) return (int)e;
+            attr1 = true;
+        }
+        hipLaunchKernelGGL(gemm_bf3_tn_kernel<true>, dim3(8 * tm * r3d_cdiv(tn, 8)), dim3(512), lds1, s, d, tm, tn);
+        R3D_LAUNCH_CHECK();
+        return R3D_OK;
+    }
     const size_t lds = (size_t)2 * 6 * 128 * 40 * sizeof(unsigned short);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf3_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf3_tn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm_bf3_tn_kernel, dim3(8 * tm * r3d_cdiv(tn, 8)), dim3(512), lds, s, d, tm, tn);
+    hipLaunchKernelGGL(gemm_bf3_tn_kernel<false>, dim3(8 * tm * r3d_cdiv(tn, 8)), dim3(512), lds, s, d, tm, tn);
     R3D_LAUNCH_CHECK();
     return R3D_OK;
 }

@@ -819,7 +819,7 @@ static int gemm_validate(const r3d_gemm_desc* d) {
     if (!d || !d->A || !d->B || !d->C) return R3D_EINVAL;
     if (d->M <= 0 || d->N <= 0 || d->K <= 0) return R3D_EINVAL;
     if (d->layout < 0 || d->layout > 2) return R3D_EINVAL;
-    if (d->tile < 1 || d->tile > 11) return R3D_EINVAL;
+    if (d->tile < 1 || d->tile > 12) return R3D_EINVAL;
     const int a_min = (d->layout == R3D_GEMM_TN) ? d->M : d->K;
     const int b_min = (d->layout == R3D_GEMM_NT) ? d->K : d->N;
     if (d->lda < a_min || d->ldb < b_min || d->ldc < d->N) return R3D_EINVAL;
@@ -833,7 +833,7 @@ static int gemm_validate(const r3d_gemm_desc* d) {
     if (d->bias_grad && (d->layout != R3D_GEMM_TN || d->splitk > 1)) return R3D_EINVAL;
     if (d->adam_m) {                     // AdamW epilogue: nothing else may want the product
         if (!d->adam_v || !d->adam_lr || !d->adam_step || d->splitk > 1) return R3D_EINVAL;
-        if (d->tile != 2 && d->tile != 3 && d->tile != 10) return R3D_EINVAL;   // tiles without k-split waves; the bf16x3 TN tile
+        if (d->tile != 2 && d->tile != 3 && d->tile != 10 && d->tile != 12) return R3D_EINVAL;   // tiles without k-split waves; the bf16x3 TN tile
         if ((d->N & 3) || (d->ldc & 3) || d->c_row_xor || d->alpha == 0.f) return R3D_EINVAL;
         if (!r3d_aligned16(d->C) || !r3d_aligned16(d->adam_m) || !r3d_aligned16(d->adam_v)) return R3D_EALIGN;
         if (d->bias || d->pre_out || d->act || d->drop_mask || d->mul || d->res1 || d->res2 || d->accumulate) return R3D_EINVAL;
@@ -915,7 +915,7 @@ R3D_EXPORT int r3d_gemm_plan(r3d_gemm_desc* d) {
         t.splitk = 1;
         // ... and beyond its 128 x 128 limit, the tiled kernel on the bf16 matrix cores (wide N, enough rows to amortise the split)
         if (d->prec == 1 && !wgrad_panel_ok(t) && d->N >= 2048 && d->K >= 64 && (long)d->M * d->K >= 128 * 128 && gemm_bf3_tn_ok(t)) {
-            d->tile = 10; d->splitk = 1; d->k_per_split = d->K;
+            d->tile = 12; d->splitk = 1; d->k_per_split = d->K;     // (12: tile 10's kernel with one LDS stage, two workgroups per CU)
             return R3D_OK;
         }
         if (wgrad_panel_ok(t)) {
@@ -944,7 +944,7 @@ R3D_EXPORT int r3d_gemm_f32(const r3d_gemm_desc* dp, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const int ns = nsplits_of(d);
     if (d.tile == 8 || d.tile == 9 || d.tile == 11) return launch_gemm_bf3_nt(d, s);          // long-K NT split-K on the bf16 matrix cores
-    if (d.tile == 10) return launch_gemm_bf3_tn(d, s);                        // wide TN (weight gradient) on the same
+    if (d.tile == 10 || d.tile == 12) return launch_gemm_bf3_tn(d, s);                        // wide TN (weight gradient) on the same
     if (d.tile == 7) {                   // the same panel kernel on the bf16 matrix cores (exact 3-way operand split)
         if (!wgrad_panel_ok(d) || (d.ldc & 3) || !r3d_aligned16(d.C)) return R3D_EINVAL;
         return launch_wgrad_panel_bf3(d, s);

@@ -1030,7 +1030,7 @@ class FusionEngine:
 
     def depth_adamw_fusable(self):
         """True when depth_projection.weight can be updated inside its weight-gradient kernel at a gain: one rank (its gradient
-        needs no exchange) and the product runs on the tiled bf16x3 TN kernel (tile 10: more than 128 token rows or hidden units),
+        needs no exchange) and the product runs on the tiled bf16x3 TN kernel (tiles 10 / 12: more than 128 token rows or hidden units),
         whose epilogue then streams parameter and moments while the rest of the chip multiplies -- the flat AdamW launch no
         longer reads and re-writes 86 % of the model (cfg4's per-GPU shape 1.127 -> 1.082 ms, cfg5's 1.644 -> 1.553; at the
         headline shape the product runs on the panel kernel, where fusing was measured neutral, so it stays off there)."""
@@ -1042,7 +1042,7 @@ class FusionEngine:
         if not hasattr(w, "_depth_tile"):
             w._depth_tile = ops.gemm_planned_tile(GEMM_TN, w.d_dep_pre, st["x_dep"], self.arena.p("depth_projection.weight"),
                                                   prec=self.depth_prec)
-        return w._depth_tile == 10
+        return w._depth_tile in (10, 12)
 
     def prepare_fused_adamw(self, cfg):
         """cfg: None or dict(lr, weight_decay[, betas, eps, grad_scale]); consumed by backward_depth_wgrad()."""

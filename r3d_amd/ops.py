@@ -120,7 +120,7 @@ def gemm(layout, a, b, c, *, ws=None, tile=0, splitk=0, defer_reduce=False, adam
         d.adam_beta1, d.adam_beta2, d.adam_eps = adam["beta1"], adam["beta2"], adam["eps"]
         d.adam_wd, d.adam_gscale = adam["weight_decay"], adam["grad_scale"]
         d.splitk, d.k_per_split = 1, K
-        if d.tile != 10:                                # (the bf16x3 TN tile has the epilogue itself)
+        if d.tile not in (10, 12) and tile not in (10, 12):     # (the bf16x3 TN tiles have the epilogue themselves)
             d.tile = 3 if d.tile in (3, 5) else 2       # the AdamW epilogue needs a tile without k-split waves
     if tile:
         d.tile = tile

@@ -582,8 +582,9 @@ def test_gemm_bf16x3_weight_gradient_panels(ops, K, M, N):
     assert float(big[:, N:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("tile", [0, 10])
 @pytest.mark.parametrize("K,M,N", [(512, 512, 50176), (256, 128, 19200), (2048, 1024, 4096), (100, 384, 4100), (130, 132, 2052)])
-def test_gemm_bf16x3_weight_gradient_tiled(ops, K, M, N):
+def test_gemm_bf16x3_weight_gradient_tiled(ops, K, M, N, tile):
     """TN product beyond the panel kernel's 128 x 128 limit (tile 10), with alpha and accumulate, against fp64."""
     from r3d_amd._lib import GEMM_TN
     a = rnd(K, M, seed=K + M) * 0.05
@@ -593,10 +594,10 @@ def test_gemm_bf16x3_weight_gradient_tiled(ops, K, M, N):
     scale = float(want.abs().max())
     c1, c0 = dev(c_init.clone()), dev(c_init.clone())
     ws = ops.GemmWorkspace("cuda")
-    d1 = ops.gemm(GEMM_TN, dev(a), dev(b), c1, ws=ws, prec=1, alpha=0.5, accumulate=True)
+    d1 = ops.gemm(GEMM_TN, dev(a), dev(b), c1, ws=ws, prec=1, alpha=0.5, accumulate=True, tile=tile)   # 0: the planner's (12)
     d0 = ops.gemm(GEMM_TN, dev(a), dev(b), c0, ws=ws, prec=0, alpha=0.5, accumulate=True)
     torch.cuda.synchronize()
-    assert d1.tile == 10 and d0.tile <= 5, (d1.tile, d0.tile)
+    assert d1.tile in (10, 12) and d0.tile <= 5, (d1.tile, d0.tile)
     e1 = float((c1.cpu().double() - want).abs().max()) / scale
     e0 = float((c0.cpu().double() - want).abs().max()) / scale
     assert e1 < 3e-6 and e1 < 4 * e0 + 3e-7, (e1, e0)
@@ -624,7 +625,7 @@ def test_gemm_bf16x3_weight_gradient_tiled_with_adamw_epilogue(ops, K, M, N):
         d0 = ops.gemm(GEMM_TN, a, b, g, ws=ws, prec=1, alpha=0.5)
         ops.adamw_flat(pr.view(-1), g.view(-1), mr.view(-1), vr.view(-1), lr_t, step_t, weight_decay=5e-3, grad_scale=0.25)
         torch.cuda.synchronize()
-        assert d1.tile == 10 and d0.tile == 10
+        assert d1.tile in (10, 12) and d0.tile in (10, 12)
         assert_close(mf.cpu(), mr.cpu(), 1e-6, 1e-9, f"step {step} exp_avg")
         assert_close(vf.cpu(), vr.cpu(), 1e-6, 1e-12, f"step {step} exp_avg_sq")
         assert_close(pf.cpu(), pr.cpu(), 1e-6, 1e-7, f"step {step} parameter")

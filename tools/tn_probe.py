@@ -9,8 +9,9 @@ a = torch.randn(K, M, device="cuda") * 0.05
 b = torch.rand(K, N, device="cuda")
 c = torch.empty(M, N, device="cuda")
 ws = ops.GemmWorkspace("cuda")
-d = ops.gemm(GEMM_TN, a, b, c, ws=ws, prec=1)
 ref = a.double().t() @ b.double()
-err = float((c.double() - ref).abs().max() / ref.abs().max())
-t = bench.time_kernel(lambda: ops.gemm(GEMM_TN, a, b, c, ws=ws, prec=1))
-print("TN", (K, M, N), "tile", d.tile, "us", round(t * 1e6, 1), "err", f"{err:.1e}", flush=True)
+for tile in (0, 12):                         # the planner's tile (10 at these shapes) and the two-workgroups-per-CU variant
+    d = ops.gemm(GEMM_TN, a, b, c, ws=ws, prec=1, tile=tile)
+    err = float((c.double() - ref).abs().max() / ref.abs().max())
+    t = bench.time_kernel(lambda: ops.gemm(GEMM_TN, a, b, c, ws=ws, prec=1, tile=tile))
+    print("TN", (K, M, N), "tile", d.tile, "us", round(t * 1e6, 1), "err", f"{err:.1e}", flush=True)
